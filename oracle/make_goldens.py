@@ -1,0 +1,305 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference + installed
+transformers) in the build container, and cross-check oracle/pianobart_oracle.py against it.
+
+Run:  python oracle/make_goldens.py          (only works where /root/reference exists)
+
+Nothing here travels as a dependency: the GPU box and the test-suite only read the
+committed .npz / .json vectors. TEST INFRASTRUCTURE ONLY.
+"""
+import hashlib
+import io
+import json
+import os
+import pickle
+import random
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from transformers import BartConfig as HFBartConfig, BartModel  # noqa: F401  (import first)
+sys.modules['transformers'].AdamW = torch.optim.AdamW               # removed upstream; pretrain.py:3
+sys.modules['shapesimilarity'] = types.ModuleType('shapesimilarity')
+sys.modules['shapesimilarity'].shape_similarity = lambda *a, **k: 0.0
+
+import PianoBart as ref_pb            # noqa: E402  reference
+import model as ref_model             # noqa: E402  reference
+import pretrain as ref_pretrain       # noqa: E402  reference
+
+from oracle import pianobart_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(GOLD, exist_ok=True)
+
+with open(os.path.join(REF, 'Data', 'Octuple.pkl'), 'rb') as f:
+    E2W, W2E = pickle.load(f)
+
+
+def sd_checksum(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd.keys()):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def cfg_pair(S, d, L, f, h, dropout=0.1):
+    kw = dict(max_position_embeddings=S, d_model=d, encoder_layers=L, decoder_layers=L,
+              encoder_ffn_dim=f, decoder_ffn_dim=f, encoder_attention_heads=h,
+              decoder_attention_heads=h, dropout=dropout)
+    return HFBartConfig(**kw), O.BartConfig(**kw)
+
+
+def build_pair(S, d, L, f, h, seed, dropout=0.1, lm=True):
+    """Oracle model with seeded, *non-trivial* weights; same weights loaded into the reference
+    with strict=True (this also pins the state_dict key layout, SURVEY b-3)."""
+    hf_cfg, o_cfg = cfg_pair(S, d, L, f, h, dropout)
+    o = O.PianoBart(o_cfg, E2W, W2E)
+    r = ref_pb.PianoBart(hf_cfg, E2W, W2E)
+    if lm:
+        o = O.PianoBartLM(o)
+        r = ref_model.PianoBartLM(r)
+    O_randomize(o, seed)
+    assert list(o.state_dict().keys()) == list(r.state_dict().keys()), "state_dict key order differs"
+    for (k1, v1), (k2, v2) in zip(o.state_dict().items(), r.state_dict().items()):
+        assert v1.shape == v2.shape, (k1, v1.shape, v2.shape)
+    r.load_state_dict(o.state_dict(), strict=True)
+    return o, r
+
+
+def O_randomize(model, seed):
+    from tests.golden_util import randomize_params
+    randomize_params(model, seed)
+
+
+def synth_batch(B, S, seed, min_len=None):
+    from tests.golden_util import synth_octuple_batch
+    return synth_octuple_batch(B, S, seed, min_len)
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def save(name, **arrs):
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def g_vocab():
+    out = os.path.join(ROOT, 'pianobart_amd', 'data')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'octuple_vocab.json'), 'w') as f:
+        json.dump({'e2w': E2W}, f)
+    print('vocab sha', hashlib.sha256(open(os.path.join(REF, 'Data', 'Octuple.pkl'), 'rb').read()).hexdigest()[:16])
+
+
+def g1_forward():
+    """G1/G2/G3: cfg-1 shape forward (eval), encoder-only branch, loss/acc/argmax."""
+    o, r = build_pair(128, 128, 2, 512, 4, seed=11)
+    o.eval(); r.eval()
+    enc, dec, loss_mask, emask, dmask, target = synth_batch(2, 128, seed=5)
+    # make one decoder row "padded then non-padded" 
+    dmask = dmask.clone(); dmask[1, 3] = 0
+    with torch.no_grad():
+        yo = o(enc, dec, emask, dmask)
+        yr = r(enc, dec, emask, dmask)
+        ho = o.pianobart(enc, dec, emask, dmask)
+        hr = r.pianobart(enc, dec, emask, dmask)
+        eo = o.pianobart(enc, None, emask, None)
+        er = r.pianobart(enc, None, emask, None)
+    for i in range(8):
+        assert rel(yo[i], yr[i]) < 2e-5, ('logits', i, rel(yo[i], yr[i]))
+    assert rel(ho.last_hidden_state, hr.last_hidden_state) < 2e-5
+    assert rel(ho.encoder_last_hidden_state, hr.encoder_last_hidden_state) < 2e-5
+    assert rel(eo.last_hidden_state, er.last_hidden_state) < 2e-5
+    tot_r, losses_r, accs_r, arg_r = O.pretrain_loss([t.clone() for t in yr], target, loss_mask, E2W)
+    # loss through the reference's own compute_loss (pretrain.py:112-118)
+    tr = ref_pretrain.Pretrainer.__new__(ref_pretrain.Pretrainer)
+    tr.loss_func = torch.nn.CrossEntropyLoss(reduction='none')
+    ref_losses = [tr.compute_loss(yr[i].permute(0, 2, 1), target[..., i], loss_mask[..., i]) for i in range(8)]
+    n_tok = [len(E2W[e]) for e in E2W]
+    ref_total = sum(l * w for l, w in zip(ref_losses, n_tok)) / sum(n_tok)
+    assert abs(float(ref_total) - float(tot_r)) < 1e-6
+    save('g1_forward_cfg1.npz', enc=enc.to(torch.int16), dec=dec.to(torch.int16), emask=emask, dmask=dmask,
+         loss_mask=loss_mask.to(torch.uint8), target=target.to(torch.int16),
+         logits=torch.cat(yr, dim=-1), hidden=hr.last_hidden_state,
+         enc_hidden=hr.encoder_last_hidden_state, enc_only_hidden=er.last_hidden_state,
+         total_loss=ref_total, head_losses=torch.stack(ref_losses), head_acc=torch.stack(accs_r),
+         argmax=arg_r.to(torch.int16), sd_sha=np.frombuffer(sd_checksum(r.state_dict()).encode(), dtype=np.uint8))
+
+
+def g4_grads():
+    """G4/G5: dropout=0 train step on the reference: grads of named tensors, global norm,
+    then one HF-AdamW step (restated formula; pinned transformers.AdamW absent) checksums."""
+    o, r = build_pair(64, 64, 2, 128, 4, seed=23, dropout=0.0)
+    o.train(); r.train()
+    enc, dec, loss_mask, emask, dmask, target = synth_batch(2, 64, seed=9)
+    names = ['pianobart.word_emb.0.lut.weight', 'pianobart.word_emb.5.lut.weight',
+             'pianobart.encoder_linear.weight', 'pianobart.encoder_linear.bias',
+             'pianobart.bart.encoder.embed_positions.weight',
+             'pianobart.bart.encoder.layernorm_embedding.weight',
+             'pianobart.bart.encoder.layers.0.self_attn.q_proj.weight',
+             'pianobart.bart.encoder.layers.1.fc1.bias',
+             'pianobart.bart.decoder.layers.0.encoder_attn.k_proj.weight',
+             'pianobart.bart.decoder.layers.1.encoder_attn.v_proj.bias',
+             'pianobart.bart.decoder.layers.1.self_attn.out_proj.weight',
+             'pianobart.bart.decoder.layers.1.final_layer_norm.bias',
+             'pianobart.bart.decoder.layers.0.fc2.weight',
+             'mask_lm.proj.2.weight', 'mask_lm.proj.7.bias']
+    outs = {}
+    for tag, m in (('o', o), ('r', r)):
+        m.zero_grad()
+        y = m(enc, dec, emask, dmask)
+        total, losses, accs, arg = O.pretrain_loss(y, target, loss_mask, E2W)
+        total.backward()
+        outs[tag] = (total.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert abs(float(outs['o'][0]) - float(outs['r'][0])) < 1e-5
+    for k in names:
+        assert rel(outs['o'][1][k], outs['r'][1][k]) < 5e-4, (k, rel(outs['o'][1][k], outs['r'][1][k]))
+    gr = outs['r'][1]
+    gnorm = torch.sqrt(sum((g.double() ** 2).sum() for g in gr.values())).float()
+    # per-parameter grad norms for every parameter (cheap, pins all of backward)
+    all_names = sorted(gr.keys())
+    per_norm = torch.stack([gr[k].double().norm().float() for k in all_names])
+    # clip + HF AdamW step on the reference's parameters
+    params = [p for k, p in r.named_parameters() if k in gr]
+    pnames = [k for k, p in r.named_parameters() if k in gr]
+    grads = [gr[k].clone() for k in pnames]
+    O.clip_grad_norm(grads, 3.0)
+    m1 = [torch.zeros_like(p) for p in params]
+    v1 = [torch.zeros_like(p) for p in params]
+    with torch.no_grad():
+        newp = [p.detach().clone() for p in params]
+        O.hf_adamw_step(newp, grads, m1, v1, step=1, lr=2e-5)
+        delta = torch.stack([(n - p).double().norm().float() for n, p in zip(newp, params)])
+        psum = torch.stack([n.double().sum().float() for n in newp])
+    save('g4_grads_small.npz', enc=enc.to(torch.int16), dec=dec.to(torch.int16), emask=emask, dmask=dmask,
+         loss_mask=loss_mask.to(torch.uint8), target=target.to(torch.int16), total_loss=outs['r'][0],
+         grad_norm=gnorm, per_param_grad_norm=per_norm,
+         param_names=np.array(all_names), step_param_names=np.array(pnames),
+         adamw_delta_norm=delta, adamw_param_sum=psum,
+         **{'grad__' + k: gr[k] for k in names})
+
+
+def g6_gen_mask():
+    """G6: exact gen_mask outputs of the reference under fixed seeds (seeds 0-4 x choices 1-5)."""
+    o, r = build_pair(64, 32, 1, 64, 4, seed=3, lm=False)
+    tr = ref_pretrain.Pretrainer.__new__(ref_pretrain.Pretrainer)
+    tr.pianobart = r
+    tr.max_seq_len = 64
+    tr.mask_percent = 0.15
+    tr.Lseq = list(range(64))
+    tr.Lseq_element = list(range(64 * 8))
+    tr.device = torch.device('cpu')
+    corr = O.Corruptor(o, 64, 0.15)
+    ids = synth_batch(1, 64, seed=17, min_len=64)[5][0].long()
+    out = {'ids': ids.to(torch.int16)}
+    for choice in range(1, 6):
+        for seed in range(5):
+            random.seed(seed); np.random.seed(seed)
+            mr, pr = tr.gen_mask(ids.clone(), choice)
+            random.seed(seed); np.random.seed(seed)
+            mo, po = corr.gen_mask(ids.clone(), choice)
+            mr_t = torch.as_tensor(np.asarray(mr)); pr_t = torch.as_tensor(np.asarray(pr))
+            assert mr_t.shape == mo.shape and bool((mr_t.double() == mo.double()).all()), (choice, seed)
+            assert bool((pr_t.double() == torch.as_tensor(np.asarray(po)).double()).all()), (choice, seed)
+            assert mr_t.dtype == mo.dtype, (choice, seed, mr_t.dtype, mo.dtype)
+            out['masked_c%d_s%d' % (choice, seed)] = mr_t.to(torch.int16)
+            out['pos_c%d_s%d' % (choice, seed)] = pr_t.to(torch.uint8)
+    # whole-batch construction (pretrain.py:127-153) under one seed
+    random.seed(7); np.random.seed(7)
+    batch = synth_batch(3, 64, seed=21)[5]
+    enc_o, dec_o, lm_o, em_o, dm_o = O.pretrain_batch(corr, batch)
+    out.update(batch=batch.to(torch.int16), batch_enc=enc_o.to(torch.int16), batch_dec=dec_o.to(torch.int16),
+               batch_loss_mask=lm_o.to(torch.uint8), batch_emask=em_o, batch_dmask=dm_o)
+    save('g6_gen_mask.npz', **out)
+
+
+def g7_sampling():
+    """G7: nucleus/sampling known answers and RNG stream position."""
+    rng = np.random.default_rng(4)
+    logits = torch.from_numpy(rng.normal(size=(6, 1, 40)).astype(np.float32) * 3)
+    res = {}
+    picks_ref, picks_o = [], []
+    np.random.seed(2023)
+    for i in range(6):
+        for p, t in ((1, 1.2), (0.9, 1.0), (0.9, 2.0)):
+            picks_ref.append(ref_model.sampling(logits[i], p, t))
+    after_ref = np.random.rand()
+    np.random.seed(2023)
+    for i in range(6):
+        for p, t in ((1, 1.2), (0.9, 1.0), (0.9, 2.0)):
+            picks_o.append(O.sampling(logits[i], p, t))
+    after_o = np.random.rand()
+    assert picks_ref == picks_o and after_ref == after_o
+    save('g7_sampling.npz', logits=logits, picks=np.array(picks_ref), rng_after=after_ref)
+
+
+def g8_generate():
+    """G8: generate trace (token ids) on a tiny model under np.random.seed(2023)."""
+    o, r = build_pair(24, 64, 2, 128, 4, seed=31)
+    o.eval(); r.eval()
+    enc, dec, loss_mask, emask, dmask, target = synth_batch(1, 24, seed=13, min_len=20)
+    with torch.no_grad():
+        np.random.seed(2023)
+        gr = r(enc, None, emask, None, generate=True)
+        np.random.seed(2023)
+        go = o(enc, None, emask, None, generate=True)
+        # pre-sampling logits at step 0 (decoder = SOS + PAD rows)
+        pad = torch.from_numpy(r.pianobart.pad_word_np)
+        d0 = pad.repeat(1, 24, 1); d0[:, 0, :] = torch.tensor(r.pianobart.sos_word_np)
+        dm0 = torch.zeros_like(emask); dm0[:, 0] = 1
+        step0 = torch.cat(r(enc, d0, emask, dm0), dim=-1)[:, 0]
+    assert bool((gr == go).all()), 'generate trace differs'
+    save('g8_generate.npz', enc=enc.to(torch.int16), emask=emask, tokens=gr.to(torch.int16), step0_logits=step0,
+         sd_sha=np.frombuffer(sd_checksum(r.state_dict()).encode(), dtype=np.uint8))
+
+
+def g9_state_dict():
+    """G9: key list + shapes for (2L,128) and (12L,768)."""
+    out = {}
+    for tag, (S, d, L, f, h) in {'cfg1': (128, 128, 2, 512, 4), 'cfg2': (1024, 768, 12, 3072, 12)}.items():
+        hf_cfg, _ = cfg_pair(S, d, L, f, h)
+        with torch.device('meta'):
+            r = ref_model.PianoBartLM(ref_pb.PianoBart(hf_cfg, E2W, W2E))
+        out[tag] = [[k, list(v.shape)] for k, v in r.state_dict().items()]
+        out[tag + '_n_params'] = sum(p.numel() for p in r.parameters())
+    with open(os.path.join(GOLD, 'g9_state_dict.json'), 'w') as f:
+        json.dump(out, f)
+    print('wrote g9_state_dict.json', out['cfg1_n_params'], out['cfg2_n_params'])
+
+
+def g10_cfg2_spot():
+    """G10: cfg-2 shape spot check, B=1 S=1024 eval forward on the reference."""
+    o, r = build_pair(1024, 768, 12, 3072, 12, seed=41)
+    r.eval()
+    enc, dec, loss_mask, emask, dmask, target = synth_batch(1, 1024, seed=19)
+    with torch.no_grad():
+        y = torch.cat(r(enc, dec, emask, dmask), dim=-1)[0]      # (1024,1280)
+    offs = np.cumsum([0] + r.pianobart.n_tokens)
+    arg = torch.stack([y[:, offs[i]:offs[i + 1]].argmax(-1) for i in range(8)], dim=-1)
+    # top-2 gap per head/position, so the test can skip near-ties
+    gap = torch.stack([(lambda t: t[:, 0] - t[:, 1])(y[:, offs[i]:offs[i + 1]].topk(2, dim=-1).values) for i in range(8)], dim=-1)
+    rows = np.linspace(0, 1023, 64).astype(np.int64)
+    save('g10_cfg2_spot.npz', argmax=arg.to(torch.int16), top2_gap=gap, rows=rows, logit_rows=y[rows],
+         logit_absmax=y.abs().max(), sd_sha=np.frombuffer(sd_checksum(r.state_dict()).encode(), dtype=np.uint8))
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['vocab', 'g1', 'g4', 'g6', 'g7', 'g8', 'g9', 'g10']
+    fns = dict(vocab=g_vocab, g1=g1_forward, g4=g4_grads, g6=g6_gen_mask, g7=g7_sampling, g8=g8_generate,
+               g9=g9_state_dict, g10=g10_cfg2_spot)
+    for w in which:
+        print('==', w)
+        fns[w]()
