@@ -1,0 +1,128 @@
+/* pianobart_hip.h -- C ABI of libpianobart_hip.so (gfx950 / MI355X).
+ *
+ * The reference (RS2002/PianoBart) has no FFI: its hot path is Python calling ATen ops through
+ * `transformers.BartModel`. This header is the boundary a maintainer binds
+ * instead (ctypes stub in INTEGRATION.md): one entry per op of SURVEY.md 2.2, plain pointers and
+ * sizes, a hipStream_t passed as void*, int status (0 = ok; otherwise pb_last_error() describes it).
+ * All pointers are DEVICE pointers unless stated. No global state besides the last-error string.
+ *
+ * Storage dtype of activations / weight shadows: PB_F32 (exact-f32 parity path, f32-input MFMA)
+ * or PB_BF16 (throughput path, bf16 MFMA, f32 accumulate). Statistics, loss, optimizer state,
+ * biases and LayerNorm parameters are always f32.
+ */
+#ifndef PIANOBART_HIP_H
+#define PIANOBART_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PB_F32 0
+#define PB_BF16 1
+
+#define PB_ABI_VERSION 1
+int pb_abi_version(void);
+const char* pb_last_error(void);
+
+/* ---- K3/K5/K6/K7/K8 (+ unfused attention products): C (+)= epi(alpha * A.B^T) ------------------
+ * Replaces nn.Linear forward/backward inside transformers BartAttention / Bart*Layer
+ * (modeling_bart.py:207,227-228,255,297-302) and model.py:124-125 (MLM heads); PianoBart.py:68,71.
+ * A(m,k): a_kcontig ? A[m*lda + k] : A[k*lda + m];  B(n,k): b_kcontig ? B[n*ldb + k] : B[k*ldb + n].
+ * Batched over nb1*nb2 problems with element strides s?1 / s?2. */
+#define PB_GEMM_ACCUM 1          /* C = C + result                                   */
+#define PB_GEMM_C_F32 2          /* C is float regardless of dtype                   */
+#define PB_GEMM_GELU 4           /* aux_out = pre-activation; C = gelu_erf(result)    */
+#define PB_GEMM_MUL_GELU_GRAD 8  /* C = result * gelu'(aux_in)                        */
+typedef struct pb_gemm_desc {
+    const void* A; const void* B; void* C;
+    const float* bias;            /* per-n, may be NULL */
+    const void* aux_in; void* aux_out; /* dtype storage, leading dim ldaux */
+    int32_t dtype, a_kcontig, b_kcontig, flags;
+    int32_t M, N, K, nb1, nb2, _pad;
+    int64_t lda, ldb, ldc, ldaux;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+    float alpha; float _pad2;
+} pb_gemm_desc;
+int pb_gemm(const pb_gemm_desc* d, void* stream);
+
+/* ---- K1/K2: Octuple gather-sum + position + LayerNorm (+dropout) -----------------------------
+ * Replaces PianoBart.py:60-71 (8 x Embedding*16 -> cat -> Linear) and modeling_bart.py:520-525 /
+ * 648-654 (x + pos[s+2] -> layernorm_embedding -> dropout). P is the projected table
+ * P[off_i + v] = 16 * E_i[v] @ W_lin[:, 256 i : 256 i + 256]^T  (1280 x d, f32), built with pb_gemm. */
+int pb_ids_to_i16(const int64_t* ids, int16_t* out, int64_t n, void* stream);
+int pb_embed_ln_fwd(const int16_t* ids16 /*(T,8)*/, const float* P, const int32_t* seg_off /*host, 8*/,
+                    const float* lin_bias, const float* pos /*(S+2,d)*/, const float* ln_w, const float* ln_b,
+                    void* y /*(T,d) dtype*/, float* mean, float* rstd, int32_t T, int32_t S, int32_t d,
+                    int32_t dtype, float eps, uint64_t seed, uint32_t site, float p_drop, void* stream);
+/* backward: dy -> dP (scatter-add, f32 atomics), dpos (S+2,d), dbias (d), dgamma/dbeta (d). */
+int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float* P, const int32_t* seg_off,
+                    const float* lin_bias, const float* pos, const float* ln_w, const float* mean,
+                    const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
+                    float* partials /*workspace, pb_ln_partials_floats()*/, int32_t T, int32_t S, int32_t d,
+                    int32_t dtype, uint64_t seed, uint32_t site, float p_drop, void* stream);
+
+/* ---- K5/K6 tail: y = LayerNorm(res + dropout(a)) ------------------------------------------------
+ * Replaces dropout + residual + LayerNorm of modeling_bart.py:292-294,300-302,362-364,377-379,386-388. */
+int64_t pb_ln_partials_floats(int32_t d);
+int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, const float* ln_b, void* y,
+                  float* mean, float* rstd, int32_t T, int32_t d, int32_t dtype, float eps,
+                  uint64_t seed, uint32_t site, float p_drop, void* stream);
+/* dres gets dz (accumulated into if accum_dres), da gets dz*dropmask; dgamma/dbeta/dbias_a are ADDED to. */
+int pb_add_ln_bwd(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
+                  const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
+                  float* partials, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32, int32_t accum_dres,
+                  uint64_t seed, uint32_t site, float p_drop, void* stream);
+
+/* ---- bias gradients: out[n] += sum_t dy[t][n] --------------------------------------------------*/
+/* partials: workspace of at least pb_colsum_partials_floats(N) floats */
+int64_t pb_colsum_partials_floats(int32_t N);
+int pb_colsum(const void* dy, int64_t ld, float* out, float* partials, int32_t T, int32_t N, int32_t dtype,
+              int32_t src_f32, void* stream);
+
+/* ---- K4 (unfused form, both dtypes): masked softmax over key axis -------------------------------
+ * scores (B,H,Sq,Sk) f32 = q.k^T (unscaled); P = softmax(scale*scores + mask); a query row with no
+ * visible key gives an all-zero row (transformers 5.x SDPA behaviour, oracle header).
+ * key_mask (B,Sk) float (!=0 keeps) or NULL; causal: key j visible to query i iff j <= i. */
+int pb_softmax_fwd(const float* scores, const float* key_mask, void* P, int32_t B, int32_t H, int32_t Sq,
+                   int32_t Sk, float scale, int32_t causal, int32_t dtype, void* stream);
+/* dS = scale * P * (dP - rowsum(dP*P)) written in dtype */
+int pb_softmax_bwd(const float* dP, const void* P, void* dS, int64_t rows, int32_t Sk, float scale,
+                   int32_t dtype, void* stream);
+
+/* ---- K9: fused 8-segment log-softmax + CE + argmax + masked accuracy (+ dlogits) ----------------
+ * Replaces pretrain.py:112-118,163-189 (np.argmax x8, CrossEntropyLoss x8, masked means).
+ * logits (T,V) f32 with the 8 heads at column offsets seg_off[i]; target (T,8) int16; loss_mask
+ * (T,8) f32. sums (3,8) f32 += {sum ce*m, sum m, sum correct*m}. If dlogits != NULL:
+ * dlogits[t, off_i+c] = coef[i] * m[t,i] * (softmax_c - 1[c==target]) in dtype, coef (8) device f32
+ * (= w_i / (sum_w * M_i)). argmax_out (T,8) int16 may be NULL. */
+int pb_ce_fwd_bwd(const float* logits, const int16_t* target, const float* loss_mask, const int32_t* seg_off /*host 9*/,
+                  float* sums, float* partials, const float* coef, void* dlogits, int16_t* argmax_out,
+                  int32_t T, int32_t V, int32_t dtype, void* stream);
+int64_t pb_ce_partials_floats(void);
+/* counts[i] = sum_t loss_mask[t,i]  (f32, 8) -- the M_i of pretrain.py:117 */
+int pb_mask_count(const float* loss_mask, float* counts, int64_t T, void* stream);
+/* coef[i] = w[i] / (sum_w * counts[i]) */
+int pb_loss_coef(const float* counts, const float* w /*device 8*/, float* coef, void* stream);
+
+/* ---- K10/K11: global grad norm, clip, HF-AdamW, bf16 shadow refresh --------------------------------
+ * Replaces clip_grad_norm_(.,3.0) (pretrain.py:195) and transformers.AdamW.step (pretrain.py:76,196;
+ * 4.29.2 formula: eps added to sqrt(v) before bias correction, decoupled decay after the update). */
+int64_t pb_norm_partials_floats(void);
+int pb_grad_sqnorm(const float* g, int64_t n, float* partials, float* out_sq /*1 float, overwritten*/, void* stream);
+/* clip_coef = min(1, max_norm / (sqrt(sq * gscale^2) + 1e-6)) * gscale */
+int pb_clip_coef(const float* sq, float max_norm, float gscale, float* coef, void* stream);
+int pb_adamw_step(float* p, const float* g, float* m, float* v, void* shadow /*bf16 or NULL*/, int64_t n,
+                  const float* clip_coef /*device, may be NULL*/, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, void* stream);
+int pb_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int pb_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+int pb_fill_f32(float* dst, float value, int64_t n, void* stream);
+
+/* ---- device-side corruption for the pre-train step (distributional counterpart of gen_mask's
+ * TokenMask n=0 branch, pretrain.py:276-295) and decoder shift-right (pretrain.py:132-139) ---------*/
+int pb_shift_right(const int16_t* ids, const int16_t* sos_row /*device 8*/, int16_t* out, int32_t B, int32_t S, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,90 @@
+"""ctypes binding of libpianobart_hip.so, generated from include/pianobart_hip.h.
+
+The product path has no CPU fallback: if the library is missing or fails to load, every op raises.
+"""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), 'include', 'pianobart_hip.h')
+LIB_PATH = os.path.join(HERE, 'libpianobart_hip.so')
+
+PB_F32, PB_BF16 = 0, 1
+GEMM_ACCUM, GEMM_C_F32, GEMM_GELU, GEMM_MUL_GELU_GRAD = 1, 2, 4, 8
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('C', ctypes.c_void_p),
+                ('bias', ctypes.c_void_p), ('aux_in', ctypes.c_void_p), ('aux_out', ctypes.c_void_p),
+                ('dtype', ctypes.c_int32), ('a_kcontig', ctypes.c_int32), ('b_kcontig', ctypes.c_int32), ('flags', ctypes.c_int32),
+                ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('nb1', ctypes.c_int32),
+                ('nb2', ctypes.c_int32), ('_pad', ctypes.c_int32),
+                ('lda', ctypes.c_int64), ('ldb', ctypes.c_int64), ('ldc', ctypes.c_int64), ('ldaux', ctypes.c_int64),
+                ('sA1', ctypes.c_int64), ('sA2', ctypes.c_int64), ('sB1', ctypes.c_int64), ('sB2', ctypes.c_int64),
+                ('sC1', ctypes.c_int64), ('sC2', ctypes.c_int64),
+                ('alpha', ctypes.c_float), ('_pad2', ctypes.c_float)]
+
+
+_SCALARS = {'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64,
+            'uint32_t': ctypes.c_uint32, 'float': ctypes.c_float, 'int': ctypes.c_int}
+
+
+def parse_header(path=HEADER):
+    """Returns {name: (restype, [argtypes])} for every function the header declares."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    src = re.sub(r'//[^\n]*', ' ', src)
+    src = re.sub(r'typedef\s+struct.*?}\s*\w+\s*;', ' ', src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r'(const\s+char\s*\*|int64_t|int)\s+(pb_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if 'char' in ret else _SCALARS[ret.strip()]
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(ctypes.POINTER(GemmDesc) if 'pb_gemm_desc' in a else ctypes.c_void_p)
+                else:
+                    argtypes.append(_SCALARS[a.replace('const', '').split()[0]])
+        decls[name] = (restype, argtypes)
+    return decls
+
+
+class PBError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self.decls = parse_header()
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise PBError('libpianobart_hip.so is not built (%s); run `python -c "import __graft_entry__ as g; g.build()"` '
+                              'or `python pianobart_amd/build.py`. There is no CPU fallback.' % LIB_PATH)
+            dll = ctypes.CDLL(LIB_PATH)
+            for name, (restype, argtypes) in self.decls.items():
+                fn = getattr(dll, name)          # AttributeError => header/library mismatch: fail loudly
+                fn.restype = restype
+                fn.argtypes = argtypes
+            ver = dll.pb_abi_version()
+            if ver != 1:
+                raise PBError('ABI version mismatch: library %d, binding 1' % ver)
+            self._dll = dll
+        return self._dll
+
+    def call(self, name, *args):
+        dll = self.load()
+        rc = getattr(dll, name)(*args)
+        if rc != 0:
+            raise PBError('%s failed (%d): %s' % (name, rc, dll.pb_last_error().decode()))
+
+    def query(self, name, *args):
+        return getattr(self.load(), name)(*args)
+
+
+LIB = _Lib()

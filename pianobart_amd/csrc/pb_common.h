@@ -1,0 +1,100 @@
+// Shared device helpers for the PianoBART gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PB_WAVE 64
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- error reporting (host) -------------------------------------------------
+extern "C" const char* pb_last_error(void);
+void pb_set_error(const char* fmt, ...);
+#define PB_CHECK_HIP(expr)                                                     \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) {                                                \
+            pb_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -1;                                                         \
+        }                                                                      \
+    } while (0)
+#define PB_REQUIRE(cond, ...)                                                  \
+    do {                                                                       \
+        if (!(cond)) { pb_set_error(__VA_ARGS__); return -2; }                 \
+    } while (0)
+#define PB_LAUNCH_CHECK() PB_CHECK_HIP(hipGetLastError())
+
+// ---- scalar conversions -------------------------------------------------------
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }  // v_cvt_pk_bf16_f32, RNE, NaN-safe
+
+// ---- 4-element vector load/store as float (8 B for bf16, 16 B for f32) -----------
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+    bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = r;
+}
+
+// ---- wave64 reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- exact-erf GELU (activation_function="gelu") -----------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- counter-based RNG for dropout: Philox4x32-7 -----------------------------------
+// One call yields 4 x 32 random bits for the 4 consecutive elements [4*idx4, 4*idx4+3] of a
+// dropout site. Forward and backward regenerate the same mask from (seed, site, idx4).
+__device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+struct DropCfg {
+    uint32_t seed_lo, seed_hi;   // per-step seed
+    uint32_t site;               // unique id of the dropout site inside a step
+    uint32_t thresh;             // drop if rnd < thresh  (thresh = p * 2^32); 0 => dropout off
+    float scale;                 // 1/(1-p)
+};
+__device__ __forceinline__ f32x4 drop_mask4(const DropCfg& d, uint32_t idx4) {
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (d.thresh == 0u) return m;
+    const uint4 r = philox4x32(idx4, d.site, 0x5EEDu, 0u, d.seed_lo, d.seed_hi);
+    m[0] = r.x < d.thresh ? 0.f : d.scale;
+    m[1] = r.y < d.thresh ? 0.f : d.scale;
+    m[2] = r.z < d.thresh ? 0.f : d.scale;
+    m[3] = r.w < d.thresh ? 0.f : d.scale;
+    return m;
+}

@@ -1,0 +1,130 @@
+// K9: fused 8-head (segmented) log-softmax + cross-entropy + argmax + masked accuracy, with the
+// gradient w.r.t. the logits produced in the same pass. Replaces pretrain.py:163-189: 8 full-logit
+// D2H copies + np.argmax, 8 x (permute + CrossEntropyLoss(reduction='none') * mask, sum/sum).
+// One wave64 per token row of V = sum n_i logits (f32); lane i < 8 carries head i's scalars.
+#include "pb_common.h"
+#include "pb_api_internal.h"
+
+namespace {
+
+struct Seg9 { int off[9]; };
+constexpr int CE_MAX_BLOCKS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int16_t* __restrict__ target,
+        const float* __restrict__ loss_mask, const Seg9 so, float* __restrict__ partials, const float* __restrict__ coef,
+        T* __restrict__ dlogits, int16_t* __restrict__ argmax_out, int rows, int V) {
+    __shared__ float red[4][24];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a_ce = 0.f, a_m = 0.f, a_ok = 0.f;       // lane i<8: running sums of head i
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float* x = logits + row * V;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = so.off[i], n = so.off[i + 1] - o;
+            const int tgt = target[row * 8 + i];
+            const float m = loss_mask[row * 8 + i];
+            // max + first-argmax (np.argmax tie rule: lowest index)
+            float mx = -INFINITY; int am = 0x7fffffff;
+            for (int c = lane; c < n; c += 64) {
+                const float v = x[o + c];
+                if (v > mx) { mx = v; am = c; }
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                const float ov = __shfl_xor(mx, sft, 64);
+                const int oa = __shfl_xor(am, sft, 64);
+                if (ov > mx || (ov == mx && oa < am)) { mx = ov; am = oa; }
+            }
+            float se = 0.f;
+            for (int c = lane; c < n; c += 64) se += __expf(x[o + c] - mx);
+            se = wave_sum(se);
+            const float xt = (tgt >= 0 && tgt < n) ? x[o + tgt] : 0.f;
+            const float ce = __logf(se) + mx - xt;
+            if (lane == i) {
+                a_ce += ce * m; a_m += m; a_ok += (am == tgt ? 1.f : 0.f) * m;
+                if (argmax_out) argmax_out[row * 8 + i] = (int16_t)am;
+            }
+            if (dlogits) {
+                const float k = m != 0.f ? coef[i] * m : 0.f;
+                const float inv = 1.0f / se;
+                T* g = dlogits + row * V + o;
+                for (int c = lane; c < n; c += 64) {
+                    const float pr = __expf(x[o + c] - mx) * inv;
+                    g[c] = from_f<T>(k * (pr - (c == tgt ? 1.f : 0.f)));
+                }
+            }
+        }
+    }
+    if (lane < 8) { red[wave][lane] = a_ce; red[wave][8 + lane] = a_m; red[wave][16 + lane] = a_ok; }
+    __syncthreads();
+    if (threadIdx.x < 24)
+        partials[(size_t)blockIdx.x * 24 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void ce_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ sums) {
+    const int k = threadIdx.x;
+    if (k >= 24) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * 24 + k];
+    sums[k] += s;
+}
+
+__global__ void mask_count_kernel(const float* __restrict__ loss_mask, float* __restrict__ counts, long T) {
+    // single block, deterministic: thread t sums column (t & 7) over a strided set of rows
+    __shared__ float red[256];
+    const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    float s = 0.f;
+    for (long r = r0; r < T; r += 32) s += loss_mask[r * 8 + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[k * 8 + threadIdx.x];
+        counts[threadIdx.x] = t;
+    }
+}
+
+__global__ void loss_coef_kernel(const float* __restrict__ counts, const float* __restrict__ w, float* __restrict__ coef) {
+    const int i = threadIdx.x;
+    if (i >= 8) return;
+    float sw = 0.f;
+    for (int k = 0; k < 8; ++k) sw += w[k];
+    coef[i] = w[i] / (sw * counts[i]);
+}
+
+}  // namespace
+
+extern "C" int64_t pb_ce_partials_floats(void) { return (int64_t)CE_MAX_BLOCKS * 24; }
+
+extern "C" int pb_ce_fwd_bwd(const float* logits, const int16_t* target, const float* loss_mask, const int32_t* seg_off,
+                             float* sums, float* partials, const float* coef, void* dlogits, int16_t* argmax_out, int32_t T,
+                             int32_t V, int32_t dtype, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (T <= 0) return 0;
+    PB_REQUIRE(seg_off[8] == V && seg_off[0] == 0, "pb_ce_fwd_bwd: segment offsets do not cover V=%d", V);
+    PB_REQUIRE(dlogits == nullptr || coef != nullptr, "pb_ce_fwd_bwd: dlogits needs coef");
+    Seg9 so;
+    for (int i = 0; i < 9; ++i) so.off[i] = seg_off[i];
+    const int grid = max(1, min(CE_MAX_BLOCKS, (T + 3) / 4));
+    if (dtype == PB_BF16)
+        hipLaunchKernelGGL((ce_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, logits, target, loss_mask, so, partials, coef, (bf16_t*)dlogits, argmax_out, T, V);
+    else
+        hipLaunchKernelGGL((ce_kernel<float>), dim3(grid), dim3(256), 0, stream, logits, target, loss_mask, so, partials, coef, (float*)dlogits, argmax_out, T, V);
+    PB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(32), 0, stream, partials, grid, sums);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_mask_count(const float* loss_mask, float* counts, int64_t T, void* stream_) {
+    hipLaunchKernelGGL(mask_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, loss_mask, counts, (long)T);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_loss_coef(const float* counts, const float* w, float* coef, void* stream_) {
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, counts, w, coef);
+    PB_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,451 @@
+// Row kernels of the PianoBART step (HBM-bound, one wave64 per token row, rows kept in registers):
+//   * Octuple gather-sum + position + LayerNorm (+dropout)            [K1/K2]  fwd / bwd
+//   * y = LayerNorm(res + dropout(a))                                 [K5/K6]  fwd / bwd
+//   * column sums for bias gradients
+// A lane owns columns {4*(lane + 64*it) .. +3}; NIT = ceil(d/256) is a template parameter so the
+// row lives in registers. Parameter-gradient reductions (dgamma, dbeta, dbias) are accumulated in
+// registers over a grid-stride loop of rows, reduced across the 4 waves through LDS, written as
+// per-block partials and summed by a second tiny kernel: deterministic, no atomics.
+#include "pb_common.h"
+#include "pb_api_internal.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256, LN_WAVES = 4, LN_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
+    DropCfg d;
+    d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32); d.site = site;
+    d.thresh = p > 0.f ? (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f) : 0u;
+    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
+}
+
+// ------------------------------------------------------------------ LayerNorm core (registers)
+template <int NIT>
+__device__ __forceinline__ void ln_stats(const f32x4 (&z)[NIT], int lane, int d4, int d, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+        if (lane + 64 * it < d4) s += z[it][0] + z[it][1] + z[it][2] + z[it][3];
+    mean = wave_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+        if (lane + 64 * it < d4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float c = z[it][j] - mean; q += c * c; }
+        }
+    rstd = rsqrtf(wave_sum(q) / d + eps);
+}
+
+// ------------------------------------------------------------------ y = LN(res + drop(a))
+template <typename T, int NIT>
+__global__ __launch_bounds__(LN_THREADS) void add_ln_fwd_kernel(const T* __restrict__ res, const T* __restrict__ a,
+        const float* __restrict__ w, const float* __restrict__ b, T* __restrict__ y, float* __restrict__ mean_o,
+        float* __restrict__ rstd_o, int rows, int d, float eps, uint64_t seed, uint32_t site, float p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
+    const DropCfg dc = make_drop(seed, site, p);
+    for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
+        f32x4 z[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = lane + 64 * it;
+            if (c4 < d4) {
+                const f32x4 r = load4(res + row * d + 4 * c4);
+                const f32x4 x = load4(a + row * d + 4 * c4);
+                const f32x4 m = drop_mask4(dc, (uint32_t)(row * d4 + c4));
+                z[it] = r + x * m;
+            }
+        }
+        float mean, rstd;
+        ln_stats<NIT>(z, lane, d4, d, eps, mean, rstd);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = lane + 64 * it;
+            if (c4 < d4) {
+                const f32x4 g = load4(w + 4 * c4), be = load4(b + 4 * c4);
+                store4(y + row * d + 4 * c4, (z[it] - mean) * rstd * g + be);
+            }
+        }
+        if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    }
+}
+
+// Cross-wave reduction of NACC per-lane accumulators and partial write: partials[blk][k][d].
+template <int NIT, int NACC>
+__device__ __forceinline__ void write_partials(f32x4 (&acc)[NACC][NIT], float* __restrict__ partials, int d, float* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = lane + 64 * it;
+            if (c4 < d4) *reinterpret_cast<f32x4*>(lds + (size_t)wave * d + 4 * c4) = acc[k][it];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < d; c += LN_THREADS) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < LN_WAVES; ++wv) s += lds[(size_t)wv * d + c];
+            partials[((size_t)blockIdx.x * NACC + k) * d + c] = s;
+        }
+    }
+}
+
+template <typename T, typename TR, int NIT>
+__global__ __launch_bounds__(LN_THREADS) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ res,
+        const T* __restrict__ a, const float* __restrict__ w, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+        TR* __restrict__ dres, T* __restrict__ da, float* __restrict__ partials, int rows, int d, int accum_dres,
+        uint64_t seed, uint32_t site, float p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
+    const DropCfg dc = make_drop(seed, site, p);
+    f32x4 acc[3][NIT];   // 0: dgamma, 1: dbeta, 2: dbias_a (column sum of da)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) acc[k][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        f32x4 xh[NIT], g[NIT], msk[NIT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = lane + 64 * it;
+            if (c4 < d4) {
+                const f32x4 r = load4(res + row * d + 4 * c4);
+                const f32x4 x = load4(a + row * d + 4 * c4);
+                msk[it] = drop_mask4(dc, (uint32_t)(row * d4 + c4));
+                xh[it] = (r + x * msk[it] - mean) * rstd;
+                const f32x4 dyv = load4(dy + row * d + 4 * c4);
+                g[it] = dyv * load4(w + 4 * c4);
+                acc[0][it] += dyv * xh[it];
+                acc[1][it] += dyv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1 += g[it][j]; s2 += g[it][j] * xh[it][j]; }
+            }
+        }
+        s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = lane + 64 * it;
+            if (c4 < d4) {
+                const f32x4 dz = (g[it] - s1 - xh[it] * s2) * rstd;
+                const f32x4 dav = dz * msk[it];
+                acc[2][it] += dav;
+                f32x4 o = dz;
+                if (accum_dres) o += load4(dres + row * d + 4 * c4);
+                store4(dres + row * d + 4 * c4, o);
+                if (da) store4(da + row * d + 4 * c4, dav);
+            }
+        }
+    }
+    write_partials<NIT, 3>(acc, partials, d, lds);
+}
+
+// out_k[c] += sum_blk partials[blk][k][c]   for k < nacc (NULL outputs skipped)
+__global__ void finalize_partials_kernel(const float* __restrict__ partials, int nblk, int nacc, int d,
+                                         float* o0, float* o1, float* o2, float* o3) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (c >= d) return;
+    float* o = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
+    if (!o) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partials[((size_t)b * nacc + k) * d + c];
+    o[c] += s;
+}
+
+// ------------------------------------------------------------------ Octuple embed + pos + LN
+struct SegOff { int off[8]; };
+
+template <int NIT>
+__device__ __forceinline__ void embed_row(f32x4 (&z)[NIT], const int16_t* __restrict__ ids16, const float* __restrict__ P,
+                                          const SegOff& so, const float* __restrict__ lin_bias, const float* __restrict__ pos,
+                                          long row, int S, int d, int lane) {
+    const int d4 = d >> 2;
+    // one 16-byte load of the 8 int16 ids of this token, broadcast over the wave
+    const uint4 raw = *reinterpret_cast<const uint4*>(ids16 + row * 8);
+    int id[8];
+    id[0] = (int)(raw.x & 0xffff); id[1] = (int)(raw.x >> 16); id[2] = (int)(raw.y & 0xffff); id[3] = (int)(raw.y >> 16);
+    id[4] = (int)(raw.z & 0xffff); id[5] = (int)(raw.z >> 16); id[6] = (int)(raw.w & 0xffff); id[7] = (int)(raw.w >> 16);
+    const int s = (int)(row % S);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c4 = lane + 64 * it;
+        if (c4 < d4) {
+            f32x4 v = load4(lin_bias + 4 * c4) + load4(pos + (size_t)(s + 2) * d + 4 * c4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v += load4(P + (size_t)(so.off[i] + id[i]) * d + 4 * c4);
+            z[it] = v;
+        }
+    }
+}
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(LN_THREADS) void embed_ln_fwd_kernel(const int16_t* __restrict__ ids16, const float* __restrict__ P,
+        const SegOff so, const float* __restrict__ lin_bias, const float* __restrict__ pos, const float* __restrict__ w,
+        const float* __restrict__ b, T* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+        int rows, int S, int d, float eps, uint64_t seed, uint32_t site, float p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
+    const DropCfg dc = make_drop(seed, site, p);
+    for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
+        f32x4 z[NIT];
+        embed_row<NIT>(z, ids16, P, so, lin_bias, pos, row, S, d, lane);
+        float mean, rstd;
+        ln_stats<NIT>(z, lane, d4, d, eps, mean, rstd);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = lane + 64 * it;
+            if (c4 < d4) {
+                const f32x4 g = load4(w + 4 * c4), be = load4(b + 4 * c4);
+                const f32x4 m = drop_mask4(dc, (uint32_t)(row * d4 + c4));     // dropout AFTER the LN here
+                store4(y + row * d + 4 * c4, ((z[it] - mean) * rstd * g + be) * m);
+            }
+        }
+        if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    }
+}
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(const T* __restrict__ dy, const int16_t* __restrict__ ids16,
+        const float* __restrict__ P, const SegOff so, const float* __restrict__ lin_bias, const float* __restrict__ pos,
+        const float* __restrict__ w, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+        float* __restrict__ dP, float* __restrict__ dpos, float* __restrict__ partials,
+        int rows, int S, int d, uint64_t seed, uint32_t site, float p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
+    const DropCfg dc = make_drop(seed, site, p);
+    f32x4 acc[3][NIT];   // 0: dgamma, 1: dbeta, 2: dbias (column sum of dz)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) acc[k][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        f32x4 z[NIT], g[NIT];
+        embed_row<NIT>(z, ids16, P, so, lin_bias, pos, row, S, d, lane);
+        float s1 = 0.f, s2 = 0.f, nz = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = lane + 64 * it;
+            if (c4 < d4) {
+                z[it] = (z[it] - mean) * rstd;                                   // xhat
+                const f32x4 m = drop_mask4(dc, (uint32_t)(row * d4 + c4));
+                const f32x4 dyv = load4(dy + row * d + 4 * c4) * m;
+                g[it] = dyv * load4(w + 4 * c4);
+                acc[0][it] += dyv * z[it];
+                acc[1][it] += dyv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1 += g[it][j]; s2 += g[it][j] * z[it][j]; nz += fabsf(dyv[j]); }
+            }
+        }
+        s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d; nz = wave_sum(nz);
+        if (nz == 0.f) continue;        // rows that received no gradient (PAD tail) add exact zeros: skip the atomics
+        const uint4 raw = *reinterpret_cast<const uint4*>(ids16 + row * 8);
+        int id[8];
+        id[0] = (int)(raw.x & 0xffff); id[1] = (int)(raw.x >> 16); id[2] = (int)(raw.y & 0xffff); id[3] = (int)(raw.y >> 16);
+        id[4] = (int)(raw.z & 0xffff); id[5] = (int)(raw.z >> 16); id[6] = (int)(raw.w & 0xffff); id[7] = (int)(raw.w >> 16);
+        const int s = (int)(row % S);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = lane + 64 * it;
+            if (c4 < d4) {
+                const f32x4 dz = (g[it] - s1 - z[it] * s2) * rstd;
+                acc[2][it] += dz;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    atomicAdd(dpos + (size_t)(s + 2) * d + 4 * c4 + j, dz[j]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) atomicAdd(dP + (size_t)(so.off[i] + id[i]) * d + 4 * c4 + j, dz[j]);
+                }
+            }
+        }
+    }
+    write_partials<NIT, 3>(acc, partials, d, lds);
+}
+
+// ------------------------------------------------------------------ column sums (bias grads)
+// grid (ceil(N/256), nrb): thread owns one column over a row block.
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ dy, long ld, float* __restrict__ partials, int rows, int N, int rows_per_blk) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += to_f(dy[(long)r * ld + c]);
+    partials[(size_t)blockIdx.y * N + c] = s;
+}
+
+int ln_grid(int rows) { return max(1, min((rows + LN_WAVES - 1) / LN_WAVES, LN_MAX_BLOCKS)); }
+
+}  // namespace
+
+#define PB_LN_DISPATCH(NITV, ...)                        \
+    switch (NITV) {                                      \
+        case 1: { constexpr int NIT = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int NIT = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int NIT = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int NIT = 4; __VA_ARGS__; } break; \
+        default: { constexpr int NIT = 8; __VA_ARGS__; } break; \
+    }
+
+static int check_ln_dims(const char* who, int T, int d) {
+    PB_REQUIRE(T >= 0 && d > 0 && d % 4 == 0 && d <= 2048, "%s: d=%d must be a multiple of 4 and <= 2048", who, d);
+    return 0;
+}
+static int nit_for(int d) { const int n = (d / 4 + 63) / 64; return n <= 4 ? n : 8; }
+
+extern "C" int64_t pb_ln_partials_floats(int32_t d) { return (int64_t)LN_MAX_BLOCKS * 3 * d; }
+
+extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, const float* ln_b, void* y, float* mean,
+                             float* rstd, int32_t T, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
+                             float p_drop, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (check_ln_dims("pb_add_ln_fwd", T, d)) return -2;
+    if (T == 0) return 0;
+    const int grid = ln_grid(T);
+    PB_LN_DISPATCH(nit_for(d),
+        if (dtype == PB_BF16)
+            hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, (const bf16_t*)res,
+                               (const bf16_t*)a, ln_w, ln_b, (bf16_t*)y, mean, rstd, T, d, eps, seed, site, p_drop);
+        else
+            hipLaunchKernelGGL((add_ln_fwd_kernel<float, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, (const float*)res,
+                               (const float*)a, ln_w, ln_b, (float*)y, mean, rstd, T, d, eps, seed, site, p_drop));
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_finalize(const float* partials, int nblk, int nacc, int d, float* o0, float* o1, float* o2, float* o3,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(finalize_partials_kernel, dim3((d + 255) / 256, nacc), dim3(256), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_add_ln_bwd(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
+                             const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
+                             float* partials, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32, int32_t accum_dres,
+                             uint64_t seed, uint32_t site, float p_drop, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (check_ln_dims("pb_add_ln_bwd", T, d)) return -2;
+    if (T == 0) return 0;
+    const int grid = ln_grid(T);
+    const size_t lds = (size_t)LN_WAVES * d * sizeof(float);
+    PB_LN_DISPATCH(nit_for(d),
+        if (dtype == PB_BF16) {
+            if (dres_f32)
+                hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, float, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream,
+                                   (const bf16_t*)dy, (const bf16_t*)res, (const bf16_t*)a, ln_w, mean, rstd, (float*)dres,
+                                   (bf16_t*)da, partials, T, d, accum_dres, seed, site, p_drop);
+            else
+                hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream,
+                                   (const bf16_t*)dy, (const bf16_t*)res, (const bf16_t*)a, ln_w, mean, rstd, (bf16_t*)dres,
+                                   (bf16_t*)da, partials, T, d, accum_dres, seed, site, p_drop);
+        } else {
+            hipLaunchKernelGGL((add_ln_bwd_kernel<float, float, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream,
+                               (const float*)dy, (const float*)res, (const float*)a, ln_w, mean, rstd, (float*)dres,
+                               (float*)da, partials, T, d, accum_dres, seed, site, p_drop);
+        });
+    PB_LAUNCH_CHECK();
+    return launch_finalize(partials, grid, 3, d, dgamma, dbeta, dbias_a, nullptr, stream);
+}
+
+extern "C" int pb_embed_ln_fwd(const int16_t* ids16, const float* P, const int32_t* seg_off, const float* lin_bias,
+                               const float* pos, const float* ln_w, const float* ln_b, void* y, float* mean, float* rstd,
+                               int32_t T, int32_t S, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
+                               float p_drop, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (check_ln_dims("pb_embed_ln_fwd", T, d)) return -2;
+    PB_REQUIRE(S > 0 && T % S == 0, "pb_embed_ln_fwd: T=%d not a multiple of S=%d", T, S);
+    if (T == 0) return 0;
+    SegOff so;
+    for (int i = 0; i < 8; ++i) so.off[i] = seg_off[i];
+    const int grid = ln_grid(T);
+    PB_LN_DISPATCH(nit_for(d),
+        if (dtype == PB_BF16)
+            hipLaunchKernelGGL((embed_ln_fwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, ids16, P, so, lin_bias,
+                               pos, ln_w, ln_b, (bf16_t*)y, mean, rstd, T, S, d, eps, seed, site, p_drop);
+        else
+            hipLaunchKernelGGL((embed_ln_fwd_kernel<float, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, ids16, P, so, lin_bias,
+                               pos, ln_w, ln_b, (float*)y, mean, rstd, T, S, d, eps, seed, site, p_drop));
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float* P, const int32_t* seg_off,
+                               const float* lin_bias, const float* pos, const float* ln_w, const float* mean,
+                               const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
+                               float* partials, int32_t T, int32_t S, int32_t d, int32_t dtype, uint64_t seed,
+                               uint32_t site, float p_drop, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (check_ln_dims("pb_embed_ln_bwd", T, d)) return -2;
+    PB_REQUIRE(S > 0 && T % S == 0, "pb_embed_ln_bwd: T=%d not a multiple of S=%d", T, S);
+    if (T == 0) return 0;
+    SegOff so;
+    for (int i = 0; i < 8; ++i) so.off[i] = seg_off[i];
+    const int grid = ln_grid(T);
+    const size_t lds = (size_t)LN_WAVES * d * sizeof(float);
+    PB_LN_DISPATCH(nit_for(d),
+        if (dtype == PB_BF16)
+            hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream, (const bf16_t*)dy,
+                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, T, S, d, seed, site, p_drop);
+        else
+            hipLaunchKernelGGL((embed_ln_bwd_kernel<float, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream, (const float*)dy,
+                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, T, S, d, seed, site, p_drop));
+    PB_LAUNCH_CHECK();
+    return launch_finalize(partials, grid, 3, d, dgamma, dbeta, dbias, nullptr, stream);
+}
+
+extern "C" int64_t pb_colsum_partials_floats(int32_t N) { return (int64_t)256 * N; }
+
+extern "C" int pb_colsum(const void* dy, int64_t ld, float* out, float* partials, int32_t T, int32_t N, int32_t dtype,
+                         int32_t src_f32, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PB_REQUIRE(T >= 0 && N > 0, "pb_colsum: bad shape");
+    if (T == 0) return 0;
+    const int nrb = max(1, min(256, (T + 63) / 64));
+    const int rpb = (T + nrb - 1) / nrb;
+    dim3 grid((N + 255) / 256, nrb);
+    if (src_f32 || dtype == PB_F32)
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, stream, (const float*)dy, (long)ld, partials, T, N, rpb);
+    else
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (long)ld, partials, T, N, rpb);
+    PB_LAUNCH_CHECK();
+    return launch_finalize(partials, nrb, 1, N, out, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int pb_ids_to_i16(const int64_t* ids, int16_t* out, int64_t n, void* stream_);
+namespace {
+__global__ void ids_to_i16_kernel(const int64_t* __restrict__ ids, int16_t* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (int16_t)ids[i];
+}
+__global__ void shift_right_kernel(const int16_t* __restrict__ ids, const int16_t* __restrict__ sos, int16_t* __restrict__ out, int B, int S) {
+    const long n = (long)B * S * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 7);
+        const long tok = i >> 3;
+        const int s = (int)(tok % S);
+        out[i] = s == 0 ? sos[c] : ids[i - 8];
+    }
+}
+}  // namespace
+extern "C" int pb_ids_to_i16(const int64_t* ids, int16_t* out, int64_t n, void* stream_) {
+    if (n <= 0) return 0;
+    const int grid = (int)min((long)2048, (long)((n + 255) / 256));
+    hipLaunchKernelGGL(ids_to_i16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, ids, out, (long)n);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pb_shift_right(const int16_t* ids, const int16_t* sos_row, int16_t* out, int32_t B, int32_t S, void* stream_) {
+    const long n = (long)B * S * 8;
+    if (n <= 0) return 0;
+    const int grid = (int)min((long)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(shift_right_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, ids, sos_row, out, B, S);
+    PB_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,150 @@
+// K10/K11: multi-tensor (flat-buffer) gradient norm, clip coefficient, HF-AdamW step with bf16
+// shadow refresh, and casts. All HBM-bound streaming kernels over ONE flat f32 buffer per role
+// (params / grads / exp_avg / exp_avg_sq), float4 per lane, grid-stride, <= 2048 workgroups.
+// HF AdamW (transformers 4.29.2 optimization.py, pretrain.py:76,196), per element:
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v)+eps)
+//   p -= lr * wd * p        (decoupled decay AFTER the update)
+#include "pb_common.h"
+#include "pb_api_internal.h"
+#include <cmath>
+
+namespace {
+
+constexpr int OPT_BLOCKS = 2048, OPT_THREADS = 256;
+
+__global__ __launch_bounds__(OPT_THREADS) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ partials) {
+    __shared__ float red[OPT_THREADS / 64];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * OPT_THREADS) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + 4 * i);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void sqnorm_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partials[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ sq, float max_norm, float gscale, float* __restrict__ coef) {
+    if (threadIdx.x == 0) {
+        const float total = sqrtf(sq[0]) * gscale;                       // norm of the (scaled) gradient
+        coef[0] = fminf(1.0f, max_norm / (total + 1e-6f)) * gscale;      // torch clip_grad_norm_ rule
+    }
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+        float* __restrict__ v, bf16_t* __restrict__ shadow, long n, const float* __restrict__ clip_coef, float step_size,
+        float b1, float b2, float eps, float decay) {
+    const float gs = clip_coef ? clip_coef[0] : 1.0f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * OPT_THREADS) {
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + 4 * i);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * i) * gs;
+        f32x4 mv = *reinterpret_cast<f32x4*>(m + 4 * i);
+        f32x4 vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mv[j] = b1 * mv[j] + (1.0f - b1) * gv[j];
+            vv[j] = b2 * vv[j] + (1.0f - b2) * gv[j] * gv[j];
+            pv[j] -= step_size * mv[j] / (sqrtf(vv[j]) + eps);
+            pv[j] -= decay * pv[j];
+        }
+        *reinterpret_cast<f32x4*>(p + 4 * i) = pv;
+        *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
+        *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+        if (shadow) store4(shadow + 4 * i, pv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        const float gg = g[i] * gs;
+        const float mm = b1 * m[i] + (1.0f - b1) * gg;
+        const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
+        float pp = p[i] - step_size * mm / (sqrtf(vv) + eps);
+        pp -= decay * pp;
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (shadow) shadow[i] = (bf16_t)pp;
+    }
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(OPT_THREADS) void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long n) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * OPT_THREADS)
+        store4(dst + 4 * i, load4(src + 4 * i));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = from_f<D>(to_f(src[(n4 << 2) + threadIdx.x]));
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void fill_kernel(float* __restrict__ dst, float v, long n) {
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) dst[i] = v;
+}
+
+int opt_grid(long n4) { return (int)std::max(1L, std::min((long)OPT_BLOCKS, (n4 + OPT_THREADS - 1) / OPT_THREADS)); }
+
+}  // namespace
+
+extern "C" int64_t pb_norm_partials_floats(void) { return OPT_BLOCKS; }
+
+extern "C" int pb_grad_sqnorm(const float* g, int64_t n, float* partials, float* out_sq, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PB_REQUIRE(n >= 0 && ((uintptr_t)g % 16 == 0), "pb_grad_sqnorm: buffer must be 16-byte aligned");
+    const int grid = opt_grid(n >> 2);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(OPT_THREADS), 0, stream, g, (long)n, partials);
+    PB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sqnorm_finalize_kernel, dim3(1), dim3(256), 0, stream, partials, grid, out_sq);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_clip_coef(const float* sq, float max_norm, float gscale, float* coef, void* stream_) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, sq, max_norm, gscale, coef);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, const float* clip_coef,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream_) {
+    PB_REQUIRE(step >= 1, "pb_adamw_step: step must be >= 1");
+    PB_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+               "pb_adamw_step: buffers must be 16-byte aligned");
+    if (n <= 0) return 0;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr * std::sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adamw_kernel, dim3(opt_grid(n >> 2)), dim3(OPT_THREADS), 0, (hipStream_t)stream_, p, g, m, v, (bf16_t*)shadow,
+                       (long)n, clip_coef, step_size, beta1, beta2, eps, lr * weight_decay);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream_) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(opt_grid(n >> 2)), dim3(OPT_THREADS), 0, (hipStream_t)stream_, src, (bf16_t*)dst, (long)n);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pb_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream_) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(opt_grid(n >> 2)), dim3(OPT_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)src, dst, (long)n);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pb_fill_f32(float* dst, float value, int64_t n, void* stream_) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(opt_grid(n >> 2)), dim3(OPT_THREADS), 0, (hipStream_t)stream_, dst, value, (long)n);
+    PB_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,167 @@
+"""Tensor-level wrappers over the C ABI (include/pianobart_hip.h). PyTorch is used only to own
+device memory and the HIP stream; every op below launches a hand-written gfx950 kernel from
+libpianobart_hip.so on torch's current stream. There is no fallback path."""
+import ctypes
+
+import torch
+
+from ._lib import (LIB, PB_BF16, PB_F32, GemmDesc, PBError, GEMM_ACCUM, GEMM_C_F32, GEMM_GELU,
+                   GEMM_MUL_GELU_GRAD)
+
+SEG_SIZES = [262, 134, 135, 262, 134, 38, 260, 55]          # PianoBart.classes order
+SEG_OFF = [0]
+for _n in SEG_SIZES:
+    SEG_OFF.append(SEG_OFF[-1] + _n)
+VOCAB = SEG_OFF[-1]                                         # 1280
+_SEG9 = (ctypes.c_int32 * 9)(*SEG_OFF)
+
+
+def seg_array(offsets):
+    return (ctypes.c_int32 * len(offsets))(*offsets)
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return PB_F32
+    if t == torch.bfloat16:
+        return PB_BF16
+    raise PBError('unsupported storage dtype %s' % t)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PBError('pianobart_amd ops need HIP device tensors (got %s); there is no CPU path' % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=None, bias=None, alpha=1.0,
+         accum=False, c_f32=False, gelu_aux_out=None, gelu_grad_aux_in=None, ldaux=0, nb1=1, nb2=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0):
+    """C[m,n] (+)= epi(alpha * sum_k A(m,k) B(n,k)). a_off/b_off/c_off are element offsets into the tensors."""
+    d = GemmDesc()
+    esz = 2 if dtype == PB_BF16 else 4
+    d.A = A.data_ptr() + a_off * esz
+    d.B = B.data_ptr() + b_off * esz
+    d.C = C.data_ptr() + c_off * (4 if c_f32 else esz)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.aux_in = gelu_grad_aux_in.data_ptr() if gelu_grad_aux_in is not None else None
+    d.aux_out = gelu_aux_out.data_ptr() if gelu_aux_out is not None else None
+    d.dtype, d.a_kcontig, d.b_kcontig = dtype, int(a_kc), int(b_kc)
+    d.flags = (GEMM_ACCUM if accum else 0) | (GEMM_C_F32 if c_f32 else 0) | \
+              (GEMM_GELU if gelu_aux_out is not None else 0) | (GEMM_MUL_GELU_GRAD if gelu_grad_aux_in is not None else 0)
+    d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, nb1, nb2
+    d.lda = lda if lda is not None else (K if a_kc else M)
+    d.ldb = ldb if ldb is not None else (K if b_kc else N)
+    d.ldc = ldc if ldc is not None else N
+    d.ldaux = ldaux or d.ldc
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    d.alpha = alpha
+    if not (A.is_cuda and B.is_cuda and C.is_cuda):
+        raise PBError('gemm needs HIP device tensors; there is no CPU path')
+    LIB.call('pb_gemm', ctypes.byref(d), _stream())
+
+
+def linear_fwd(x, w, bias, out, dtype, **kw):
+    """out (T,N) = x (T,K) @ w(N,K)^T + bias."""
+    T, K = x.shape
+    N = w.shape[0]
+    gemm(x, w, out, M=T, N=N, K=K, dtype=dtype, bias=bias, **kw)
+
+
+def ids_to_i16(ids):
+    out = torch.empty(ids.shape, dtype=torch.int16, device=ids.device)
+    ids = ids.contiguous()
+    if ids.dtype != torch.int64:
+        ids = ids.long()
+    LIB.call('pb_ids_to_i16', _p(ids), _p(out), ids.numel(), _stream())
+    return out
+
+
+def embed_ln_fwd(ids16, P, lin_bias, pos, ln_w, ln_b, y, mean, rstd, S, eps, seed, site, p_drop):
+    T, d = y.shape
+    LIB.call('pb_embed_ln_fwd', _p(ids16), _p(P), _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(ln_b), _p(y), _p(mean),
+             _p(rstd), T, S, d, dtype_code(y.dtype), eps, seed, site, p_drop, _stream())
+
+
+def embed_ln_bwd(dy, ids16, P, lin_bias, pos, ln_w, mean, rstd, dP, dpos, dbias, dgamma, dbeta, partials, S, seed, site, p_drop):
+    T, d = dy.shape
+    LIB.call('pb_embed_ln_bwd', _p(dy), _p(ids16), _p(P), _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(mean), _p(rstd),
+             _p(dP), _p(dpos), _p(dbias), _p(dgamma), _p(dbeta), _p(partials), T, S, d, dtype_code(dy.dtype), seed, site,
+             p_drop, _stream())
+
+
+def add_ln_fwd(res, a, ln_w, ln_b, y, mean, rstd, eps, seed, site, p_drop):
+    T, d = y.shape
+    LIB.call('pb_add_ln_fwd', _p(res), _p(a), _p(ln_w), _p(ln_b), _p(y), _p(mean), _p(rstd), T, d, dtype_code(y.dtype),
+             eps, seed, site, p_drop, _stream())
+
+
+def add_ln_bwd(dy, res, a, ln_w, mean, rstd, dres, da, dgamma, dbeta, dbias_a, partials, accum_dres, seed, site, p_drop):
+    T, d = dy.shape
+    LIB.call('pb_add_ln_bwd', _p(dy), _p(res), _p(a), _p(ln_w), _p(mean), _p(rstd), _p(dres), _p(da), _p(dgamma), _p(dbeta),
+             _p(dbias_a), _p(partials), T, d, dtype_code(dy.dtype), int(dres.dtype == torch.float32 and dy.dtype != torch.float32),
+             int(accum_dres), seed, site, p_drop, _stream())
+
+
+def colsum(dy, out, partials, T, N, ld=None):
+    LIB.call('pb_colsum', _p(dy), ld if ld is not None else N, _p(out), _p(partials), T, N,
+             PB_F32 if dy.dtype == torch.float32 else PB_BF16, int(dy.dtype == torch.float32), _stream())
+
+
+def softmax_fwd(scores, key_mask, P, B, H, Sq, Sk, scale, causal):
+    LIB.call('pb_softmax_fwd', _p(scores), _p(key_mask), _p(P), B, H, Sq, Sk, scale, int(causal), dtype_code(P.dtype), _stream())
+
+
+def softmax_bwd(dP, P, dS, rows, Sk, scale):
+    LIB.call('pb_softmax_bwd', _p(dP), _p(P), _p(dS), rows, Sk, scale, dtype_code(P.dtype), _stream())
+
+
+def ce_fwd_bwd(logits, target16, loss_mask, sums, partials, coef, dlogits, argmax_out):
+    T, V = logits.shape
+    LIB.call('pb_ce_fwd_bwd', _p(logits), _p(target16), _p(loss_mask), _SEG9, _p(sums), _p(partials), _p(coef), _p(dlogits),
+             _p(argmax_out), T, V, dtype_code(dlogits.dtype) if dlogits is not None else PB_F32, _stream())
+
+
+def mask_count(loss_mask, counts):
+    LIB.call('pb_mask_count', _p(loss_mask), _p(counts), loss_mask.numel() // 8, _stream())
+
+
+def loss_coef(counts, w, coef):
+    LIB.call('pb_loss_coef', _p(counts), _p(w), _p(coef), _stream())
+
+
+def grad_sqnorm(g, partials, out_sq):
+    LIB.call('pb_grad_sqnorm', _p(g), g.numel(), _p(partials), _p(out_sq), _stream())
+
+
+def clip_coef(sq, max_norm, gscale, coef):
+    LIB.call('pb_clip_coef', _p(sq), max_norm, gscale, _p(coef), _stream())
+
+
+def adamw_step(p, g, m, v, shadow, clip, lr, beta1, beta2, eps, weight_decay, step):
+    LIB.call('pb_adamw_step', _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(clip), lr, beta1, beta2, eps,
+             weight_decay, step, _stream())
+
+
+def cast_f32_to_bf16(src, dst):
+    LIB.call('pb_cast_f32_to_bf16', _p(src), _p(dst), src.numel(), _stream())
+
+
+def cast_bf16_to_f32(src, dst):
+    LIB.call('pb_cast_bf16_to_f32', _p(src), _p(dst), src.numel(), _stream())
+
+
+def fill_f32(dst, value):
+    LIB.call('pb_fill_f32', _p(dst), value, dst.numel(), _stream())
+
+
+def shift_right(ids16, sos_row16, out, B, S):
+    LIB.call('pb_shift_right', _p(ids16), _p(sos_row16), _p(out), B, S, _stream())

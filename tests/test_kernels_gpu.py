@@ -1,0 +1,259 @@
+"""GPU: every HIP kernel of libpianobart_hip.so against a plain PyTorch fp32/fp64 reference of the
+same op (called through the C ABI via pianobart_amd.ops)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from pianobart_amd import ops as o
+    return o
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('a_kc,b_kc', [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 384, 192), (200, 72, 104), (38, 768, 256), (1000, 1280, 96), (5, 8, 8)])
+def test_gemm_layouts(ops, dt, a_kc, b_kc, M, N, K):
+    g = torch.Generator(device='cuda').manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, device='cuda', generator=g)
+    B = torch.randn(N, K, device='cuda', generator=g) + 0.1 * torch.arange(N, device='cuda')[:, None] / N   # asymmetric
+    ref = A.to(dt).double() @ B.to(dt).double().t()
+    Am = (A if a_kc else A.t()).contiguous().to(dt)
+    Bm = (B if b_kc else B.t()).contiguous().to(dt)
+    C = torch.full((M, N), float('nan'), device='cuda', dtype=dt)
+    ops.gemm(Am, Bm, C, M=M, N=N, K=K, dtype=ops.dtype_code(dt), a_kc=a_kc, b_kc=b_kc)
+    torch.cuda.synchronize()
+    assert _rel(C, ref) < (3e-6 if dt == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gemm_identity_asymmetric(ops, dt):
+    """A = I with asymmetric B catches a transposed C write (guide: cdna_hip_programming 3)."""
+    n = 128
+    A = torch.eye(n, device='cuda', dtype=dt)
+    B = (torch.arange(n, device='cuda')[:, None] * 3 + torch.arange(n, device='cuda')[None, :] % 7).to(dt)  # B[n,k]
+    C = torch.zeros(n, n, device='cuda', dtype=dt)
+    ops.gemm(A, B, C, M=n, N=n, K=n, dtype=ops.dtype_code(dt))
+    assert torch.equal(C.float(), B.float().t())
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(ops, dt):
+    g = torch.Generator(device='cuda').manual_seed(3)
+    M, N, K = 192, 320, 128
+    A = torch.randn(M, K, device='cuda', generator=g).to(dt)
+    W = (torch.randn(N, K, device='cuda', generator=g) / math.sqrt(K)).to(dt)
+    bias = torch.randn(N, device='cuda', generator=g)
+    code = ops.dtype_code(dt)
+    pre = A.double() @ W.double().t() + bias.double()
+    # bias + GELU (pre-activation saved)
+    C = torch.empty(M, N, device='cuda', dtype=dt); U = torch.empty_like(C)
+    ops.gemm(A, W, C, M=M, N=N, K=K, dtype=code, bias=bias, gelu_aux_out=U)
+    assert _rel(U, pre) < TOL[dt] and _rel(C, torch.nn.functional.gelu(pre)) < TOL[dt]
+    # alpha + accumulate into f32 C
+    C32 = torch.randn(M, N, device='cuda', generator=g)
+    ref = C32.double() + 0.5 * (A.double() @ W.double().t())
+    ops.gemm(A, W, C32, M=M, N=N, K=K, dtype=code, alpha=0.5, accum=True, c_f32=True)
+    assert _rel(C32, ref) < TOL[dt]
+    # multiply by gelu'(aux)
+    u = torch.randn(M, N, device='cuda', generator=g).to(dt)
+    ud = u.double().requires_grad_(True)
+    torch.nn.functional.gelu(ud).sum().backward()
+    C = torch.empty(M, N, device='cuda', dtype=dt)
+    ops.gemm(A, W, C, M=M, N=N, K=K, dtype=code, gelu_grad_aux_in=u)
+    assert _rel(C, (A.double() @ W.double().t()) * ud.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gemm_batched_strided(ops, dt):
+    """The unfused attention products: batch over (b,h) with head-sliced strides."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    B, H, S, hd = 2, 3, 72, 32
+    d = H * hd
+    qkv = torch.randn(B, S, 3 * d, device='cuda', generator=g).to(dt)
+    scores = torch.empty(B, H, S, S, device='cuda')
+    code = ops.dtype_code(dt)
+    ops.gemm(qkv, qkv, scores, M=S, N=S, K=hd, dtype=code, lda=3 * d, ldb=3 * d, ldc=S, c_f32=True, nb1=B, nb2=H,
+             sA=(S * 3 * d, hd), sB=(S * 3 * d, hd), sC=(H * S * S, S * S), b_off=d)
+    q = qkv[..., :d].reshape(B, S, H, hd).permute(0, 2, 1, 3).double()
+    k = qkv[..., d:2 * d].reshape(B, S, H, hd).permute(0, 2, 1, 3).double()
+    v = qkv[..., 2 * d:].reshape(B, S, H, hd).permute(0, 2, 1, 3).double()
+    assert _rel(scores, q @ k.transpose(2, 3)) < TOL[dt]
+    P = torch.softmax(scores, -1).to(dt)
+    ctx = torch.empty(B, S, d, device='cuda', dtype=dt)
+    ops.gemm(P, qkv, ctx, M=S, N=hd, K=S, dtype=code, b_kc=False, lda=S, ldb=3 * d, ldc=d, nb1=B, nb2=H,
+             sA=(H * S * S, S * S), sB=(S * 3 * d, hd), sC=(S * d, hd), b_off=2 * d)
+    ref = (P.double() @ v).permute(0, 2, 1, 3).reshape(B, S, d)
+    assert _rel(ctx, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('d', [128, 768, 1024, 64])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_add_ln_fwd_bwd(ops, dt, d, p):
+    g = torch.Generator(device='cuda').manual_seed(d)
+    T = 301
+    res = torch.randn(T, d, device='cuda', generator=g).to(dt)
+    a = torch.randn(T, d, device='cuda', generator=g).to(dt)
+    w = 1 + 0.2 * torch.randn(d, device='cuda', generator=g)
+    b = 0.2 * torch.randn(d, device='cuda', generator=g)
+    dy = torch.randn(T, d, device='cuda', generator=g).to(dt)
+    y = torch.empty(T, d, device='cuda', dtype=dt)
+    mean = torch.empty(T, device='cuda'); rstd = torch.empty(T, device='cuda')
+    seed, site = 1234567, 5
+    ops.add_ln_fwd(res, a, w, b, y, mean, rstd, 1e-5, seed, site, p)
+    # recover the dropout mask by running the same site on (0, ones) with identity LN statistics
+    if p > 0:
+        ones = torch.ones(T, d, device='cuda', dtype=dt); zeros = torch.zeros_like(ones)
+        y1 = torch.empty_like(ones); m1 = torch.empty(T, device='cuda'); r1 = torch.empty(T, device='cuda')
+        ops.add_ln_fwd(zeros, ones, torch.ones(d, device='cuda'), torch.zeros(d, device='cuda'), y1, m1, r1, 1e-5, seed, site, p)
+        # z = mask/(1-p); y1 = (z-mean)*rstd  -> z = y1/rstd + mean
+        z = y1.float() / r1[:, None] + m1[:, None]
+        mask = (z > 0.5).double() / (1 - p)
+        frac = float((mask == 0).double().mean())
+        assert abs(frac - p) < 0.01
+    else:
+        mask = torch.ones(T, d, device='cuda', dtype=torch.double)
+    rd = res.double().requires_grad_(True); ad = a.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(rd + ad * mask, (d,), wd, bd, 1e-5)
+    yr.backward(dy.double())
+    assert _rel(y, yr) < TOL[dt]
+    dres = torch.empty(T, d, device='cuda', dtype=dt); da = torch.empty_like(dres)
+    dg = torch.zeros(d, device='cuda'); db = torch.zeros(d, device='cuda'); dba = torch.zeros(d, device='cuda')
+    partials = torch.empty(int(ops.LIB.query('pb_ln_partials_floats', d)), device='cuda')
+    ops.add_ln_bwd(dy, res, a, w, mean, rstd, dres, da, dg, db, dba, partials, False, seed, site, p)
+    assert _rel(dres, rd.grad) < TOL[dt] * 2
+    assert _rel(da, ad.grad) < TOL[dt] * 2
+    assert _rel(dg, wd.grad) < TOL[dt] * 2 and _rel(db, bd.grad) < TOL[dt] * 2
+    assert _rel(dba, ad.grad.sum(0)) < TOL[dt] * 4
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('d', [128, 768])
+def test_embed_ln_fwd_bwd(ops, dt, d):
+    g = torch.Generator(device='cuda').manual_seed(9)
+    B, S = 3, 40
+    T = B * S
+    ids = torch.stack([torch.randint(0, n, (T,), device='cuda', generator=g) for n in ops.SEG_SIZES], dim=1)
+    P = torch.randn(ops.VOCAB, d, device='cuda', generator=g)
+    lb = torch.randn(d, device='cuda', generator=g); pos = torch.randn(S + 2, d, device='cuda', generator=g)
+    w = 1 + 0.2 * torch.randn(d, device='cuda', generator=g); b = 0.2 * torch.randn(d, device='cuda', generator=g)
+    ids16 = ops.ids_to_i16(ids)
+    assert torch.equal(ids16.long(), ids)
+    y = torch.empty(T, d, device='cuda', dtype=dt); mean = torch.empty(T, device='cuda'); rstd = torch.empty(T, device='cuda')
+    ops.embed_ln_fwd(ids16, P, lb, pos, w, b, y, mean, rstd, S, 1e-5, 0, 0, 0.0)
+    Pd = P.double().requires_grad_(True); lbd = lb.double().requires_grad_(True); posd = pos.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    off = torch.tensor(ops.SEG_OFF[:8], device='cuda')
+    z = Pd[(ids + off).reshape(-1)].reshape(T, 8, d).sum(1) + lbd + posd[2:2 + S].repeat(B, 1)
+    yr = torch.nn.functional.layer_norm(z, (d,), wd, bd, 1e-5)
+    assert _rel(y, yr) < TOL[dt]
+    dy = torch.randn(T, d, device='cuda', generator=g).to(dt)
+    dy[7] = 0                                                    # a row without gradient (skip path)
+    yr.backward(dy.double())
+    dP = torch.zeros_like(P); dpos = torch.zeros_like(pos); dlb = torch.zeros(d, device='cuda')
+    dg = torch.zeros(d, device='cuda'); db = torch.zeros(d, device='cuda')
+    partials = torch.empty(int(ops.LIB.query('pb_ln_partials_floats', d)), device='cuda')
+    ops.embed_ln_bwd(dy, ids16, P, lb, pos, w, mean, rstd, dP, dpos, dlb, dg, db, partials, S, 0, 0, 0.0)
+    assert _rel(dP, Pd.grad) < 1e-4 and _rel(dpos, posd.grad) < 1e-4 and _rel(dlb, lbd.grad) < 1e-4
+    assert _rel(dg, wd.grad) < 1e-4 and _rel(db, bd.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('causal', [False, True])
+def test_softmax_fwd_bwd(ops, dt, causal):
+    g = torch.Generator(device='cuda').manual_seed(2)
+    B, H, Sq, Sk = 2, 3, 50, 50
+    scores = torch.randn(B, H, Sq, Sk, device='cuda', generator=g) * 3
+    km = (torch.rand(B, Sk, device='cuda', generator=g) > 0.3).float()
+    km[1, :] = 0                                                  # batch 1: nothing visible -> zero rows
+    km[0, 0] = 0                                                  # causal row 0 of batch 0 sees nothing
+    P = torch.empty(B, H, Sq, Sk, device='cuda', dtype=dt)
+    ops.softmax_fwd(scores, km, P, B, H, Sq, Sk, 0.25, causal)
+    vis = (km != 0)[:, None, None, :].expand(B, H, Sq, Sk)
+    if causal:
+        vis = vis & torch.ones(Sq, Sk, dtype=torch.bool, device='cuda').tril()
+    s = (scores.double() * 0.25).masked_fill(~vis, float('-inf'))
+    ref = torch.where(vis.any(-1, keepdim=True), torch.softmax(s, -1), torch.zeros_like(s))
+    ref = torch.nan_to_num(ref, nan=0.0)
+    assert float((P.double() - ref).abs().max()) < (1e-6 if dt == torch.float32 else 4e-3)
+    dP = torch.randn(B, H, Sq, Sk, device='cuda', generator=g)
+    dS = torch.empty_like(P)
+    ops.softmax_bwd(dP, P, dS, B * H * Sq, Sk, 0.25)
+    Pd = P.double()
+    refd = 0.25 * Pd * (dP.double() - (dP.double() * Pd).sum(-1, keepdim=True))
+    assert float((dS.double() - refd).abs().max()) < (1e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_ce_fwd_bwd(ops, dt):
+    g = torch.Generator(device='cuda').manual_seed(4)
+    T, V = 333, ops.VOCAB
+    logits = torch.randn(T, V, device='cuda', generator=g) * 2
+    logits[5, 0] = logits[5, 1] = 50.0                           # tie: argmax must pick the lower index
+    target = torch.stack([torch.randint(0, n, (T,), device='cuda', generator=g) for n in ops.SEG_SIZES], dim=1)
+    m = (torch.rand(T, 8, device='cuda', generator=g) < 0.3).float()
+    m[:, 5] = 0; m[0, 5] = 1
+    w = torch.tensor([262, 134, 262, 134, 38, 135, 55, 260], device='cuda', dtype=torch.float32)
+    counts = torch.empty(8, device='cuda'); coef = torch.empty(8, device='cuda')
+    ops.mask_count(m, counts); ops.loss_coef(counts, w, coef)
+    assert torch.allclose(counts, m.sum(0))
+    sums = torch.zeros(24, device='cuda')
+    partials = torch.empty(int(ops.LIB.query('pb_ce_partials_floats')), device='cuda')
+    dl = torch.empty(T, V, device='cuda', dtype=dt); am = torch.empty(T, 8, device='cuda', dtype=torch.int16)
+    ops.ce_fwd_bwd(logits, target.to(torch.int16), m, sums, partials, coef, dl, am)
+    ld = logits.double().requires_grad_(True)
+    total = 0
+    for i in range(8):
+        seg = ld[:, ops.SEG_OFF[i]:ops.SEG_OFF[i + 1]]
+        ce = torch.nn.functional.cross_entropy(seg, target[:, i], reduction='none')
+        li = (ce * m[:, i].double()).sum() / m[:, i].double().sum()
+        assert abs(float(sums[i]) / float(sums[8 + i]) - float(li)) < 1e-5 * max(1, abs(float(li)))
+        ok = ((seg.argmax(-1) == target[:, i]).double() * m[:, i].double()).sum()
+        assert abs(float(sums[16 + i]) - float(ok)) < 1e-3
+        assert torch.equal(am[:, i].long(), torch.from_numpy(np.argmax(seg.detach().cpu().numpy(), -1)).cuda())
+        total = total + li * w[i].double()
+    total = total / w.double().sum()
+    total.backward()
+    assert _rel(dl, ld.grad) < (1e-5 if dt == torch.float32 else 1e-2)
+    assert int(am[5, 0]) == 0
+
+
+def test_optimizer_kernels(ops):
+    from oracle import pianobart_oracle as O
+    g = torch.Generator(device='cuda').manual_seed(8)
+    n = 100003
+    n_pad = (n + 3) // 4 * 4
+    p = torch.randn(n_pad, device='cuda', generator=g)[:n]; gr = torch.randn(n_pad, device='cuda', generator=g)[:n] * 0.1
+    m = torch.zeros(n, device='cuda'); v = torch.zeros(n, device='cuda'); sh = torch.empty(n, device='cuda', dtype=torch.bfloat16)
+    partials = torch.empty(int(ops.LIB.query('pb_norm_partials_floats')), device='cuda')
+    sq = torch.empty(1, device='cuda'); coef = torch.empty(1, device='cuda')
+    ops.grad_sqnorm(gr, partials, sq)
+    assert abs(float(sq) - float((gr.double() ** 2).sum())) / float(sq) < 1e-6
+    ops.clip_coef(sq, 3.0, 1.0, coef)
+    gc = gr.cpu().clone(); tot = O.clip_grad_norm([gc], 3.0)
+    pc, mc, vc = p.cpu().clone(), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        ops.adamw_step(p, gr, m, v, sh, coef, 2e-5, 0.9, 0.999, 1e-6, 0.01, step)
+        O.hf_adamw_step([pc], [gc], [mc], [vc], step=step, lr=2e-5)
+    assert _rel(p.cpu(), pc) < 1e-6 and _rel(m.cpu(), mc) < 1e-5 and _rel(v.cpu(), vc) < 1e-5
+    assert torch.equal(sh.cpu(), p.cpu().to(torch.bfloat16))
+    x = torch.randn(1027, device='cuda', generator=g); xb = torch.empty(1027, device='cuda', dtype=torch.bfloat16); xf = torch.empty(1027, device='cuda')
+    ops.cast_f32_to_bf16(x, xb); ops.cast_bf16_to_f32(xb, xf)
+    assert torch.equal(xb, x.to(torch.bfloat16)) and torch.equal(xf, xb.float())
