@@ -1,0 +1,640 @@
+"""Execution engine of the PianoBART hot path on MI355X.
+
+Owns (a) one flat f32 parameter buffer + one flat f32 gradient buffer (+ Adam moments and a bf16
+weight shadow) whose slices are what the nn.Parameters of pianobart_amd.model alias, (b) the saved
+activations of one forward, and (c) the explicit forward / backward schedules, written as sequences
+of C-ABI kernel launches on torch's current HIP stream (no autograd graph inside, no tracing).
+
+Reference semantics followed (file:line into /root/reference; tf: = transformers modeling_bart.py):
+  embed:   PianoBart.py:60-71 + tf:520-525/648-654   -> P = 16 E_i W_i^T once per step, gather-sum + pos + LN
+  layers:  tf:280-308 (encoder, post-LN), tf:343-390 (decoder: self, cross, ffn)
+  heads:   model.py:119-126  -> one (d x 1280) GEMM
+  loss:    pretrain.py:112-118,163-189 ; step: pretrain.py:192-196 (clip 3.0, HF AdamW)
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import LIB, PB_BF16, PB_F32, PBError
+
+LN_EPS = 1e-5
+
+
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Slot:
+    __slots__ = ('off', 'shape', 'numel')
+
+    def __init__(self, off, shape):
+        self.off, self.shape = off, tuple(shape)
+        self.numel = int(np.prod(shape))
+
+
+class Engine:
+    def __init__(self, pianobart, mask_lm, precision='bf16'):
+        if precision not in ('bf16', 'fp32'):
+            raise PBError('precision must be "bf16" or "fp32"')
+        self.pb, self.mlm = pianobart, mask_lm
+        self.precision = precision
+        self.code = PB_BF16 if precision == 'bf16' else PB_F32
+        self.xdt = torch.bfloat16 if precision == 'bf16' else torch.float32
+        cfg = pianobart.bartConfig
+        self.cfg = cfg
+        self.d = cfg.d_model
+        self.H = cfg.encoder_attention_heads
+        self.hd = self.d // self.H
+        self.NE, self.ND = cfg.encoder_layers, cfg.decoder_layers
+        self.fe, self.fd = cfg.encoder_ffn_dim, cfg.decoder_ffn_dim
+        self.Smax = cfg.max_position_embeddings
+        self.p_drop = float(getattr(cfg, 'dropout', 0.1))
+        self.device = None
+        self._layout()
+        self._ws_cache = {}
+        self._saved = None
+        self._fwd_token = 0
+        self._seed = 0x5EED1234
+        self.step_count = 0
+        self.opt_m = self.opt_v = None
+        self._versions = None
+
+    # ------------------------------------------------------------------ flat parameter layout
+    def _layout(self):
+        d, fe, fd = self.d, self.fe, self.fd
+        slots, cur = {}, [0]
+
+        def add(name, *shape):
+            slots[name] = _Slot(cur[0], shape)
+            cur[0] += _r4(int(np.prod(shape)))
+
+        # region A: matrices whose gradients are OVERWRITTEN by one wgrad GEMM each step
+        add('emb', ops.VOCAB, 256)
+        add('lin.w', d, 2048)
+        for l in range(self.NE):
+            p = 'enc.%d.' % l
+            add(p + 'wqkv', 3 * d, d); add(p + 'wo', d, d); add(p + 'w1', fe, d); add(p + 'w2', d, fe)
+        for l in range(self.ND):
+            p = 'dec.%d.' % l
+            add(p + 'wqkv', 3 * d, d); add(p + 'wo', d, d); add(p + 'wq_c', d, d); add(p + 'wkv_c', 2 * d, d)
+            add(p + 'wo_c', d, d); add(p + 'w1', fd, d); add(p + 'w2', d, fd)
+        if self.mlm is not None:
+            add('head.w', ops.VOCAB, d)
+        self.n_matrix = cur[0]
+        # region B: vectors / tables whose gradients are ACCUMULATED (zeroed at the start of each backward)
+        add('lin.b', d)
+        for side, n in (('enc', self.NE), ('dec', self.ND)):
+            add(side + '.pos', self.Smax + 2, d); add(side + '.lne.w', d); add(side + '.lne.b', d)
+            for l in range(n):
+                p = '%s.%d.' % (side, l)
+                add(p + 'bqkv', 3 * d); add(p + 'bo', d); add(p + 'ln1.w', d); add(p + 'ln1.b', d)
+                if side == 'dec':
+                    add(p + 'bq_c', d); add(p + 'bkv_c', 2 * d); add(p + 'bo_c', d); add(p + 'lnc.w', d); add(p + 'lnc.b', d)
+                add(p + 'b1', fe if side == 'enc' else fd); add(p + 'b2', d); add(p + 'ln2.w', d); add(p + 'ln2.b', d)
+        if self.mlm is not None:
+            add('head.b', ops.VOCAB)
+        self.n_total = cur[0]
+        self.slots = slots
+
+    def _param_map(self):
+        """[(nn.Parameter, slot name, row offset in slot)] for every live parameter, in a fixed order."""
+        pb, d = self.pb, self.d
+        out = []
+        off = 0
+        for i in range(8):
+            out.append((pb.word_emb[i].lut.weight, 'emb', off)); off += ops.SEG_SIZES[i]
+        out.append((pb.encoder_linear.weight, 'lin.w', 0)); out.append((pb.encoder_linear.bias, 'lin.b', 0))
+        for side, stack, n in (('enc', pb.bart.encoder, self.NE), ('dec', pb.bart.decoder, self.ND)):
+            out.append((stack.embed_positions.weight, side + '.pos', 0))
+            out.append((stack.layernorm_embedding.weight, side + '.lne.w', 0)); out.append((stack.layernorm_embedding.bias, side + '.lne.b', 0))
+            for l in range(n):
+                L, p = stack.layers[l], '%s.%d.' % (side, l)
+                sa = L.self_attn
+                out += [(sa.q_proj.weight, p + 'wqkv', 0), (sa.k_proj.weight, p + 'wqkv', d), (sa.v_proj.weight, p + 'wqkv', 2 * d),
+                        (sa.q_proj.bias, p + 'bqkv', 0), (sa.k_proj.bias, p + 'bqkv', d), (sa.v_proj.bias, p + 'bqkv', 2 * d),
+                        (sa.out_proj.weight, p + 'wo', 0), (sa.out_proj.bias, p + 'bo', 0),
+                        (L.self_attn_layer_norm.weight, p + 'ln1.w', 0), (L.self_attn_layer_norm.bias, p + 'ln1.b', 0)]
+                if side == 'dec':
+                    ca = L.encoder_attn
+                    out += [(ca.q_proj.weight, p + 'wq_c', 0), (ca.q_proj.bias, p + 'bq_c', 0),
+                            (ca.k_proj.weight, p + 'wkv_c', 0), (ca.v_proj.weight, p + 'wkv_c', d),
+                            (ca.k_proj.bias, p + 'bkv_c', 0), (ca.v_proj.bias, p + 'bkv_c', d),
+                            (ca.out_proj.weight, p + 'wo_c', 0), (ca.out_proj.bias, p + 'bo_c', 0),
+                            (L.encoder_attn_layer_norm.weight, p + 'lnc.w', 0), (L.encoder_attn_layer_norm.bias, p + 'lnc.b', 0)]
+                out += [(L.fc1.weight, p + 'w1', 0), (L.fc1.bias, p + 'b1', 0), (L.fc2.weight, p + 'w2', 0), (L.fc2.bias, p + 'b2', 0),
+                        (L.final_layer_norm.weight, p + 'ln2.w', 0), (L.final_layer_norm.bias, p + 'ln2.b', 0)]
+        if self.mlm is not None:
+            off = 0
+            for i in range(8):
+                out.append((self.mlm.proj[i].weight, 'head.w', off)); out.append((self.mlm.proj[i].bias, 'head.b', off))
+                off += ops.SEG_SIZES[i]
+        return out
+
+    def _elem_off(self, slot, row):
+        s = self.slots[slot]
+        inner = int(np.prod(s.shape[1:])) if len(s.shape) > 1 else 1
+        return s.off + row * inner
+
+    # ------------------------------------------------------------------ binding params to the flat buffers
+    def bind(self, device):
+        """(Re)build the flat buffers on `device` and make every nn.Parameter alias its slice."""
+        pm = self._param_map()
+        if self.device is not None and all(p.data_ptr() == self.P32.data_ptr() + 4 * self._elem_off(s, r) for p, s, r in pm):
+            return
+        pdev = pm[0][0].device
+        if device.type != 'cuda' or pdev.type != 'cuda':
+            raise PBError('pianobart_amd runs on the HIP device only (model on %s, inputs on %s). Move the model with '
+                          '.to("cuda"); there is no CPU execution path.' % (pdev, device))
+        self.device = device
+        P32 = torch.zeros(self.n_total, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, s, r in pm:
+                o = self._elem_off(s, r)
+                P32[o:o + p.numel()].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            for p, s, r in pm:
+                o = self._elem_off(s, r)
+                p.data = P32[o:o + p.numel()].view(p.shape)
+        self.P32 = P32
+        self.G32 = torch.zeros(self.n_total, dtype=torch.float32, device=device)
+        self.G32_alt = None
+        self.Pbf = torch.empty(self.n_total, dtype=torch.bfloat16, device=device) if self.code == PB_BF16 else None
+        self.params = [p for p, _, _ in pm]
+        self.param_slots = [(s, r) for _, s, r in pm]
+        self.grad_views = [self.G32[self._elem_off(s, r):self._elem_off(s, r) + p.numel()].view(p.shape) for p, s, r in pm]
+        self.w, self.wf, self.g = {}, {}, {}
+        for name, s in self.slots.items():
+            self.wf[name] = P32[s.off:s.off + s.numel].view(s.shape)
+            self.g[name] = self.G32[s.off:s.off + s.numel].view(s.shape)
+            self.w[name] = (self.Pbf[s.off:s.off + s.numel].view(s.shape) if self.code == PB_BF16 else self.wf[name])
+        self.Gcur = self.G32
+        self.opt_m = self.opt_v = None
+        self._versions = None
+        self._ws_cache = {}
+        self.ptab = torch.empty(ops.VOCAB, self.d, dtype=torch.float32, device=device)
+        self.dptab = torch.empty(ops.VOCAB, self.d, dtype=torch.float32, device=device)
+        npart = max(int(LIB.query('pb_ln_partials_floats', self.d)), int(LIB.query('pb_colsum_partials_floats', max(3 * self.d, self.fe, self.fd, ops.VOCAB))),
+                    int(LIB.query('pb_ce_partials_floats')), int(LIB.query('pb_norm_partials_floats')))
+        self.partials = torch.empty(npart, dtype=torch.float32, device=device)
+        self.scal = torch.zeros(64, dtype=torch.float32, device=device)    # [0:24] ce sums, [24:32] counts, [32:40] coef, [40] sq, [41] clip
+        w = [len(self.pb.e2w[k]) for k in self.pb.e2w]                       # dict order (pretrain.py:185-189)
+        self.loss_w = torch.tensor(w, dtype=torch.float32, device=device)
+        self.sos16 = torch.tensor(self.pb.sos_word_np, dtype=torch.int16, device=device)
+
+    def refresh_shadow(self, force=False):
+        """bf16 weight shadow follows the f32 masters (after load_state_dict / an external optimizer)."""
+        if self.code != PB_BF16:
+            return
+        ver = sum(p._version for p in self.params)
+        if force or ver != self._versions:
+            ops.cast_f32_to_bf16(self.P32, self.Pbf)
+            self._versions = ver
+
+    # ------------------------------------------------------------------ workspace
+    def _ws(self, B, S):
+        key = (B, S)
+        ws = self._ws_cache.get(key)
+        if ws is not None:
+            return ws
+        dev, X, d, H = self.device, self.xdt, self.d, self.H
+        T = B * S
+        e = lambda *shape, dt=X: torch.empty(*shape, dtype=dt, device=dev)
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+
+        def attn_ws():
+            return dict(P=e(B, H, S, S))
+
+        def layer(dec):
+            ff = self.fd if dec else self.fe
+            L = dict(qkv=e(T, 3 * d), ctx=e(T, d), a1=e(T, d), y1=e(T, d), m1=f(T), r1=f(T), u=e(T, ff), g=e(T, ff), a2=e(T, d),
+                     y2=e(T, d), m2=f(T), r2=f(T), attn=attn_ws())
+            if dec:
+                L.update(qc=e(T, d), kvc=e(T, 2 * d), ctxc=e(T, d), ac=e(T, d), yc=e(T, d), mc=f(T), rc=f(T), attnc=attn_ws())
+            return L
+
+        ws = dict(B=B, S=S, T=T,
+                  x_enc=e(T, d), me=f(T), re=f(T), x_dec=e(T, d), md=f(T), rd=f(T),
+                  enc=[layer(False) for _ in range(self.NE)], dec=[layer(True) for _ in range(self.ND)],
+                  logits=f(T, ops.VOCAB) if self.mlm is not None else None,
+                  scores=f(B, H, S, S), dS=e(B, H, S, S),
+                  gy=[e(T, d), e(T, d)], gA=e(T, d), gB=e(T, d), gC=e(T, d), dqkv=e(T, 3 * d), dq=e(T, d), dkv=e(T, 2 * d),
+                  du=e(T, max(self.fe, self.fd)), genc=e(T, d), dlogits=e(T, ops.VOCAB) if self.mlm is not None else None)
+        self._ws_cache = {key: ws}          # keep one shape resident
+        return ws
+
+    # ------------------------------------------------------------------ building blocks
+    def _linear(self, x, wname, bname, out, M, N, K, **kw):
+        ops.gemm(x, self.w[wname], out, M=M, N=N, K=K, dtype=self.code, bias=self.wf[bname] if bname else None, **kw)
+
+    def _attn_fwd(self, q, k, v, out, key_mask, causal, B, Sq, Sk, save):
+        """q,k,v,out: (tensor, elem offset, row stride). Unfused form: QK^T -> masked softmax -> PV."""
+        H, hd = self.H, self.hd
+        ws = self._cur_ws
+        scores, P = ws['scores'], save['P']
+        (qt, qo, ql), (kt, ko, kl), (vt, vo, vl), (ot, oo, ol) = q, k, v, out
+        ops.gemm(qt, kt, scores, M=Sq, N=Sk, K=hd, dtype=self.code, lda=ql, ldb=kl, ldc=Sk, c_f32=True, nb1=B, nb2=H,
+                 sA=(Sq * ql, hd), sB=(Sk * kl, hd), sC=(H * Sq * Sk, Sq * Sk), a_off=qo, b_off=ko)
+        ops.softmax_fwd(scores, key_mask, P, B, H, Sq, Sk, hd ** -0.5, causal)
+        ops.gemm(P, vt, ot, M=Sq, N=hd, K=Sk, dtype=self.code, b_kc=False, lda=Sk, ldb=vl, ldc=ol, nb1=B, nb2=H,
+                 sA=(H * Sq * Sk, Sq * Sk), sB=(Sk * vl, hd), sC=(Sq * ol, hd), b_off=vo, c_off=oo)
+
+    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save):
+        H, hd = self.H, self.hd
+        ws = self._cur_ws
+        dP, dS, P = ws['scores'], ws['dS'], save['P']
+        (qt, qo, ql), (kt, ko, kl), (vt, vo, vl) = q, k, v
+        (dot, doo, dol) = dout
+        (dqt, dqo, dql), (dkt, dko, dkl), (dvt, dvo, dvl) = dq, dk, dv
+        bs = (H * Sq * Sk, Sq * Sk)
+        ops.gemm(dot, vt, dP, M=Sq, N=Sk, K=hd, dtype=self.code, lda=dol, ldb=vl, ldc=Sk, c_f32=True, nb1=B, nb2=H,
+                 sA=(Sq * dol, hd), sB=(Sk * vl, hd), sC=bs, a_off=doo, b_off=vo)
+        ops.softmax_bwd(dP, P, dS, B * H * Sq, Sk, hd ** -0.5)
+        ops.gemm(dS, kt, dqt, M=Sq, N=hd, K=Sk, dtype=self.code, b_kc=False, lda=Sk, ldb=kl, ldc=dql, nb1=B, nb2=H,
+                 sA=bs, sB=(Sk * kl, hd), sC=(Sq * dql, hd), b_off=ko, c_off=dqo)
+        ops.gemm(dS, qt, dkt, M=Sk, N=hd, K=Sq, dtype=self.code, a_kc=False, b_kc=False, lda=Sk, ldb=ql, ldc=dkl, nb1=B, nb2=H,
+                 sA=bs, sB=(Sq * ql, hd), sC=(Sk * dkl, hd), b_off=qo, c_off=dko)
+        ops.gemm(P, dot, dvt, M=Sk, N=hd, K=Sq, dtype=self.code, a_kc=False, b_kc=False, lda=Sk, ldb=dol, ldc=dvl, nb1=B, nb2=H,
+                 sA=bs, sB=(Sq * dol, hd), sC=(Sk * dvl, hd), b_off=doo, c_off=dvo)
+
+    def _site(self, kind, layer=0, sub=0):
+        return {'enc_emb': 0, 'dec_emb': 1}.get(kind, 2 + (layer * 8 + sub) * 2 + (0 if kind == 'enc' else 1))
+
+    def build_ptab(self):
+        """P[off_i + v] = 16 * E_i[v] @ W_lin[:, 256 i : 256 i + 256]^T in exact f32 (PianoBart.py:16,67-71)."""
+        E, W = self.wf['emb'], self.wf['lin.w']
+        for i in range(8):
+            o, n = ops.SEG_OFF[i], ops.SEG_SIZES[i]
+            ops.gemm(E, W, self.ptab, M=n, N=self.d, K=256, dtype=PB_F32, lda=256, ldb=2048, ldc=self.d, alpha=16.0, c_f32=True,
+                     a_off=o * 256, b_off=256 * i, c_off=o * self.d)
+
+    # ------------------------------------------------------------------ forward
+    def forward_hidden(self, enc16, dec16, emask, dmask, train, seed, reuse_encoder=False):
+        """enc16/dec16: (B,S,8) int16 device; masks (B,S) f32 or None. Returns (dec_hidden, enc_hidden) in storage dtype."""
+        B, S = enc16.shape[:2]
+        if S > self.Smax:
+            raise PBError('sequence length %d exceeds max_position_embeddings %d' % (S, self.Smax))
+        d, T = self.d, B * S
+        ws = self._ws(B, S)
+        self._cur_ws = ws
+        p = self.p_drop if train else 0.0
+        self.refresh_shadow()
+        self.build_ptab()
+        wf = self.wf
+        x = ws['x_enc']
+        if not reuse_encoder:
+            ops.embed_ln_fwd(enc16, self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], wf['enc.lne.b'], x, ws['me'], ws['re'], S,
+                             LN_EPS, seed, self._site('enc_emb'), p)
+        for l in range(self.NE if not reuse_encoder else 0):
+            L, pf = ws['enc'][l], 'enc.%d.' % l
+            self._linear(x, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
+            self._attn_fwd((L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d), (L['ctx'], 0, d), emask, False, B, S, S, L['attn'])
+            self._linear(L['ctx'], pf + 'wo', pf + 'bo', L['a1'], T, d, d)
+            ops.add_ln_fwd(x, L['a1'], wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], L['y1'], L['m1'], L['r1'], LN_EPS, seed, self._site('enc', l, 0), p)
+            self._linear(L['y1'], pf + 'w1', pf + 'b1', L['g'], T, self.fe, d, gelu_aux_out=L['u'])
+            self._linear(L['g'], pf + 'w2', pf + 'b2', L['a2'], T, d, self.fe)
+            ops.add_ln_fwd(L['y1'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('enc', l, 1), p)
+            x = L['y2']
+        enc_out = x if not reuse_encoder else (ws['enc'][-1]['y2'] if self.NE else x)
+        if dec16 is None:
+            return None, enc_out
+        y = ws['x_dec']
+        ops.embed_ln_fwd(dec16, self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], wf['dec.lne.b'], y, ws['md'], ws['rd'], S,
+                         LN_EPS, seed, self._site('dec_emb'), p)
+        for l in range(self.ND):
+            L, pf = ws['dec'][l], 'dec.%d.' % l
+            self._linear(y, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
+            self._attn_fwd((L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d), (L['ctx'], 0, d), dmask, True, B, S, S, L['attn'])
+            self._linear(L['ctx'], pf + 'wo', pf + 'bo', L['a1'], T, d, d)
+            ops.add_ln_fwd(y, L['a1'], wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], L['y1'], L['m1'], L['r1'], LN_EPS, seed, self._site('dec', l, 0), p)
+            self._linear(L['y1'], pf + 'wq_c', pf + 'bq_c', L['qc'], T, d, d)
+            self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', L['kvc'], T, 2 * d, d)
+            self._attn_fwd((L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d), (L['ctxc'], 0, d), emask, False, B, S, S, L['attnc'])
+            self._linear(L['ctxc'], pf + 'wo_c', pf + 'bo_c', L['ac'], T, d, d)
+            ops.add_ln_fwd(L['y1'], L['ac'], wf[pf + 'lnc.w'], wf[pf + 'lnc.b'], L['yc'], L['mc'], L['rc'], LN_EPS, seed, self._site('dec', l, 1), p)
+            self._linear(L['yc'], pf + 'w1', pf + 'b1', L['g'], T, self.fd, d, gelu_aux_out=L['u'])
+            self._linear(L['g'], pf + 'w2', pf + 'b2', L['a2'], T, d, self.fd)
+            ops.add_ln_fwd(L['yc'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('dec', l, 2), p)
+            y = L['y2']
+        self._saved = dict(enc16=enc16, dec16=dec16, emask=emask, dmask=dmask, p=p, seed=seed, enc_out=enc_out, dec_out=y, B=B, S=S)
+        return y, enc_out
+
+    def heads_forward(self, dec_hidden):
+        ws = self._cur_ws
+        T = dec_hidden.shape[0]
+        ops.gemm(dec_hidden, self.w['head.w'], ws['logits'], M=T, N=ops.VOCAB, K=self.d, dtype=self.code, bias=self.wf['head.b'], c_f32=True)
+        return ws['logits']
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, dy, x, gname, M, N, T, ldy=None, ldx=None, dy_off=0, x_off=0, g_off=0):
+        """G[gname] (M,N) = dy(T,M)^T @ x(T,N)  (TN GEMM into the f32 gradient buffer)."""
+        ops.gemm(dy, x, self.g[gname], M=M, N=N, K=T, dtype=self.code, a_kc=False, b_kc=False, lda=ldy or M, ldb=ldx or N, ldc=N,
+                 c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off)
+
+    def _dgrad(self, dy, wname, out, T, N, K, accum, ldy=None, **kw):
+        """out(T,N) (+)= dy(T,K) @ W(K,N)   (NN GEMM, W stored [K][N])."""
+        ops.gemm(dy, self.w[wname], out, M=T, N=N, K=K, dtype=self.code, b_kc=False, lda=ldy or K, ldb=N, ldc=N, accum=accum, **kw)
+
+    def _ffn_ln_bwd(self, L, pf, ff, gy, y_in, seed, site, p):
+        """Backward of y2 = LN2(y_in + drop(fc2(gelu(fc1(y_in))))). gy: grad wrt y2. Returns grad wrt y_in in ws['gA']."""
+        ws, g, d, T = self._cur_ws, self.g, self.d, self._cur_ws['T']
+        gA, gB = ws['gA'], ws['gB']
+        da = gB if p > 0 else None
+        ops.add_ln_bwd(gy, y_in, L['a2'], self.wf[pf + 'ln2.w'], L['m2'], L['r2'], gA, da, g[pf + 'ln2.w'], g[pf + 'ln2.b'], g[pf + 'b2'],
+                       self.partials, False, seed, site, p)
+        gb = gB if p > 0 else gA
+        self._wgrad(gb, L['g'], pf + 'w2', d, ff, T)
+        du = ws['du'][:, :ff] if ws['du'].shape[1] == ff else ws['du'].view(-1)[:T * ff].view(T, ff)
+        self._dgrad(gb, pf + 'w2', du, T, ff, d, False, gelu_grad_aux_in=L['u'], ldaux=ff)
+        ops.colsum(du, g[pf + 'b1'], self.partials, T, ff)
+        self._wgrad(du, y_in, pf + 'w1', ff, d, T)
+        self._dgrad(du, pf + 'w1', gA, T, d, ff, True)
+        return gA
+
+    def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk):
+        """Backward of y = LN(x_in + drop(out_proj(attn(q,k,v)))) up to dq/dk/dv. gy: grad wrt y; gout receives grad wrt x_in
+        (residual path only; the projection paths are added by the caller)."""
+        ws, g, d, T = self._cur_ws, self.g, self.d, self._cur_ws['T']
+        gB, gC = ws['gB'], ws['gC']
+        wo, bo = names
+        da = gB if p > 0 else None
+        ops.add_ln_bwd(gy, x_in, a, lnw, mean, rstd, gout, da, lnw_g, lnb_g, g[bo], self.partials, False, seed, site, p)
+        gb = gB if p > 0 else gout
+        self._wgrad(gb, ctx, wo, d, d, T)
+        self._dgrad(gb, wo, gC, T, d, d, False)
+        self._attn_bwd((gC, 0, d), q, k, v, dq, dk, dv, B, Sq, Sk, attn_save)
+
+    def backward(self, gy_dec, gy_enc_extra=None):
+        """gy_dec: grad wrt decoder output (T,d) storage dtype (None for encoder-only). Writes all parameter gradients
+        into the flat buffer currently selected by self._gsel (vector region zeroed first)."""
+        sv = self._saved
+        if sv is None:
+            raise PBError('backward called without a saved forward')
+        ws = self._cur_ws
+        B, S, T, d = sv['B'], sv['S'], ws['T'], self.d
+        p, seed, wf, g = sv['p'], sv['seed'], self.wf, self.g
+        emask, dmask = sv['emask'], sv['dmask']
+        gy, galt = ws['gy']
+        genc = ws['genc']
+        if gy_dec is not None:
+            cur = gy_dec
+            for l in reversed(range(self.ND)):
+                L, pf = ws['dec'][l], 'dec.%d.' % l
+                x_in = ws['dec'][l - 1]['y2'] if l > 0 else ws['x_dec']
+                gA = self._ffn_ln_bwd(L, pf, self.fd, cur, L['yc'], seed, self._site('dec', l, 2), p)
+                # cross-attention block: y_c = LN(y1 + drop(out_c(attn(q_c(y1), kv_c(enc)))))
+                g1 = gy if cur is not gy else galt
+                self._attn_block_bwd(L, pf, (pf + 'wo_c', pf + 'bo_c'), gA, L['y1'], (L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d),
+                                     (ws['dq'], 0, d), (ws['dkv'], 0, 2 * d), (ws['dkv'], d, 2 * d), L['ctxc'], L['ac'], L['attnc'],
+                                     L['mc'], L['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1, seed, self._site('dec', l, 1), p, B, S, S)
+                ops.colsum(ws['dq'], g[pf + 'bq_c'], self.partials, T, d)
+                self._wgrad(ws['dq'], L['y1'], pf + 'wq_c', d, d, T)
+                self._dgrad(ws['dq'], pf + 'wq_c', g1, T, d, d, True)
+                ops.colsum(ws['dkv'], g[pf + 'bkv_c'], self.partials, T, 2 * d)
+                self._wgrad(ws['dkv'], sv['enc_out'], pf + 'wkv_c', 2 * d, d, T)
+                self._dgrad(ws['dkv'], pf + 'wkv_c', genc, T, d, 2 * d, l != self.ND - 1)
+                # self-attention block
+                g2 = gy if g1 is not gy else galt
+                self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), g1, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
+                                     (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
+                                     L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('dec', l, 0), p, B, S, S)
+                ops.colsum(ws['dqkv'], g[pf + 'bqkv'], self.partials, T, 3 * d)
+                self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
+                self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
+                cur = g2
+            ops.embed_ln_bwd(cur, sv['dec16'], self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], ws['md'], ws['rd'], self.dptab,
+                             g['dec.pos'], g['lin.b'], g['dec.lne.w'], g['dec.lne.b'], self.partials, S, seed, self._site('dec_emb'), p)
+            cur = genc
+            if gy_enc_extra is not None:
+                cur = genc.add_(gy_enc_extra)
+        else:
+            cur = gy_enc_extra
+        for l in reversed(range(self.NE)):
+            L, pf = ws['enc'][l], 'enc.%d.' % l
+            x_in = ws['enc'][l - 1]['y2'] if l > 0 else ws['x_enc']
+            gA = self._ffn_ln_bwd(L, pf, self.fe, cur, L['y1'], seed, self._site('enc', l, 1), p)
+            g2 = gy if cur is not gy else galt
+            self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), gA, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
+                                 (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
+                                 L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('enc', l, 0), p, B, S, S)
+            ops.colsum(ws['dqkv'], g[pf + 'bqkv'], self.partials, T, 3 * d)
+            self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
+            self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
+            cur = g2
+        ops.embed_ln_bwd(cur, sv['enc16'], self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], ws['me'], ws['re'], self.dptab,
+                         g['enc.pos'], g['lin.b'], g['enc.lne.w'], g['enc.lne.b'], self.partials, S, seed, self._site('enc_emb'), p)
+        # projected-table gradient -> embedding tables and the shared merge Linear (exact f32)
+        E, W = self.wf['emb'], self.wf['lin.w']
+        for i in range(8):
+            o, n = ops.SEG_OFF[i], ops.SEG_SIZES[i]
+            ops.gemm(self.dptab, W, g['emb'], M=n, N=256, K=d, dtype=PB_F32, b_kc=False, lda=d, ldb=2048, ldc=256, alpha=16.0, c_f32=True,
+                     a_off=o * d, b_off=256 * i, c_off=o * 256)
+            ops.gemm(self.dptab, E, g['lin.w'], M=d, N=256, K=n, dtype=PB_F32, a_kc=False, b_kc=False, lda=d, ldb=256, ldc=2048, alpha=16.0,
+                     c_f32=True, a_off=o * d, b_off=o * 256, c_off=256 * i)
+
+    def zero_accumulated_grads(self):
+        """Vector/table gradients are accumulated by the kernels (+=): zero them (and dP) before a backward."""
+        ops.fill_f32(self.Gcur[self.n_matrix:], 0.0)
+        ops.fill_f32(self.dptab, 0.0)
+
+    def heads_backward(self, dlogits, dec_hidden):
+        """dlogits (T,1280) storage dtype -> head grads + grad wrt decoder hidden (returned in ws['gy'][0])."""
+        ws, g, T, d = self._cur_ws, self.g, self._cur_ws['T'], self.d
+        ops.colsum(dlogits, g['head.b'], self.partials, T, ops.VOCAB)
+        self._wgrad(dlogits, dec_hidden, 'head.w', ops.VOCAB, d, T)
+        gy = ws['gy'][0]
+        self._dgrad(dlogits, 'head.w', gy, T, d, ops.VOCAB, False)
+        return gy
+
+    # ------------------------------------------------------------------ gradient buffer selection
+    def _select_grads(self, alt):
+        if alt and self.G32_alt is None:
+            self.G32_alt = torch.zeros_like(self.G32)
+        self.Gcur = self.G32_alt if alt else self.G32
+        self.g = {}
+        for name, s in self.slots.items():
+            self.g[name] = self.Gcur[s.off:s.off + s.numel].view(s.shape)
+
+    def grad_views_of(self, buf):
+        return [buf[self._elem_off(s, r):self._elem_off(s, r) + p.numel()].view(p.shape) for p, (s, r) in zip(self.params, self.param_slots)]
+
+    # ------------------------------------------------------------------ module-level (autograd) entry points
+    def _prep_inputs(self, enc_ids, dec_ids, emask, dmask):
+        if enc_ids.device != self.device:
+            raise PBError('inputs are on %s but the model is on %s' % (enc_ids.device, self.device))
+        enc16 = ops.ids_to_i16(enc_ids)
+        dec16 = ops.ids_to_i16(dec_ids) if dec_ids is not None else None
+        f = lambda m: None if m is None else m.to(dtype=torch.float32).contiguous()
+        return enc16, dec16, f(emask), f(dmask)
+
+    def _next_seed(self):
+        self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return self._seed
+
+    def module_forward_logits(self, enc_ids, dec_ids, emask, dmask, training):
+        if self.mlm is None:
+            raise PBError('engine has no LM heads')
+        if enc_ids.device.type != 'cuda':
+            raise PBError('pianobart_amd needs HIP device tensors (got %s); there is no CPU path' % enc_ids.device)
+        self.bind(enc_ids.device)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
+        return _LMFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, *self.params)
+
+    def module_forward_hidden(self, enc_ids, dec_ids, emask, dmask, training):
+        if enc_ids.device.type != 'cuda':
+            raise PBError('pianobart_amd needs HIP device tensors (got %s); there is no CPU path' % enc_ids.device)
+        self.bind(enc_ids.device)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
+        n_backbone = len(self.params) - (16 if self.mlm is not None else 0)
+        out = _HiddenFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, *self.params[:n_backbone])
+        return out
+
+    # ------------------------------------------------------------------ fused pre-train step (bench / Pretrainer)
+    def loss_and_grads(self, enc16, dec16, tgt16, loss_mask, emask, dmask, train=True, count_hook=None):
+        """Forward + fused CE/argmax/acc + full backward. Returns the (24,) device tensor of sums
+        {sum ce*m, sum m, sum correct*m} x 8 heads. `count_hook(counts)` may all-reduce the 8 mask counts (DP)."""
+        B, S = enc16.shape[:2]
+        T = B * S
+        seed = self._next_seed()
+        self._select_grads(False)
+        dec_h, _ = self.forward_hidden(enc16, dec16, emask, dmask, train, seed)
+        logits = self.heads_forward(dec_h)
+        ws = self._cur_ws
+        sums, counts, coef = self.scal[0:24], self.scal[24:32], self.scal[32:40]
+        ops.fill_f32(sums, 0.0)
+        lm = loss_mask.reshape(T, 8)
+        ops.mask_count(lm, counts)
+        if count_hook is not None:
+            count_hook(counts)
+        ops.loss_coef(counts, self.loss_w, coef)
+        ops.ce_fwd_bwd(logits, tgt16.reshape(T, 8), lm, sums, self.partials, coef, ws['dlogits'] if train else None, None)
+        if train:
+            self.zero_accumulated_grads()
+            gy = self.heads_backward(ws['dlogits'], dec_h)
+            self.backward(gy)
+        return sums
+
+    def optimizer_step(self, lr=2e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=3.0, gscale=1.0):
+        """clip_grad_norm_(3.0) + HF AdamW on the flat buffers, refreshing the bf16 shadow (pretrain.py:195-196)."""
+        if self.opt_m is None:
+            self.opt_m = torch.zeros_like(self.P32)
+            self.opt_v = torch.zeros_like(self.P32)
+        self.step_count += 1
+        sq, clip = self.scal[40:41], self.scal[41:42]
+        ops.grad_sqnorm(self.G32, self.partials, sq)
+        ops.clip_coef(sq, max_norm, gscale, clip)
+        ops.adamw_step(self.P32, self.G32, self.opt_m, self.opt_v, self.Pbf, clip, lr, betas[0], betas[1], eps, weight_decay, self.step_count)
+        if self.code == PB_BF16:
+            self._versions = sum(p._version for p in self.params)
+
+    # ------------------------------------------------------------------ generate (model.py:28-66)
+    def generate(self, enc_ids, emask, sample_row):
+        """Autoregressive decode. Encoder runs once; the decoder is re-evaluated per position (round 1: no KV cache
+        yet -- same tokens as the reference, which re-runs encoder AND decoder per position)."""
+        pb = self.pb
+        self.bind(enc_ids.device)
+        S = enc_ids.shape[1]
+        dev = enc_ids.device
+        pad = torch.from_numpy(pb.pad_word_np).to(dev)
+        dec = pad.repeat(1, S, 1)
+        result = pad.repeat(1, S, 1)
+        dmask = torch.zeros(1, S, dtype=torch.float32, device=dev)
+        dec[:, 0, :] = torch.tensor(pb.sos_word_np, device=dev)
+        dmask[:, 0] = 1
+        pad_cpu = torch.from_numpy(pb.pad_word_np)
+        em = emask.to(torch.float32).contiguous() if emask is not None else None
+        enc16 = ops.ids_to_i16(enc_ids)
+        with torch.no_grad():
+            for i in range(S):
+                dec16 = ops.ids_to_i16(dec)
+                dec_h, _ = self.forward_hidden(enc16, dec16, em, dmask, False, 0, reuse_encoder=(i > 0))
+                logits = self.heads_forward(dec_h)
+                cur = sample_row(logits[i].float().cpu())
+                if i != S - 1:
+                    dec[:, i + 1, :] = cur.to(dev)
+                    dmask[:, i + 1] += 1
+                if (cur >= pad_cpu).any():
+                    break
+                result[:, i, :] = cur.to(dev)
+        return result
+
+
+class _LMFn(torch.autograd.Function):
+    """PianoBartLM train branch as ONE autograd node around the explicit HIP forward/backward schedules."""
+
+    @staticmethod
+    def forward(ctx, eng, enc_ids, dec_ids, emask, dmask, training, need_grad, *params):
+        enc16, dec16, em, dm = eng._prep_inputs(enc_ids, dec_ids, emask, dmask)
+        B, S = enc16.shape[:2]
+        seed = eng._next_seed() if training else 0
+        dec_h, _ = eng.forward_hidden(enc16, dec16, em, dm, training, seed)
+        logits = eng.heads_forward(dec_h)
+        eng._fwd_token += 1
+        ctx.eng, ctx.token = eng, eng._fwd_token
+        out = logits.view(B, S, ops.VOCAB)
+        return out.clone()        # the workspace buffer is overwritten by the next forward
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.eng
+        if ctx.token != eng._fwd_token:
+            raise PBError('backward for a stale forward: the engine keeps the activations of the most recent forward only')
+        ws = eng._cur_ws
+        T = ws['T']
+        # if .grad already aliases our primary buffer (accumulation without zero_grad), write into the alternate one
+        p0 = eng.params[0]
+        alias = p0.grad is not None and p0.grad.data_ptr() == eng.grad_views[0].data_ptr()
+        eng._select_grads(alias)
+        dl = dlogits.reshape(T, ops.VOCAB).contiguous()
+        if eng.xdt == torch.float32:
+            dlx = dl.float()
+        else:
+            dlx = ws['dlogits']
+            ops.cast_f32_to_bf16(dl.float().contiguous(), dlx)
+        eng.zero_accumulated_grads()
+        gy = eng.heads_backward(dlx, eng._saved['dec_out'])
+        eng.backward(gy)
+        grads = eng.grad_views_of(eng.Gcur)
+        eng._select_grads(False)
+        return (None,) * 7 + tuple(grads)
+
+
+class _HiddenFn(torch.autograd.Function):
+    """PianoBart.forward (hidden states, f32 views for API compatibility)."""
+
+    @staticmethod
+    def forward(ctx, eng, enc_ids, dec_ids, emask, dmask, training, need_grad, *params):
+        enc16, dec16, em, dm = eng._prep_inputs(enc_ids, dec_ids, emask, dmask)
+        B, S = enc16.shape[:2]
+        seed = eng._next_seed() if training else 0
+        dec_h, enc_h = eng.forward_hidden(enc16, dec16, em, dm, training, seed)
+        if dec16 is None:
+            eng._saved = dict(enc16=enc16, dec16=None, emask=em, dmask=None, p=eng.p_drop if training else 0.0, seed=seed,
+                              enc_out=enc_h, dec_out=None, B=B, S=S)
+        eng._fwd_token += 1
+        ctx.eng, ctx.token, ctx.has_dec, ctx.nparams = eng, eng._fwd_token, dec16 is not None, len(params)
+        enc_o = enc_h.float().view(B, S, eng.d).clone() if enc_h.dtype == torch.float32 else enc_h.float().view(B, S, eng.d)
+        if dec16 is None:
+            return torch.zeros(0, device=enc_o.device), enc_o
+        dec_o = dec_h.float().view(B, S, eng.d).clone() if dec_h.dtype == torch.float32 else dec_h.float().view(B, S, eng.d)
+        return dec_o, enc_o
+
+    @staticmethod
+    def backward(ctx, d_dec, d_enc):
+        eng = ctx.eng
+        if ctx.token != eng._fwd_token:
+            raise PBError('backward for a stale forward: the engine keeps the activations of the most recent forward only')
+        ws = eng._cur_ws
+        T, d = ws['T'], eng.d
+        p0 = eng.params[0]
+        alias = p0.grad is not None and p0.grad.data_ptr() == eng.grad_views[0].data_ptr()
+        eng._select_grads(alias)
+        conv = lambda g: None if g is None else g.reshape(T, d).to(eng.xdt).contiguous()
+        eng.zero_accumulated_grads()
+        if ctx.has_dec:
+            eng.backward(conv(d_dec) if d_dec is not None else torch.zeros(T, d, dtype=eng.xdt, device=eng.device), conv(d_enc))
+        else:
+            eng.backward(None, conv(d_enc))
+        grads = eng.grad_views_of(eng.Gcur)[:ctx.nparams]
+        eng._select_grads(False)
+        return (None,) * 7 + tuple(grads)

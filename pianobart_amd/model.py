@@ -1,0 +1,289 @@
+"""Drop-in PianoBART classes for MI355X.
+
+Same public surface as the reference (PianoBart.py:9-91, model.py:14-126): `Embeddings`, `PianoBart`,
+`MLM`, `PianoBartLM`, `sampling`, `nucleus`, and the same `state_dict` layout. The
+modules below only *hold* the parameters under the reference's names; all arithmetic runs in the
+hand-written HIP kernels of libpianobart_hip.so through `pianobart_amd.engine.Engine`. There is no
+CPU execution path: calling forward with CPU tensors raises.
+"""
+import math
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import PBError
+
+CLASSES = ['Bar', 'Position', 'Instrument', 'Pitch', 'Duration', 'Velocity', 'TimeSig', 'Tempo']
+
+
+class BartConfig:
+    """Stand-in for transformers.BartConfig with the attributes the reference reads (main.py:39-47 sets the
+    first eight; the rest are BartConfig defaults). Any object with these attribute names is accepted."""
+
+    def __init__(self, max_position_embeddings=1024, d_model=1024, encoder_layers=12, encoder_ffn_dim=4096,
+                 encoder_attention_heads=16, decoder_layers=12, decoder_ffn_dim=4096, decoder_attention_heads=16,
+                 vocab_size=50265, dropout=0.1, attention_dropout=0.0, activation_dropout=0.0,
+                 activation_function="gelu", init_std=0.02, scale_embedding=False, pad_token_id=1, **kw):
+        self.max_position_embeddings = max_position_embeddings
+        self.d_model = d_model
+        self.encoder_layers = encoder_layers
+        self.encoder_ffn_dim = encoder_ffn_dim
+        self.encoder_attention_heads = encoder_attention_heads
+        self.decoder_layers = decoder_layers
+        self.decoder_ffn_dim = decoder_ffn_dim
+        self.decoder_attention_heads = decoder_attention_heads
+        self.vocab_size = vocab_size
+        self.dropout = dropout
+        self.attention_dropout = attention_dropout
+        self.activation_dropout = activation_dropout
+        self.activation_function = activation_function
+        self.init_std = init_std
+        self.scale_embedding = scale_embedding
+        self.pad_token_id = pad_token_id
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+# ---- parameter containers named exactly like transformers' BartModel (modeling_bart.py) -------------
+class _Attention(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = nn.Linear(d, d)
+        self.v_proj = nn.Linear(d, d)
+        self.q_proj = nn.Linear(d, d)
+        self.out_proj = nn.Linear(d, d)
+
+
+class _EncLayer(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.self_attn = _Attention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class _DecLayer(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.self_attn = _Attention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.encoder_attn = _Attention(d)
+        self.encoder_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class _Stack(nn.Module):
+    def __init__(self, cfg, shared, decoder):
+        super().__init__()
+        d = cfg.d_model
+        self.embed_tokens = shared      # dead 50265 x d table kept for checkpoint compatibility (never read)
+        self.embed_positions = nn.Embedding(cfg.max_position_embeddings + 2, d)
+        if decoder:
+            self.layers = nn.ModuleList([_DecLayer(d, cfg.decoder_ffn_dim) for _ in range(cfg.decoder_layers)])
+        else:
+            self.layers = nn.ModuleList([_EncLayer(d, cfg.encoder_ffn_dim) for _ in range(cfg.encoder_layers)])
+        self.layernorm_embedding = nn.LayerNorm(d)
+
+
+class _BartParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.shared = nn.Embedding(cfg.vocab_size, cfg.d_model, padding_idx=cfg.pad_token_id)
+        self.encoder = _Stack(cfg, self.shared, decoder=False)
+        self.decoder = _Stack(cfg, self.shared, decoder=True)
+        std = cfg.init_std
+        for m in self.modules():            # BartPreTrainedModel._init_weights distributions
+            if isinstance(m, nn.Linear):
+                m.weight.data.normal_(0.0, std)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Embedding):
+                m.weight.data.normal_(0.0, std)
+                if m.padding_idx is not None:
+                    m.weight.data[m.padding_idx].zero_()
+
+
+class Embeddings(nn.Module):
+    """PianoBart.py:9-16 (parameter holder; lut(x)*sqrt(d_model) is folded into the projected table)."""
+
+    def __init__(self, n_token, d_model):
+        super().__init__()
+        self.lut = nn.Embedding(n_token, d_model)
+        self.d_model = d_model
+
+    def forward(self, x):
+        raise PBError('Embeddings.forward is fused into the Octuple gather-sum HIP kernel; call PianoBart instead')
+
+
+def _check_cfg(cfg):
+    d = cfg.d_model
+    if d % 4 != 0 or d > 2048:
+        raise PBError('d_model=%d unsupported by the HIP row kernels (need a multiple of 4, <= 2048)' % d)
+    if cfg.encoder_attention_heads != cfg.decoder_attention_heads or d % cfg.encoder_attention_heads != 0:
+        raise PBError('encoder/decoder head counts must match and divide d_model')
+    if (d // cfg.encoder_attention_heads) % 8 != 0:
+        raise PBError('head_dim must be a multiple of 8')
+    if getattr(cfg, 'activation_function', 'gelu') != 'gelu':
+        raise PBError('only the exact-erf "gelu" activation of the reference is implemented')
+    if getattr(cfg, 'attention_dropout', 0.0) != 0.0 or getattr(cfg, 'activation_dropout', 0.0) != 0.0:
+        raise PBError('attention_dropout / activation_dropout must be 0 (reference defaults)')
+    if getattr(cfg, 'scale_embedding', False):
+        raise PBError('scale_embedding=True is not used by the reference and not implemented')
+
+
+class PianoBart(nn.Module):
+    """PianoBart.py:19-91. `precision`: "bf16" (throughput, bf16 MFMA) or "fp32" (exact-f32 parity path)."""
+
+    def __init__(self, bartConfig, e2w, w2e, precision='bf16'):
+        super().__init__()
+        _check_cfg(bartConfig)
+        self.bart = _BartParams(bartConfig)
+        self.hidden_size = bartConfig.d_model
+        self.bartConfig = bartConfig
+        self.n_tokens = []
+        self.classes = list(CLASSES)
+        for key in self.classes:
+            self.n_tokens.append(len(e2w[key]))
+        if self.n_tokens != ops.SEG_SIZES:
+            raise PBError('vocabulary sizes %s differ from the Octuple layout compiled into the kernels' % self.n_tokens)
+        self.emb_sizes = [256] * 8
+        self.e2w = e2w
+        self.w2e = w2e
+        self.bar_pad_word = self.e2w['Bar']['Bar <PAD>']
+        mk = lambda tag: np.array([self.e2w[e]['%s <%s>' % (e, tag)] for e in self.classes], dtype=np.int64)
+        self.mask_word_np = mk('MASK')
+        self.pad_word_np = mk('PAD')
+        self.sos_word_np = mk('SOS')
+        self.eos_word_np = mk('EOS')
+        self.word_emb = nn.ModuleList([Embeddings(self.n_tokens[i], self.emb_sizes[i]) for i in range(8)])
+        self.encoder_linear = nn.Linear(int(np.sum(self.emb_sizes)), bartConfig.d_model)
+        self.decoder_linear = self.encoder_linear
+        self.decoder_emb = None
+        self.precision = precision
+        object.__setattr__(self, '_engine', None)
+        object.__setattr__(self, '_engine_owner', None)
+
+    # -- engine plumbing ---------------------------------------------------------------------
+    def _get_engine(self):
+        if self._engine_owner is not None:
+            return self._engine_owner._get_engine()
+        if self._engine is None:
+            from .engine import Engine
+            object.__setattr__(self, '_engine', Engine(self, None, self.precision))
+        return self._engine
+
+    def forward(self, input_ids_encoder, input_ids_decoder=None, encoder_attention_mask=None,
+                decoder_attention_mask=None, output_hidden_states=True, generate=False):
+        if self.decoder_emb is not None:
+            raise PBError('change_decoder_embedding() path (TokenClassification) is outside the hot-path scope (SURVEY 8f-3)')
+        eng = self._get_engine()
+        dec_h, enc_h = eng.module_forward_hidden(input_ids_encoder, input_ids_decoder, encoder_attention_mask,
+                                                 decoder_attention_mask, self.training)
+        if input_ids_decoder is None:
+            return SimpleNamespace(last_hidden_state=enc_h)
+        return SimpleNamespace(last_hidden_state=dec_h, encoder_last_hidden_state=enc_h)
+
+    def get_rand_tok(self):
+        rand = [0] * 8
+        for i in range(8):
+            rand[i] = random.choice(range(self.n_tokens[i]))
+        return np.array(rand)
+
+    def change_decoder_embedding(self, new_embedding, new_linear=None):
+        self.decoder_emb = new_embedding
+        if new_linear is not None:
+            self.decoder_linear = new_linear
+
+
+class MLM(nn.Module):
+    """model.py:109-126 (parameter holder; the 8 heads run as one fused d x 1280 GEMM)."""
+
+    def __init__(self, e2w, n_tokens, hidden_size):
+        super().__init__()
+        self.proj = nn.ModuleList([nn.Linear(hidden_size, n_tokens[i]) for i, _ in enumerate(e2w)])
+        self.e2w = e2w
+
+    def forward(self, y):
+        raise PBError('MLM.forward is fused into PianoBartLM.forward (one d x 1280 HIP GEMM)')
+
+
+# -- nucleus sampling: host-side numpy exactly like the reference, so the RNG stream matches ----------
+def nucleus(probs, p):
+    """model.py:84-98 (mutates probs in place; draws from the global np.random)."""
+    probs /= (sum(probs) + 1e-5)
+    sorted_probs = np.sort(probs)[::-1]
+    sorted_index = np.argsort(probs)[::-1]
+    cusum_sorted_probs = np.cumsum(sorted_probs)
+    after_threshold = cusum_sorted_probs > p
+    if sum(after_threshold) > 0:
+        last_index = np.where(after_threshold)[0][0] + 1
+        candi_index = sorted_index[:last_index]
+    else:
+        candi_index = sorted_index[0:1]
+    candi_probs = [probs[i] for i in candi_index]
+    candi_probs /= sum(candi_probs)
+    word = np.random.choice(candi_index, size=1, p=candi_probs)[0]
+    return word
+
+
+def sampling(logit, p=None, t=1.0):
+    """model.py:101-107."""
+    logit = logit.squeeze()
+    probs = torch.softmax(logit / t, dim=-1)
+    probs = probs.cpu().detach().numpy()
+    return nucleus(probs, p=p)
+
+
+class PianoBartLM(nn.Module):
+    """model.py:14-78. Train branch returns a mutable list of 8 (B,S,n_i) f32 tensors with autograd;
+    generate=True runs the KV-cached HIP decode (same tokens as the reference's full re-run)."""
+
+    def __init__(self, pianobart: PianoBart):
+        super().__init__()
+        self.pianobart = pianobart
+        self.mask_lm = MLM(self.pianobart.e2w, self.pianobart.n_tokens, self.pianobart.hidden_size)
+        object.__setattr__(self, '_engine', None)
+        # plain attribute (bypass nn.Module registration: the LM must not become a child of its child)
+        object.__setattr__(pianobart, '_engine_owner', self)
+        object.__setattr__(pianobart, '_engine', None)
+
+    def _get_engine(self):
+        if self._engine is None:
+            from .engine import Engine
+            object.__setattr__(self, '_engine', Engine(self.pianobart, self.mask_lm, self.pianobart.precision))
+        return self._engine
+
+    def forward(self, input_ids_encoder, input_ids_decoder=None, encoder_attention_mask=None,
+                decoder_attention_mask=None, generate=False, device_num=-1):
+        eng = self._get_engine()
+        if not generate:
+            logits = eng.module_forward_logits(input_ids_encoder, input_ids_decoder, encoder_attention_mask,
+                                               decoder_attention_mask, self.training)
+            return [logits[..., ops.SEG_OFF[i]:ops.SEG_OFF[i + 1]] for i in range(8)]
+        if input_ids_encoder.shape[0] != 1:
+            print("ERROR")
+            exit(-1)
+        return eng.generate(input_ids_encoder, encoder_attention_mask, self.sample_row)
+
+    # model.py:68-78 -- temperatures / nucleus thresholds per head
+    SAMPLE_T = [1.2, 1.2, 5, 1, 2, 5, 5, 1.2]
+    SAMPLE_P = [1, 1, 1, 0.9, 0.9, 1, 1, 0.9]
+
+    def sample_row(self, row_logits):
+        """row_logits: (1280,) f32 tensor of one position; returns the 8 sampled ids (model.py:68-78)."""
+        out = []
+        for j in range(8):
+            y = row_logits[ops.SEG_OFF[j]:ops.SEG_OFF[j + 1]]
+            out.append(sampling(y, self.SAMPLE_P[j], self.SAMPLE_T[j]))
+        return torch.tensor(out)
+
+    def sample(self, x, index):
+        t, p = self.SAMPLE_T, self.SAMPLE_P
+        return torch.tensor([sampling(x[j][:, index, :], p[j], t[j]) for j in range(8)])

@@ -1,0 +1,77 @@
+"""CPU: host logic of the drop-in classes -- state_dict layout, checkpoint round trip with the
+oracle, loud failure without a HIP device. No compute."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import pianobart_oracle as O
+from tests.golden_util import GOLD, load_vocab, randomize_params
+
+E2W, W2E = load_vocab()
+
+
+def _cfgs(S, d, L, f, h):
+    from pianobart_amd.model import BartConfig
+    kw = dict(max_position_embeddings=S, d_model=d, encoder_layers=L, decoder_layers=L, encoder_ffn_dim=f,
+              decoder_ffn_dim=f, encoder_attention_heads=h, decoder_attention_heads=h)
+    return BartConfig(**kw), O.BartConfig(**kw)
+
+
+def test_state_dict_layout_and_roundtrip():
+    from pianobart_amd.model import PianoBart, PianoBartLM
+    g = json.load(open(os.path.join(GOLD, 'g9_state_dict.json')))
+    c, oc = _cfgs(128, 128, 2, 512, 4)
+    m = PianoBartLM(PianoBart(c, E2W, W2E))
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == g['cfg1']
+    assert sum(p.numel() for p in m.parameters()) == g['cfg1_n_params']
+    o = O.PianoBartLM(O.PianoBart(oc, E2W, W2E))
+    randomize_params(o, 3)
+    m.load_state_dict(o.state_dict(), strict=True)                 # reference-format checkpoint loads strictly
+    o2 = O.PianoBartLM(O.PianoBart(oc, E2W, W2E))
+    o2.load_state_dict(m.state_dict(), strict=True)                # and what we save loads back into the reference layout
+    for (k1, v1), (k2, v2) in zip(o.state_dict().items(), o2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    # pre-train checkpoints hold PianoBart only (pretrain.py:96-110): 105 tensors at 2 layers
+    assert len(m.pianobart.state_dict()) == 105
+    assert m.pianobart.decoder_linear is m.pianobart.encoder_linear
+    assert m.pianobart.bart.encoder.embed_tokens.weight is m.pianobart.bart.shared.weight
+
+
+def test_public_attributes():
+    from pianobart_amd.model import PianoBart
+    c, _ = _cfgs(32, 64, 1, 64, 4)
+    pb = PianoBart(c, E2W, W2E)
+    assert pb.n_tokens == [262, 134, 135, 262, 134, 38, 260, 55] and pb.hidden_size == 64 and pb.bar_pad_word == 256
+    assert list(pb.pad_word_np) == [256, 128, 129, 256, 128, 32, 254, 49]
+    assert list(pb.sos_word_np) == [258, 130, 131, 258, 130, 34, 256, 51]
+    assert list(pb.mask_word_np - pb.pad_word_np) == [1] * 8 and list(pb.eos_word_np - pb.pad_word_np) == [3] * 8
+    t = pb.get_rand_tok()
+    assert t.shape == (8,) and all(0 <= t[i] < pb.n_tokens[i] for i in range(8))
+
+
+def test_no_cpu_execution_path():
+    from pianobart_amd._lib import PBError
+    from pianobart_amd.model import PianoBart, PianoBartLM
+    c, _ = _cfgs(32, 64, 1, 64, 4)
+    m = PianoBartLM(PianoBart(c, E2W, W2E)).eval()
+    ids = torch.zeros(1, 32, 8, dtype=torch.long)
+    with pytest.raises(PBError):
+        m(ids, ids, torch.ones(1, 32), torch.ones(1, 32))
+    with pytest.raises(PBError):
+        m.pianobart(ids, None, torch.ones(1, 32), None)
+
+
+def test_engine_flat_layout_covers_every_live_parameter():
+    from pianobart_amd.engine import Engine
+    from pianobart_amd.model import PianoBart, PianoBartLM
+    c, _ = _cfgs(32, 64, 2, 128, 4)
+    m = PianoBartLM(PianoBart(c, E2W, W2E))
+    eng = Engine(m.pianobart, m.mask_lm, 'fp32')
+    pm = eng._param_map()
+    live = {id(p) for n, p in m.named_parameters() if 'shared' not in n and 'embed_tokens' not in n}
+    assert {id(p) for p, _, _ in pm} == live and len(pm) == len(live)
+    spans = sorted((eng._elem_off(s, r), eng._elem_off(s, r) + p.numel()) for p, s, r in pm)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))      # no overlap
+    assert spans[-1][1] <= eng.n_total
