@@ -387,7 +387,7 @@ def pretrain_loss(logits, target, loss_mask, e2w):
         ce = F.cross_entropy(logits[i].permute(0, 2, 1), target[..., i], reduction='none')
         m = loss_mask[..., i]
         losses.append(torch.sum(ce * m) / torch.sum(m))
-        a = torch.from_numpy(np.argmax(logits[i].detach().cpu().numpy(), axis=-1))
+        a = torch.from_numpy(np.argmax(logits[i].detach().cpu().numpy(), axis=-1)).to(target.device)
         arg.append(a)
         accs.append(torch.sum((target[..., i] == a).float() * m) / torch.sum(m))
     total = sum(l * wi for l, wi in zip(losses, w)) / sum(w)
