@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- PianoBART pre-train step throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one resident synthetic Octuple batch: forward (train mode,
+dropout 0.1 active) -> fused 8-head CE/argmax/acc -> full backward -> [RCCL gradient all-reduce] ->
+clip(3.0) -> HF AdamW (+ bf16 shadow refresh). Corrupted inputs, decoder inputs, loss mask and
+attention masks are already in HBM when the timed region starts (corruption excluded).
+Workload at N=1 = BASELINE.json configs[1]: 12L/768d/ffn3072/12 heads, S=1024, B=32, bf16.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+
+def train_flops_per_token(S, d, N, f, V=1280):
+    """Algorithmic FLOPs of the reference graph (SURVEY 8d / BASELINE.md 4): 1 MAC = 2 FLOP, train = 3 x forward,
+    causal decoder self-attention counted at 1/2, embedding merge counted as the reference's (T x 2048)(2048 x d) GEMMs."""
+    macs = 2 * S * 2048 * d + N * S * (4 * d * d + 2 * d * f) + N * 2 * S * S * d + N * S * (8 * d * d + 2 * d * f) \
+        + N * (S * S * d) + N * 2 * S * S * d + S * d * V
+    return 3 * 2 * macs / S
+
+
+def synth_batch(B, S, seed, device):
+    sys.path.insert(0, os.path.join(ROOT))
+    from tests.golden_util import synth_octuple_batch
+    return [t.to(device) for t in synth_octuple_batch(B, S, seed)]
+
+
+def cpu_baseline(cfgkw, S):
+    """The oracle (CPU restatement of the reference, kind "port") timed on this host's cores on a bounded
+    sample of the same workload: one full train step at the bench model shape with B=1 (tokens/s is
+    batch-insensitive on CPU; B=32 would take ~15 min). Checker code, timed only as the baseline."""
+    from oracle import pianobart_oracle as O
+    from tests.golden_util import load_vocab, synth_octuple_batch
+    e2w, w2e = load_vocab()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = O.PianoBartLM(O.PianoBart(O.BartConfig(**cfgkw), e2w, w2e)).train()
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(1, S, seed=3)
+    params = [p for p in m.parameters()]
+    opt_m = opt_v = None
+    times = []
+    for it in range(2):
+        t0 = time.time()
+        m.zero_grad()
+        y = m(enc, dec, emask, dmask)
+        total, *_ = O.pretrain_loss(y, target, loss_mask, e2w)
+        total.backward()
+        live = [p for p in params if p.grad is not None]
+        grads = [p.grad for p in live]
+        O.clip_grad_norm(grads, 3.0)
+        if opt_m is None:
+            opt_m = [torch.zeros_like(p) for p in live]; opt_v = [torch.zeros_like(p) for p in live]
+        with torch.no_grad():
+            O.hf_adamw_step([p.data for p in live], grads, opt_m, opt_v, step=it + 1, lr=2e-5)
+        times.append(time.time() - t0)
+    t = min(times)
+    return {"value": S / t, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": "oracle (torch fp32 restatement of the reference) full train step, same model shape, B=1 S=%d, best of 2 (%.1f s/step)" % (S, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--seq', type=int, default=1024)
+    ap.add_argument('--layers', type=int, default=12)
+    ap.add_argument('--hs', type=int, default=768)
+    ap.add_argument('--ffn', type=int, default=3072)
+    ap.add_argument('--heads', type=int, default=12)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dropout', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0)); local_rank = int(os.environ.get('LOCAL_RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU path): torch.cuda.is_available() is False')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from pianobart_amd import ops
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from pianobart_amd.parallel import GradReducer
+    from tests.golden_util import load_vocab
+    e2w, w2e = load_vocab()
+    cfgkw = dict(max_position_embeddings=args.seq, d_model=args.hs, encoder_layers=args.layers, decoder_layers=args.layers,
+                 encoder_ffn_dim=args.ffn, decoder_ffn_dim=args.ffn, encoder_attention_heads=args.heads,
+                 decoder_attention_heads=args.heads, dropout=0.0 if args.no_dropout else 0.1)
+    torch.manual_seed(0)
+    model = PianoBartLM(PianoBart(BartConfig(**cfgkw), e2w, w2e, precision=args.precision)).train().to(dev)
+    eng = model._get_engine()
+    eng.bind(dev)
+    B, S = args.batch, args.seq
+    enc, dec, loss_mask, emask, dmask, target = synth_batch(B, S, seed=1234 + rank, device=dev)
+    enc16, dec16, tgt16 = ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target)
+    loss_mask = loss_mask.contiguous()
+    reducer = GradReducer(eng, world) if world > 1 else None
+
+    def step():
+        sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=True,
+                                  count_hook=reducer.reduce_counts if reducer else None)
+        if reducer:
+            reducer.all_reduce_grads()
+        eng.optimizer_step(lr=2e-5, gscale=1.0)
+        return sums
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sums = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    ms_per_step = dt / args.steps * 1e3
+    tokens = B * S * world * args.steps
+    value = tokens / dt
+    fpt = train_flops_per_token(S, args.hs, args.layers, args.ffn)
+    step_tflops_per_gpu = fpt * B * S / (ms_per_step * 1e-3) / 1e12
+
+    # dominant kernel, measured live with HIP events on the launch stream: the bf16 NT GEMM at the fc1 shape
+    T = B * S
+    code = ops.dtype_code(eng.xdt)
+    x = torch.randn(T, args.hs, device=dev).to(eng.xdt); w = torch.randn(args.ffn, args.hs, device=dev).to(eng.xdt)
+    out = torch.empty(T, args.ffn, device=dev, dtype=eng.xdt)
+    for _ in range(3):
+        ops.gemm(x, w, out, M=T, N=args.ffn, K=args.hs, dtype=code)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nrep = 20
+    e0.record()
+    for _ in range(nrep):
+        ops.gemm(x, w, out, M=T, N=args.ffn, K=args.hs, dtype=code)
+    e1.record(); torch.cuda.synchronize()
+    gemm_ms = e0.elapsed_time(e1) / nrep
+    gemm_tflops = 2.0 * T * args.ffn * args.hs / (gemm_ms * 1e-3) / 1e12
+    peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3
+
+    if rank == 0:
+        s = sums.double().cpu()
+        w8 = torch.tensor([262, 134, 262, 134, 38, 135, 55, 260], dtype=torch.double)
+        loss = float(((s[0:8] / s[8:16]) * w8).sum() / w8.sum())
+        rec = {
+            "metric": "Octuple tokens/sec/GPU (seq=1024, 12L/768d) pretrain step; %MFMA peak",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "tokens_per_s_per_gpu": value / world,
+            "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / peak,
+            "train_loss": loss,
+            "config": {"workload": "pretrain step %dL/%dd/ffn%d/%dh S=%d B=%d/GPU dropout=%s (BASELINE configs[1])" %
+                       (args.layers, args.hs, args.ffn, args.heads, S, B, cfgkw['dropout']),
+                       "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world,
+                       "flops_per_token_train": fpt},
+            "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
+                         "traffic": None, "kernel": "gemm_kernel<%s,NT> fc1 shape M=%d N=%d K=%d" % (args.precision, T, args.ffn, args.hs),
+                         "avg_launch_ms": gemm_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(cfgkw, S)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -60,6 +60,7 @@ class Engine:
         self.step_count = 0
         self.opt_m = self.opt_v = None
         self._versions = None
+        self.grad_hook = None          # callable(lo, hi): flat gradient range is final (data-parallel bucketing)
 
     # ------------------------------------------------------------------ flat parameter layout
     def _layout(self):
@@ -351,6 +352,11 @@ class Engine:
         self._dgrad(du, pf + 'w1', gA, T, d, ff, True)
         return gA
 
+    def _ready(self, first, last=None):
+        if self.grad_hook is not None and self.Gcur is self.G32:
+            a, b = self.slots[first], self.slots[last or first]
+            self.grad_hook(a.off, b.off + b.numel)
+
     def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk):
         """Backward of y = LN(x_in + drop(out_proj(attn(q,k,v)))) up to dq/dk/dv. gy: grad wrt y; gout receives grad wrt x_in
         (residual path only; the projection paths are added by the caller)."""
@@ -402,6 +408,7 @@ class Engine:
                 self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
                 self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
                 cur = g2
+                self._ready(pf + 'wqkv', pf + 'w2')
             ops.embed_ln_bwd(cur, sv['dec16'], self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], ws['md'], ws['rd'], self.dptab,
                              g['dec.pos'], g['lin.b'], g['dec.lne.w'], g['dec.lne.b'], self.partials, S, seed, self._site('dec_emb'), p)
             cur = genc
@@ -421,6 +428,7 @@ class Engine:
             self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
             self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
             cur = g2
+            self._ready(pf + 'wqkv', pf + 'w2')
         ops.embed_ln_bwd(cur, sv['enc16'], self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], ws['me'], ws['re'], self.dptab,
                          g['enc.pos'], g['lin.b'], g['enc.lne.w'], g['enc.lne.b'], self.partials, S, seed, self._site('enc_emb'), p)
         # projected-table gradient -> embedding tables and the shared merge Linear (exact f32)
@@ -431,6 +439,9 @@ class Engine:
                      a_off=o * d, b_off=256 * i, c_off=o * 256)
             ops.gemm(self.dptab, E, g['lin.w'], M=d, N=256, K=n, dtype=PB_F32, a_kc=False, b_kc=False, lda=d, ldb=256, ldc=2048, alpha=16.0,
                      c_f32=True, a_off=o * d, b_off=o * 256, c_off=256 * i)
+        self._ready('emb', 'lin.w')
+        if self.grad_hook is not None and self.Gcur is self.G32:
+            self.grad_hook(self.n_matrix, self.n_total)          # vectors / position tables (accumulated region)
 
     def zero_accumulated_grads(self):
         """Vector/table gradients are accumulated by the kernels (+=): zero them (and dP) before a backward."""
@@ -444,6 +455,7 @@ class Engine:
         self._wgrad(dlogits, dec_hidden, 'head.w', ops.VOCAB, d, T)
         gy = ws['gy'][0]
         self._dgrad(dlogits, 'head.w', gy, T, d, ops.VOCAB, False)
+        self._ready('head.w')
         return gy
 
     # ------------------------------------------------------------------ gradient buffer selection
