@@ -89,6 +89,21 @@ int pb_softmax_fwd(const float* scores, const float* key_mask, void* P, int32_t 
 int pb_softmax_bwd(const float* dP, const void* P, void* dS, int64_t rows, int32_t Sk, float scale,
                    int32_t dtype, void* stream);
 
+/* ---- K4 fused (bf16): flash attention forward / backward, head_dim 32/64/128 --------------------
+ * Replaces modeling_bart.py:115-140 (eager) / F.scaled_dot_product_attention and its autograd backward.
+ * q,k,v,o,dout,dq,dk,dv: bf16, element (b,s,h,c) at ptr[b*sb + s*ss + h*hd + c]; lse, delta: (B,H,Sq) f32.
+ * dout must have o's strides. Backward = delta + dKV + dQ kernels (no atomics, deterministic). */
+int pb_flash_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask,
+                 int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss,
+                 int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss,
+                 float scale, int32_t causal, void* stream);
+int pb_flash_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                 const float* key_mask, void* dq, void* dk, void* dv, float* delta,
+                 int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss,
+                 int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss,
+                 int64_t dq_sb, int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss,
+                 float scale, int32_t causal, void* stream);
+
 /* ---- K9: fused 8-segment log-softmax + CE + argmax + masked accuracy (+ dlogits) ----------------
  * Replaces pretrain.py:112-118,163-189 (np.argmax x8, CrossEntropyLoss x8, masked means).
  * logits (T,V) f32 with the 8 heads at column offsets seg_off[i]; target (T,8) int16; loss_mask
@@ -100,7 +115,7 @@ int pb_ce_fwd_bwd(const float* logits, const int16_t* target, const float* loss_
                   int32_t T, int32_t V, int32_t dtype, void* stream);
 int64_t pb_ce_partials_floats(void);
 /* counts[i] = sum_t loss_mask[t,i]  (f32, 8) -- the M_i of pretrain.py:117 */
-int pb_mask_count(const float* loss_mask, float* counts, int64_t T, void* stream);
+int pb_mask_count(const float* loss_mask, float* counts, float* partials /* >= pb_ce_partials_floats() */, int64_t T, void* stream);
 /* coef[i] = w[i] / (sum_w * counts[i]) */
 int pb_loss_coef(const float* counts, const float* w /*device 8*/, float* coef, void* stream);
 

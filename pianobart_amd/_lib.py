@@ -6,6 +6,8 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- must be imported BEFORE dlopen(libpianobart_hip.so): both must share torch's HIP runtime
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'pianobart_hip.h')
 LIB_PATH = os.path.join(HERE, 'libpianobart_hip.so')

@@ -4,6 +4,7 @@
 // One wave64 per token row of V = sum n_i logits (f32); lane i < 8 carries head i's scalars.
 #include "pb_common.h"
 #include "pb_api_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -62,25 +63,40 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
         partials[(size_t)blockIdx.x * 24 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void ce_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ sums) {
-    const int k = threadIdx.x;
-    if (k >= 24) return;
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ sums) {
+    __shared__ float red[8][32];
+    const int k = threadIdx.x & 31, rg = threadIdx.x >> 5;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * 24 + k];
-    sums[k] += s;
+    if (k < 24)
+        for (int b = rg; b < nblk; b += 8) s += partials[(size_t)b * 24 + k];
+    red[rg][k] = s;
+    __syncthreads();
+    if (rg == 0 && k < 24) {
+        float t = 0.f;
+        for (int r = 0; r < 8; ++r) t += red[r][k];
+        sums[k] += t;
+    }
 }
 
-__global__ void mask_count_kernel(const float* __restrict__ loss_mask, float* __restrict__ counts, long T) {
-    // single block, deterministic: thread t sums column (t & 7) over a strided set of rows
+// counts: stage 1 = per-block column sums of a row range, stage 2 = sum of the block partials (deterministic)
+constexpr int MC_BLOCKS = 128;
+__global__ __launch_bounds__(256) void mask_count_kernel(const float* __restrict__ loss_mask, float* __restrict__ part, long T) {
     __shared__ float red[256];
     const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
     float s = 0.f;
-    for (long r = r0; r < T; r += 32) s += loss_mask[r * 8 + c];
+    for (long r = (long)blockIdx.x * 32 + r0; r < T; r += (long)gridDim.x * 32) s += loss_mask[r * 8 + c];
     red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < 8) {
         float t = 0.f;
         for (int k = 0; k < 32; ++k) t += red[k * 8 + threadIdx.x];
+        part[blockIdx.x * 8 + threadIdx.x] = t;
+    }
+}
+__global__ void mask_count_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ counts) {
+    if (threadIdx.x < 8) {
+        float t = 0.f;
+        for (int b = 0; b < nblk; ++b) t += part[b * 8 + threadIdx.x];
         counts[threadIdx.x] = t;
     }
 }
@@ -112,13 +128,16 @@ extern "C" int pb_ce_fwd_bwd(const float* logits, const int16_t* target, const f
     else
         hipLaunchKernelGGL((ce_kernel<float>), dim3(grid), dim3(256), 0, stream, logits, target, loss_mask, so, partials, coef, (float*)dlogits, argmax_out, T, V);
     PB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(32), 0, stream, partials, grid, sums);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, stream, partials, grid, sums);
     PB_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pb_mask_count(const float* loss_mask, float* counts, int64_t T, void* stream_) {
-    hipLaunchKernelGGL(mask_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, loss_mask, counts, (long)T);
+extern "C" int pb_mask_count(const float* loss_mask, float* counts, float* partials, int64_t T, void* stream_) {
+    const int nblk = (int)std::max(1L, std::min((long)MC_BLOCKS, (long)((T + 31) / 32)));
+    hipLaunchKernelGGL(mask_count_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream_, loss_mask, partials, (long)T);
+    PB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mask_count_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, partials, nblk, counts);
     PB_LAUNCH_CHECK();
     return 0;
 }

@@ -146,17 +146,22 @@ __global__ __launch_bounds__(LN_THREADS) void add_ln_bwd_kernel(const T* __restr
     write_partials<NIT, 3>(acc, partials, d, lds);
 }
 
-// out_k[c] += sum_blk partials[blk][k][c]   for k < nacc (NULL outputs skipped)
-__global__ void finalize_partials_kernel(const float* __restrict__ partials, int nblk, int nacc, int d,
-                                         float* o0, float* o1, float* o2, float* o3) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// out_k[c] += sum_blk partials[blk][k][c]   for k < nacc (NULL outputs skipped).
+// block = 64 columns x 4 row groups; grid (ceil(d/64), nacc).
+__global__ __launch_bounds__(256) void finalize_partials_kernel(const float* __restrict__ partials, int nblk, int nacc, int d,
+                                                                float* o0, float* o1, float* o2, float* o3) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     const int k = blockIdx.y;
-    if (c >= d) return;
     float* o = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
     if (!o) return;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partials[((size_t)b * nacc + k) * d + c];
-    o[c] += s;
+    if (c < d)
+        for (int b = ry; b < nblk; b += 4) s += partials[((size_t)b * nacc + k) * d + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < d) o[c] += red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
 }
 
 // ------------------------------------------------------------------ Octuple embed + pos + LN
@@ -322,7 +327,7 @@ extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, 
 
 static int launch_finalize(const float* partials, int nblk, int nacc, int d, float* o0, float* o1, float* o2, float* o3,
                            hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_partials_kernel, dim3((d + 255) / 256, nacc), dim3(256), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
+    hipLaunchKernelGGL(finalize_partials_kernel, dim3((d + 63) / 64, nacc), dim3(256), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
     PB_LAUNCH_CHECK();
     return 0;
 }

@@ -60,6 +60,7 @@ class Engine:
         self.step_count = 0
         self.opt_m = self.opt_v = None
         self._versions = None
+        self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 128))
         self.grad_hook = None          # callable(lo, hi): flat gradient range is final (data-parallel bucketing)
 
     # ------------------------------------------------------------------ flat parameter layout
@@ -204,7 +205,7 @@ class Engine:
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
 
         def attn_ws():
-            return dict(P=e(B, H, S, S))
+            return dict(lse=f(B, H, S)) if self.use_flash else dict(P=e(B, H, S, S))
 
         def layer(dec):
             ff = self.fd if dec else self.fe
@@ -218,7 +219,7 @@ class Engine:
                   x_enc=e(T, d), me=f(T), re=f(T), x_dec=e(T, d), md=f(T), rd=f(T),
                   enc=[layer(False) for _ in range(self.NE)], dec=[layer(True) for _ in range(self.ND)],
                   logits=f(T, ops.VOCAB) if self.mlm is not None else None,
-                  scores=f(B, H, S, S), dS=e(B, H, S, S),
+                  scores=None if self.use_flash else f(B, H, S, S), dS=None if self.use_flash else e(B, H, S, S), delta=f(B, H, S),
                   gy=[e(T, d), e(T, d)], gA=e(T, d), gB=e(T, d), gC=e(T, d), dqkv=e(T, 3 * d), dq=e(T, d), dkv=e(T, 2 * d),
                   du=e(T, max(self.fe, self.fd)), genc=e(T, d), dlogits=e(T, ops.VOCAB) if self.mlm is not None else None)
         self._ws_cache = {key: ws}          # keep one shape resident
@@ -232,6 +233,10 @@ class Engine:
         """q,k,v,out: (tensor, elem offset, row stride). Unfused form: QK^T -> masked softmax -> PV."""
         H, hd = self.H, self.hd
         ws = self._cur_ws
+        if self.use_flash:
+            ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
+            ops.flash_fwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), save['lse'], key_mask, B, H, Sq, Sk, hd, hd ** -0.5, causal)
+            return
         scores, P = ws['scores'], save['P']
         (qt, qo, ql), (kt, ko, kl), (vt, vo, vl), (ot, oo, ol) = q, k, v, out
         ops.gemm(qt, kt, scores, M=Sq, N=Sk, K=hd, dtype=self.code, lda=ql, ldb=kl, ldc=Sk, c_f32=True, nb1=B, nb2=H,
@@ -240,9 +245,15 @@ class Engine:
         ops.gemm(P, vt, ot, M=Sq, N=hd, K=Sk, dtype=self.code, b_kc=False, lda=Sk, ldb=vl, ldc=ol, nb1=B, nb2=H,
                  sA=(H * Sq * Sk, Sq * Sk), sB=(Sk * vl, hd), sC=(Sq * ol, hd), b_off=vo, c_off=oo)
 
-    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save):
+    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save, out=None, key_mask=None, causal=False):
         H, hd = self.H, self.hd
         ws = self._cur_ws
+        if self.use_flash:
+            ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
+            assert dout[1] == 0 and dout[2] == out[2]
+            ops.flash_bwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
+                          ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal)
+            return
         dP, dS, P = ws['scores'], ws['dS'], save['P']
         (qt, qo, ql), (kt, ko, kl), (vt, vo, vl) = q, k, v
         (dot, doo, dol) = dout
@@ -357,7 +368,7 @@ class Engine:
             a, b = self.slots[first], self.slots[last or first]
             self.grad_hook(a.off, b.off + b.numel)
 
-    def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk):
+    def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk, key_mask, causal):
         """Backward of y = LN(x_in + drop(out_proj(attn(q,k,v)))) up to dq/dk/dv. gy: grad wrt y; gout receives grad wrt x_in
         (residual path only; the projection paths are added by the caller)."""
         ws, g, d, T = self._cur_ws, self.g, self.d, self._cur_ws['T']
@@ -368,7 +379,7 @@ class Engine:
         gb = gB if p > 0 else gout
         self._wgrad(gb, ctx, wo, d, d, T)
         self._dgrad(gb, wo, gC, T, d, d, False)
-        self._attn_bwd((gC, 0, d), q, k, v, dq, dk, dv, B, Sq, Sk, attn_save)
+        self._attn_bwd((gC, 0, d), q, k, v, dq, dk, dv, B, Sq, Sk, attn_save, out=(ctx, 0, d), key_mask=key_mask, causal=causal)
 
     def backward(self, gy_dec, gy_enc_extra=None):
         """gy_dec: grad wrt decoder output (T,d) storage dtype (None for encoder-only). Writes all parameter gradients
@@ -392,7 +403,7 @@ class Engine:
                 g1 = gy if cur is not gy else galt
                 self._attn_block_bwd(L, pf, (pf + 'wo_c', pf + 'bo_c'), gA, L['y1'], (L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d),
                                      (ws['dq'], 0, d), (ws['dkv'], 0, 2 * d), (ws['dkv'], d, 2 * d), L['ctxc'], L['ac'], L['attnc'],
-                                     L['mc'], L['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1, seed, self._site('dec', l, 1), p, B, S, S)
+                                     L['mc'], L['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1, seed, self._site('dec', l, 1), p, B, S, S, emask, False)
                 ops.colsum(ws['dq'], g[pf + 'bq_c'], self.partials, T, d)
                 self._wgrad(ws['dq'], L['y1'], pf + 'wq_c', d, d, T)
                 self._dgrad(ws['dq'], pf + 'wq_c', g1, T, d, d, True)
@@ -403,7 +414,7 @@ class Engine:
                 g2 = gy if g1 is not gy else galt
                 self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), g1, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
                                      (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
-                                     L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('dec', l, 0), p, B, S, S)
+                                     L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('dec', l, 0), p, B, S, S, dmask, True)
                 ops.colsum(ws['dqkv'], g[pf + 'bqkv'], self.partials, T, 3 * d)
                 self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
                 self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
@@ -423,7 +434,7 @@ class Engine:
             g2 = gy if cur is not gy else galt
             self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), gA, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
                                  (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
-                                 L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('enc', l, 0), p, B, S, S)
+                                 L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('enc', l, 0), p, B, S, S, emask, False)
             ops.colsum(ws['dqkv'], g[pf + 'bqkv'], self.partials, T, 3 * d)
             self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
             self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
@@ -515,7 +526,7 @@ class Engine:
         sums, counts, coef = self.scal[0:24], self.scal[24:32], self.scal[32:40]
         ops.fill_f32(sums, 0.0)
         lm = loss_mask.reshape(T, 8)
-        ops.mask_count(lm, counts)
+        ops.mask_count(lm, counts, self.partials)
         if count_hook is not None:
             count_hook(counts)
         ops.loss_coef(counts, self.loss_w, coef)

@@ -212,7 +212,8 @@ def test_ce_fwd_bwd(ops, dt):
     m[:, 5] = 0; m[0, 5] = 1
     w = torch.tensor([262, 134, 262, 134, 38, 135, 55, 260], device='cuda', dtype=torch.float32)
     counts = torch.empty(8, device='cuda'); coef = torch.empty(8, device='cuda')
-    ops.mask_count(m, counts); ops.loss_coef(counts, w, coef)
+    partials = torch.empty(int(ops.LIB.query('pb_ce_partials_floats')), device='cuda')
+    ops.mask_count(m, counts, partials); ops.loss_coef(counts, w, coef)
     assert torch.allclose(counts, m.sum(0))
     sums = torch.zeros(24, device='cuda')
     partials = torch.empty(int(ops.LIB.query('pb_ce_partials_floats')), device='cuda')
@@ -257,3 +258,46 @@ def test_optimizer_kernels(ops):
     x = torch.randn(1027, device='cuda', generator=g); xb = torch.empty(1027, device='cuda', dtype=torch.bfloat16); xf = torch.empty(1027, device='cuda')
     ops.cast_f32_to_bf16(x, xb); ops.cast_bf16_to_f32(xb, xf)
     assert torch.equal(xb, x.to(torch.bfloat16)) and torch.equal(xf, xb.float())
+
+
+@pytest.mark.parametrize('hd', [32, 64, 128])
+@pytest.mark.parametrize('causal', [False, True])
+@pytest.mark.parametrize('S', [64, 200, 136])
+def test_flash_attention_fwd_bwd(ops, hd, causal, S):
+    """Fused attention (bf16) vs an fp64 reference incl. key-padding masks, causal, ragged S and zero rows."""
+    g = torch.Generator(device='cuda').manual_seed(hd + S)
+    B, H = 2, 3
+    d = H * hd
+    qkv = (torch.randn(B, S, 3 * d, device='cuda', generator=g) * 1.5).to(torch.bfloat16)
+    km = (torch.rand(B, S, device='cuda', generator=g) > 0.25).float()
+    km[0, 0] = 0                       # causal row 0 of batch 0 sees nothing -> zero row
+    km[1, S // 2:] = 0                 # padded tail
+    out = torch.full((B, S, d), float('nan'), device='cuda', dtype=torch.bfloat16)
+    lse = torch.empty(B, H, S, device='cuda')
+    scale = hd ** -0.5
+    sl = lambda off: (qkv, off, 3 * d, S * 3 * d)
+    ops.flash_fwd(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), lse, km, B, H, S, S, hd, scale, causal)
+    qd = qkv.double().requires_grad_(True)
+    q = qd[..., :d].reshape(B, S, H, hd).permute(0, 2, 1, 3)
+    k = qd[..., d:2 * d].reshape(B, S, H, hd).permute(0, 2, 1, 3)
+    v = qd[..., 2 * d:].reshape(B, S, H, hd).permute(0, 2, 1, 3)
+    vis = (km != 0)[:, None, None, :].expand(B, H, S, S)
+    if causal:
+        vis = vis & torch.ones(S, S, dtype=torch.bool, device='cuda').tril()
+    s = (q @ k.transpose(2, 3) * scale).masked_fill(~vis, float('-inf'))
+    p = torch.where(vis.any(-1, keepdim=True), torch.softmax(s, -1), torch.zeros_like(s))
+    p = torch.nan_to_num(p, nan=0.0)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, S, d)
+    assert float((out.double() - ref).abs().max()) < 3e-2
+    has = vis.any(-1)
+    ref_lse = torch.logsumexp(s, -1)
+    assert float((lse.double() - ref_lse)[has].abs().max()) < 2e-2
+    dout = torch.randn(B, S, d, device='cuda', generator=g).to(torch.bfloat16)
+    ref.backward(dout.double())
+    dqkv = torch.full((B, S, 3 * d), float('nan'), device='cuda', dtype=torch.bfloat16)
+    delta = torch.empty(B, H, S, device='cuda')
+    dsl = lambda off: (dqkv, off, 3 * d, S * 3 * d)
+    ops.flash_bwd(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), dout, lse, km, dsl(0), dsl(d), dsl(2 * d), delta, B, H, S, S, hd, scale, causal)
+    gref = qd.grad
+    err = float((dqkv.double() - gref).abs().max() / gref.abs().max())
+    assert err < 3e-2, err
