@@ -33,6 +33,7 @@ const char* pb_last_error(void);
 #define PB_GEMM_C_F32 2          /* C is float regardless of dtype                   */
 #define PB_GEMM_GELU 4           /* aux_out = pre-activation; C = gelu_erf(result)    */
 #define PB_GEMM_MUL_GELU_GRAD 8  /* C = result * gelu'(aux_in)                        */
+#define PB_GEMM_FORCE_V1 16      /* use the generic register-staged kernel (tests)    */
 typedef struct pb_gemm_desc {
     const void* A; const void* B; void* C;
     const float* bias;            /* per-n, may be NULL */
@@ -42,6 +43,8 @@ typedef struct pb_gemm_desc {
     int64_t lda, ldb, ldc, ldaux;
     int64_t sA1, sA2, sB1, sB2, sC1, sC2;
     float alpha; float _pad2;
+    int32_t splitk; int32_t _pad3;   /* >1: split K over blockIdx.z into f32 slabs (bf16, f32 C, no epilogue) */
+    void* slabs;                      /* workspace of splitk*M*N floats when splitk > 1 */
 } pb_gemm_desc;
 int pb_gemm(const pb_gemm_desc* d, void* stream);
 

@@ -25,7 +25,8 @@ class GemmDesc(ctypes.Structure):
                 ('lda', ctypes.c_int64), ('ldb', ctypes.c_int64), ('ldc', ctypes.c_int64), ('ldaux', ctypes.c_int64),
                 ('sA1', ctypes.c_int64), ('sA2', ctypes.c_int64), ('sB1', ctypes.c_int64), ('sB2', ctypes.c_int64),
                 ('sC1', ctypes.c_int64), ('sC2', ctypes.c_int64),
-                ('alpha', ctypes.c_float), ('_pad2', ctypes.c_float)]
+                ('alpha', ctypes.c_float), ('_pad2', ctypes.c_float),
+                ('splitk', ctypes.c_int32), ('_pad3', ctypes.c_int32), ('slabs', ctypes.c_void_p)]
 
 
 _SCALARS = {'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64,

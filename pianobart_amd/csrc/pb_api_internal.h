@@ -1,3 +1,6 @@
 // Internal: the public C ABI plus shared launch helpers.
 #pragma once
 #include "../../include/pianobart_hip.h"
+
+// pb_gemm2.hip: bf16 fast path; returns 1 when it declines (caller falls back), 0 ok, <0 error.
+int pb_gemm2_try(const pb_gemm_desc* d, void* stream);

@@ -309,6 +309,10 @@ extern "C" int pb_gemm(const pb_gemm_desc* d, void* stream_) {
     PB_REQUIRE(d->A && d->B && d->C, "pb_gemm: null operand");
     PB_REQUIRE(!(d->flags & PB_GEMM_GELU) || d->aux_out, "pb_gemm: GELU epilogue needs aux_out");
     PB_REQUIRE(!(d->flags & PB_GEMM_MUL_GELU_GRAD) || d->aux_in, "pb_gemm: gelu-grad epilogue needs aux_in");
+    if (!(d->flags & PB_GEMM_FORCE_V1)) {
+        const int r2 = pb_gemm2_try(d, stream_);
+        if (r2 <= 0) return r2;
+    }
     const int esz = d->dtype == PB_BF16 ? 2 : 4, epv = 16 / esz;
     GemmArgs a;
     a.A = d->A; a.B = d->B; a.C = d->C; a.bias = d->bias; a.aux_in = d->aux_in; a.aux_out = d->aux_out;

@@ -61,6 +61,7 @@ class Engine:
         self.opt_m = self.opt_v = None
         self._versions = None
         self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 128))
+        self._slabs = None
         self.grad_hook = None          # callable(lo, hi): flat gradient range is final (data-parallel bucketing)
 
     # ------------------------------------------------------------------ flat parameter layout
@@ -340,8 +341,18 @@ class Engine:
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dy, x, gname, M, N, T, ldy=None, ldx=None, dy_off=0, x_off=0, g_off=0):
         """G[gname] (M,N) = dy(T,M)^T @ x(T,N)  (TN GEMM into the f32 gradient buffer)."""
+        nsplit, slabs = 1, None
+        if self.code == PB_BF16:
+            tiles = ((M + 127) // 128) * ((N + 127) // 128)
+            while tiles * nsplit < 512 and nsplit < 32 and T % (128 * nsplit) == 0:
+                nsplit *= 2
+            if nsplit > 1:
+                need = nsplit * M * N
+                if self._slabs is None or self._slabs.numel() < need:
+                    self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
+                slabs = self._slabs
         ops.gemm(dy, x, self.g[gname], M=M, N=N, K=T, dtype=self.code, a_kc=False, b_kc=False, lda=ldy or M, ldb=ldx or N, ldc=N,
-                 c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off)
+                 c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off, splitk=nsplit, slabs=slabs)
 
     def _dgrad(self, dy, wname, out, T, N, K, accum, ldy=None, **kw):
         """out(T,N) (+)= dy(T,K) @ W(K,N)   (NN GEMM, W stored [K][N])."""
