@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int LN_THREADS = 256, LN_WAVES = 4, LN_MAX_BLOCKS = 1024;
+constexpr int LN_THREADS = 256, LN_WAVES = 4, LN_MAX_BLOCKS = 512;
 
 __device__ __forceinline__ DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
     DropCfg d;
@@ -275,15 +275,28 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(const T* __res
 }
 
 // ------------------------------------------------------------------ column sums (bias grads)
-// grid (ceil(N/256), nrb): thread owns one column over a row block.
+// grid (ceil(N/256), nrb): a lane owns 4 adjacent columns (8/16-byte loads), the 4 waves of a block take
+// interleaved rows of the block's row range, 4 rows in flight per lane; waves are combined through LDS.
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ dy, long ld, float* __restrict__ partials, int rows, int N, int rows_per_blk) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, long ld, float* __restrict__ partials, int rows, int N, int rows_per_blk) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += to_f(dy[(long)r * ld + c]);
-    partials[(size_t)blockIdx.y * N + c] = s;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        int r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            const f32x4 a = load4(dy + (long)r * ld + c), b = load4(dy + (long)(r + 4) * ld + c);
+            const f32x4 e = load4(dy + (long)(r + 8) * ld + c), f = load4(dy + (long)(r + 12) * ld + c);
+            s += (a + b) + (e + f);
+        }
+        for (; r < r1; r += 4) s += load4(dy + (long)r * ld + c);
+    }
+    *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = s;
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < N) partials[(size_t)blockIdx.y * N + cc] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 int ln_grid(int rows) { return max(1, min((rows + LN_WAVES - 1) / LN_WAVES, LN_MAX_BLOCKS)); }
@@ -411,9 +424,9 @@ extern "C" int64_t pb_colsum_partials_floats(int32_t N) { return (int64_t)256 * 
 extern "C" int pb_colsum(const void* dy, int64_t ld, float* out, float* partials, int32_t T, int32_t N, int32_t dtype,
                          int32_t src_f32, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    PB_REQUIRE(T >= 0 && N > 0, "pb_colsum: bad shape");
+    PB_REQUIRE(T >= 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "pb_colsum: N and ld must be multiples of 4");
     if (T == 0) return 0;
-    const int nrb = max(1, min(256, (T + 63) / 64));
+    const int nrb = max(1, min(128, (T + 63) / 64));
     const int rpb = (T + nrb - 1) / nrb;
     dim3 grid((N + 255) / 256, nrb);
     if (src_f32 || dtype == PB_F32)

@@ -18,7 +18,7 @@ def test_header_parses_and_library_exports_all():
     for name in decls:
         assert hasattr(dll, name), 'library does not export %s' % name
     assert _lib.LIB.query('pb_abi_version') == 1
-    assert _lib.LIB.query('pb_ln_partials_floats', 768) == 1024 * 3 * 768
+    assert _lib.LIB.query('pb_ln_partials_floats', 768) == 512 * 3 * 768
 
 
 def test_gemm_desc_layout_matches_header():

@@ -262,8 +262,9 @@ def test_optimizer_kernels(ops):
 
 @pytest.mark.parametrize('hd', [32, 64, 128])
 @pytest.mark.parametrize('causal', [False, True])
-@pytest.mark.parametrize('S', [64, 200, 136])
-def test_flash_attention_fwd_bwd(ops, hd, causal, S):
+@pytest.mark.parametrize('S', [64, 200, 136, 384])
+@pytest.mark.parametrize('generic', [False, True])
+def test_flash_attention_fwd_bwd(ops, hd, causal, S, generic):
     """Fused attention (bf16) vs an fp64 reference incl. key-padding masks, causal, ragged S and zero rows."""
     g = torch.Generator(device='cuda').manual_seed(hd + S)
     B, H = 2, 3
@@ -276,7 +277,7 @@ def test_flash_attention_fwd_bwd(ops, hd, causal, S):
     lse = torch.empty(B, H, S, device='cuda')
     scale = hd ** -0.5
     sl = lambda off: (qkv, off, 3 * d, S * 3 * d)
-    ops.flash_fwd(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), lse, km, B, H, S, S, hd, scale, causal)
+    ops.flash_fwd(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), lse, km, B, H, S, S, hd, scale, causal, force_generic=generic)
     qd = qkv.double().requires_grad_(True)
     q = qd[..., :d].reshape(B, S, H, hd).permute(0, 2, 1, 3)
     k = qd[..., d:2 * d].reshape(B, S, H, hd).permute(0, 2, 1, 3)
@@ -297,7 +298,7 @@ def test_flash_attention_fwd_bwd(ops, hd, causal, S):
     dqkv = torch.full((B, S, 3 * d), float('nan'), device='cuda', dtype=torch.bfloat16)
     delta = torch.empty(B, H, S, device='cuda')
     dsl = lambda off: (dqkv, off, 3 * d, S * 3 * d)
-    ops.flash_bwd(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), dout, lse, km, dsl(0), dsl(d), dsl(2 * d), delta, B, H, S, S, hd, scale, causal)
+    ops.flash_bwd(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), dout, lse, km, dsl(0), dsl(d), dsl(2 * d), delta, B, H, S, S, hd, scale, causal, force_generic=generic)
     gref = qd.grad
     err = float((dqkv.double() - gref).abs().max() / gref.abs().max())
     assert err < 3e-2, err
