@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, l
     if (cc < N) partials[(size_t)blockIdx.y * N + cc] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-int ln_grid(int rows) { return max(1, min((rows + LN_WAVES - 1) / LN_WAVES, LN_MAX_BLOCKS)); }
+int ln_grid(int rows) { return max(1, min((rows + LN_WAVES - 1) / LN_WAVES, LN_MAX_BLOCKS)); }        // kernels that write per-block partials
+int ln_grid_fwd(int rows) { return max(1, min((rows + LN_WAVES - 1) / LN_WAVES, 2048)); }
 
 }  // namespace
 
@@ -326,7 +327,7 @@ extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, 
     hipStream_t stream = (hipStream_t)stream_;
     if (check_ln_dims("pb_add_ln_fwd", T, d)) return -2;
     if (T == 0) return 0;
-    const int grid = ln_grid(T);
+    const int grid = ln_grid_fwd(T);
     PB_LN_DISPATCH(nit_for(d),
         if (dtype == PB_BF16)
             hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, (const bf16_t*)res,
@@ -383,7 +384,7 @@ extern "C" int pb_embed_ln_fwd(const int16_t* ids16, const float* P, const int32
     if (T == 0) return 0;
     SegOff so;
     for (int i = 0; i < 8; ++i) so.off[i] = seg_off[i];
-    const int grid = ln_grid(T);
+    const int grid = ln_grid_fwd(T);
     PB_LN_DISPATCH(nit_for(d),
         if (dtype == PB_BF16)
             hipLaunchKernelGGL((embed_ln_fwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, ids16, P, so, lin_bias,
