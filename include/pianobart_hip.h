@@ -34,6 +34,8 @@ const char* pb_last_error(void);
 #define PB_GEMM_GELU 4           /* aux_out = pre-activation; C = gelu_erf(result)    */
 #define PB_GEMM_MUL_GELU_GRAD 8  /* C = result * gelu'(aux_in)                        */
 #define PB_GEMM_FORCE_V1 16      /* use the generic register-staged kernel (tests)    */
+#define PB_GEMM_TILE128 32       /* bf16 fast path: force the 128x128 tile             */
+#define PB_GEMM_TILE256 64       /* bf16 fast path: prefer the 256x256 tile (default when M >= 512, N >= 256) */
 typedef struct pb_gemm_desc {
     const void* A; const void* B; void* C;
     const float* bias;            /* per-n, may be NULL */

@@ -22,8 +22,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NT2 = 256;
-constexpr int OPER_BYTES = 16384, STAGE_BYTES = 2 * OPER_BYTES;
+constexpr int BK = 64;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct Gemm2Args {
@@ -43,36 +42,43 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// K-contiguous operand tile: rows r0..r0+127 (clamped to R-1), k0..k0+63. Image [128][128 B], chunk-swizzled.
+// K-contiguous operand tile: rows r0..r0+RT-1 (clamped to R-1), k0..k0+63. Image [RT][128 B], chunk-swizzled.
+// RT*128 bytes = RT/8 DMA pieces of 1 KiB, dealt round-robin to the NW waves.
+template <int RT, int NW>
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ base, long ld, int r0, int k0, int R, char* lds, int wave, int lane) {
+    constexpr int PPW = (RT / 8) / NW;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int inst = wave * 4 + n;
+    for (int n = 0; n < PPW; ++n) {
+        const int inst = wave * PPW + n;
         const int row = inst * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ kswz(row);
         const int gr = min(r0 + row, R - 1);
         glds16(base + (long)gr * ld + k0 + chunk * 8, lds + inst * 1024);
     }
 }
-// Row-contiguous operand tile ([K][R] in memory): k rows k0..k0+63, columns r0..r0+127 (clamped). Image [64][256 B].
+// Row-contiguous operand tile ([K][R] in memory): k rows k0..k0+63, columns r0..r0+RT-1 (clamped). Image [64][RT*2 B].
+template <int RT, int NW>
 __device__ __forceinline__ void stage_rc(const bf16_t* __restrict__ base, long ld, int r0, int k0, int R, char* lds, int wave, int lane) {
+    constexpr int PPW = (RT / 8) / NW;            // pieces per wave (64 * RT * 2 / 1024 = RT / 8 pieces)
+    constexpr int RPP = 512 / RT;                 // k-rows per piece
+    constexpr int LPR = 64 / RPP;                 // lanes (16-B chunks) per row
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int inst = wave * 4 + n;
-        const int krow = inst * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ rswz(krow);
+    for (int n = 0; n < PPW; ++n) {
+        const int inst = wave * PPW + n;
+        const int krow = inst * RPP + lane / LPR;
+        const int chunk = (lane % LPR) ^ rswz(krow);
         const int gc = min(r0 + chunk * 8, R - 8);
         glds16(base + (long)(k0 + krow) * ld + gc, lds + inst * 1024);
     }
 }
-template <bool KC>
+template <bool KC, int RT, int NW>
 __device__ __forceinline__ void stage(const bf16_t* base, long ld, int r0, int k0, int R, char* lds, int wave, int lane) {
-    if constexpr (KC) stage_kc(base, ld, r0, k0, R, lds, wave, lane);
-    else stage_rc(base, ld, r0, k0, R, lds, wave, lane);
+    if constexpr (KC) stage_kc<RT, NW>(base, ld, r0, k0, R, lds, wave, lane);
+    else stage_rc<RT, NW>(base, ld, r0, k0, R, lds, wave, lane);
 }
 
 // MFMA fragment (8 k-values 32 ks + 8 g + j of row `row16 + lane&15`).
-template <bool KC>
+template <bool KC, int RT>
 __device__ __forceinline__ bf16x8 frag(const char* lds, int rbase /*multiple of 16*/, int ks, int lane) {
     const int lr = lane & 15, g = lane >> 4;
     if constexpr (KC) {
@@ -83,8 +89,8 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int rbase /*multiple of 
         const int q = lr >> 2, pp = lr & 3;
         const int kb = ks * 32 + g * 8;
         const int chunk = (rbase >> 3) + (pp >> 1);
-        const int off0 = (kb + q) * 256 + ((chunk ^ rswz(kb + q)) << 4) + ((pp & 1) << 3);
-        const int off1 = (kb + 4 + q) * 256 + ((chunk ^ rswz(kb + 4 + q)) << 4) + ((pp & 1) << 3);
+        const int off0 = (kb + q) * (RT * 2) + ((chunk ^ rswz(kb + q)) << 4) + ((pp & 1) << 3);
+        const int off1 = (kb + 4 + q) * (RT * 2) + ((chunk ^ rswz(kb + 4 + q)) << 4) + ((pp & 1) << 3);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + off0));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + off1));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -93,12 +99,18 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int rbase /*multiple of 
     }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(NT2) void gemm2_kernel(const Gemm2Args p) {
+// WM x WN waves, each TM x TN MFMA tiles of 16x16: block tile BM = 16*WM*TM by BN = 16*WN*TN.
+// Measured (tools/gemm_probe.py, MI355X): the 128x128 main loop is bound by the L2 -> LDS load path (~60 GB/s per CU,
+// 64 FLOP per loaded byte -> ~1 PF ceiling), the 256x256 one reaches 1.1-1.2 PF; the output write (HBM write rate,
+// ~3.1 TB/s) is NOT overlapped with the main loop yet (next: deferred stores under the following tile's K loop).
+template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WM * WN, BM = 16 * WM * TM, BN = 16 * WN * TN;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     int bid = blockIdx.x;
     const int ntiles = p.tiles_m * p.tiles_n;
     {
@@ -112,67 +124,73 @@ __global__ __launch_bounds__(NT2) void gemm2_kernel(const Gemm2Args p) {
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
     const long coff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
     const int kbeg = zs * p.Kc, kend = min(p.K, kbeg + p.Kc);
-    const int nk = (kend - kbeg) / BK;
+    const int nk = (p.flags & 256) ? 0 : max(0, kend - kbeg) / BK;   // bit 8: profiling build of the epilogue alone
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage<A_KC>(A, p.lda, m0, kbeg, p.M, smem, wave, lane);
-    stage<B_KC>(B, p.ldb, n0, kbeg, p.N, smem + OPER_BYTES, wave, lane);
+    if (nk > 0) {
+        stage<A_KC, BM, NW>(A, p.lda, m0, kbeg, p.M, smem, wave, lane);
+        stage<B_KC, BN, NW>(B, p.ldb, n0, kbeg, p.N, smem + A_BYTES, wave, lane);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const char* cur = smem + (kt & 1) * STAGE_BYTES;
         char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
         if (kt + 1 < nk) {
-            stage<A_KC>(A, p.lda, m0, kbeg + (kt + 1) * BK, p.M, nxt, wave, lane);
-            stage<B_KC>(B, p.ldb, n0, kbeg + (kt + 1) * BK, p.N, nxt + OPER_BYTES, wave, lane);
+            stage<A_KC, BM, NW>(A, p.lda, m0, kbeg + (kt + 1) * BK, p.M, nxt, wave, lane);
+            stage<B_KC, BN, NW>(B, p.ldb, n0, kbeg + (kt + 1) * BK, p.N, nxt + A_BYTES, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[4], b[4];
+            bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = frag<A_KC>(cur, wm * 64 + i * 16, ks, lane);
-                b[i] = frag<B_KC>(cur + OPER_BYTES, wn * 64 + i * 16, ks, lane);
-            }
+            for (int i = 0; i < TM; ++i) a[i] = frag<A_KC, BM>(cur, (wm * TM + i) * 16, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < TN; ++j) b[j] = frag<B_KC, BN>(cur + A_BYTES, (wn * TN + j) * 16, ks, lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();          // hipcc adds s_waitcnt vmcnt(0) here: next tile has landed, current one is free
     }
+    if (p.flags & 128) return;                                      // bit 7: profiling build without the epilogue
 
-    // ---- epilogue through LDS: per wave a 32 x 64 f32 panel (row stride 68 floats), two passes ----
+    // ---- epilogue through LDS: per wave a 32 x (16 TN) f32 panel, TM/2 passes ----
+    constexpr int PW = 16 * TN + 4;                                 // panel row stride (floats)
+    constexpr int LPRW = (16 * TN) / 4;                             // lanes per panel row in the read-back phase
+    constexpr int RPI = 64 / LPRW;                                  // rows per read-back iteration
     const int lr = lane & 15, lg = lane >> 4;
     const bool accum = p.flags & PB_GEMM_ACCUM, c32 = p.flags & PB_GEMM_C_F32;
     const bool do_gelu = p.flags & PB_GEMM_GELU, mul_gg = p.flags & PB_GEMM_MUL_GELU_GRAD;
-    float* panel = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+    float* panel = reinterpret_cast<float*>(smem) + wave * (32 * PW);
     float* C32 = reinterpret_cast<float*>(p.C) + coff;
     bf16_t* CT = reinterpret_cast<bf16_t*>(p.C) + coff;
-    const int colb = n0 + wn * 64 + lr * 4;                       // this lane's 4 output columns in the read-back phase
+    const int pcol = (lane % LPRW) * 4;
+    const int colb = n0 + wn * (16 * TN) + pcol;                   // this lane's 4 output columns in the read-back phase
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && colb < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + colb);   // N % 4 == 0 checked on the host
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int pass = 0; pass < TM / 2; ++pass) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) panel[(ii * 16 + lg * 4 + r) * 68 + j * 16 + lr] = acc[half * 2 + ii][j][r];
+                for (int r = 0; r < 4; ++r) panel[(ii * 16 + lg * 4 + r) * PW + j * 16 + lr] = acc[pass * 2 + ii][j][r];
         __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the wave's own panel writes are done
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int prow = it * 4 + lg;
-            const int row = m0 + wm * 64 + half * 32 + prow;
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int prow = it * RPI + lane / LPRW;
+            const int row = m0 + wm * (16 * TM) + pass * 32 + prow;
             if (row < p.M && colb < p.N) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(panel + prow * 68 + lr * 4) * p.alpha + bv;
+                f32x4 v = *reinterpret_cast<const f32x4*>(panel + prow * PW + pcol) * p.alpha + bv;
                 if (do_gelu) {
                     store4(p.aux_out + (long)row * p.ldaux + colb, v);
 #pragma unroll
@@ -213,7 +231,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (d->dtype != PB_BF16) return 1;
     const int nsplit = d->splitk > 1 ? d->splitk : 1;
-    if (d->K <= 0 || d->K % (BK * nsplit) != 0) return 1;
+    if (d->K <= 0 || d->K % BK != 0) return 1;
     if (d->N % 8 != 0) return 1;
     const bool a_kc = d->a_kcontig, b_kc = d->b_kcontig;
     auto al = [](const void* p, long ld, long s1, long s2) { return ((uintptr_t)p % 16 == 0) && ld % 8 == 0 && s1 % 8 == 0 && s2 % 8 == 0; };
@@ -225,7 +243,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % 4 != 0 || d->sC1 % 4 != 0 || d->sC2 % 4 != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 4 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 256)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue");
         return -2;
     }
@@ -233,7 +251,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     a.A = (const bf16_t*)d->A; a.B = (const bf16_t*)d->B;
     a.C = nsplit > 1 ? d->slabs : d->C;
     a.bias = d->bias; a.aux_in = (const bf16_t*)d->aux_in; a.aux_out = (bf16_t*)d->aux_out;
-    a.M = d->M; a.N = d->N; a.K = d->K; a.Kc = d->K / nsplit;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.Kc = ((d->K / BK + nsplit - 1) / nsplit) * BK;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = nsplit > 1 ? d->N : d->ldc; a.ldaux = d->ldaux;
     const int nb1 = d->nb1 > 0 ? d->nb1 : 1;
     a.nb2 = d->nb2 > 0 ? d->nb2 : 1;
@@ -241,13 +259,31 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2; a.sC1 = d->sC1; a.sC2 = d->sC2;
     a.sCz = (long)d->M * d->N;
     a.alpha = d->alpha; a.flags = d->flags;
-    a.tiles_m = (d->M + BM - 1) / BM; a.tiles_n = (d->N + BN - 1) / BN;
-    dim3 grid(a.tiles_m * a.tiles_n, nb1 * a.nb2, nsplit), block(NT2);
-    const size_t lds = 2 * STAGE_BYTES;
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm2_kernel<true, true>), grid, block, lds, stream, a);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm2_kernel<true, false>), grid, block, lds, stream, a);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm2_kernel<false, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((gemm2_kernel<false, false>), grid, block, lds, stream, a);
+    // tile choice: 128x128 (4 waves, 2 blocks/CU) by default; 256x256 (8 waves, 128x64 per wave, half the L2->LDS
+    // traffic per FLOP) when asked for (PB_GEMM_TILE256: the split-K wgrad GEMMs, whose output phase is negligible)
+    const bool big = (d->flags & PB_GEMM_TILE256) && d->M >= 256 && d->N >= 256;
+    const int BMs = big ? 256 : 128, BNs = big ? 256 : 128;
+    a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
+    dim3 grid(a.tiles_m * a.tiles_n, nb1 * a.nb2, nsplit);
+#define PB_G2_LAUNCH(AK, BK_, WM_, WN_, TM_, TN_)                                                                       \
+    do {                                                                                                                 \
+        auto kfn = gemm2_kernel<AK, BK_, WM_, WN_, TM_, TN_>;                                                              \
+        const size_t lds = 2 * (size_t)(16 * WM_ * TM_ + 16 * WN_ * TN_) * 128;                                            \
+        if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, stream, a);                                                \
+    } while (0)
+    if (big) {
+        if (a_kc && b_kc) PB_G2_LAUNCH(true, true, 2, 4, 8, 4);
+        else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 2, 4, 8, 4);
+        else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 2, 4, 8, 4);
+        else PB_G2_LAUNCH(false, false, 2, 4, 8, 4);
+    } else {
+        if (a_kc && b_kc) PB_G2_LAUNCH(true, true, 2, 2, 4, 4);
+        else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 2, 2, 4, 4);
+        else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 2, 2, 4, 4);
+        else PB_G2_LAUNCH(false, false, 2, 2, 4, 4);
+    }
+#undef PB_G2_LAUNCH
     if (hipGetLastError() != hipSuccess) { pb_set_error("pb_gemm2 launch failed"); return -1; }
     if (nsplit > 1) {
         if (d->ldc != d->N) { pb_set_error("pb_gemm: split-K needs a dense C (ldc == N)"); return -2; }

@@ -341,18 +341,19 @@ class Engine:
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dy, x, gname, M, N, T, ldy=None, ldx=None, dy_off=0, x_off=0, g_off=0):
         """G[gname] (M,N) = dy(T,M)^T @ x(T,N)  (TN GEMM into the f32 gradient buffer)."""
-        nsplit, slabs = 1, None
-        if self.code == PB_BF16:
-            tiles = ((M + 127) // 128) * ((N + 127) // 128)
-            while tiles * nsplit < 512 and nsplit < 32 and T % (128 * nsplit) == 0:
-                nsplit *= 2
+        nsplit, slabs, big = 1, None, False
+        if self.code == PB_BF16 and T % 64 == 0:
+            big = M >= 256 and N >= 256                       # 256x256 tiles: one block per CU, ~256 blocks in flight
+            tl = 256 if big else 128
+            tiles = ((M + tl - 1) // tl) * ((N + tl - 1) // tl)
+            nsplit = max(1, min(32, T // 64, round((256 if big else 512) / tiles)))
             if nsplit > 1:
                 need = nsplit * M * N
                 if self._slabs is None or self._slabs.numel() < need:
                     self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
                 slabs = self._slabs
         ops.gemm(dy, x, self.g[gname], M=M, N=N, K=T, dtype=self.code, a_kc=False, b_kc=False, lda=ldy or M, ldb=ldx or N, ldc=N,
-                 c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off, splitk=nsplit, slabs=slabs)
+                 c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off, splitk=nsplit, slabs=slabs, tile256=big)
 
     def _dgrad(self, dy, wname, out, T, N, K, accum, ldy=None, **kw):
         """out(T,N) (+)= dy(T,K) @ W(K,N)   (NN GEMM, W stored [K][N])."""

@@ -42,7 +42,7 @@ def _p(t):
 
 def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=None, bias=None, alpha=1.0,
          accum=False, c_f32=False, gelu_aux_out=None, gelu_grad_aux_in=None, ldaux=0, nb1=1, nb2=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, splitk=1, slabs=None, force_v1=False):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, splitk=1, slabs=None, force_v1=False, tile128=False, tile256=False, dbg=0):
     """C[m,n] (+)= epi(alpha * sum_k A(m,k) B(n,k)). a_off/b_off/c_off are element offsets into the tensors."""
     d = GemmDesc()
     esz = 2 if dtype == PB_BF16 else 4
@@ -55,7 +55,7 @@ def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, l
     d.dtype, d.a_kcontig, d.b_kcontig = dtype, int(a_kc), int(b_kc)
     d.flags = (GEMM_ACCUM if accum else 0) | (GEMM_C_F32 if c_f32 else 0) | \
               (GEMM_GELU if gelu_aux_out is not None else 0) | (GEMM_MUL_GELU_GRAD if gelu_grad_aux_in is not None else 0) | \
-              (16 if force_v1 else 0)
+              (16 if force_v1 else 0) | (32 if tile128 else 0) | (64 if tile256 else 0) | dbg
     d.splitk = splitk if (splitk > 1 and slabs is not None) else 1
     d.slabs = slabs.data_ptr() if (splitk > 1 and slabs is not None) else None
     d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, nb1, nb2

@@ -306,8 +306,10 @@ def test_flash_attention_fwd_bwd(ops, hd, causal, S, generic):
 
 @pytest.mark.parametrize('a_kc,b_kc', [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize('M,N,K,splitk', [(128, 128, 64, 1), (256, 384, 192, 1), (200, 136, 128, 1), (1000, 1280, 256, 1),
-                                          (768, 384, 2048, 4), (264, 72, 1024, 8), (3072, 768, 4096, 2)])
-def test_gemm2_fast_path_matches_generic(ops, a_kc, b_kc, M, N, K, splitk):
+                                          (768, 384, 2048, 4), (264, 72, 1024, 8), (3072, 768, 4096, 2), (1000, 520, 448, 3),
+                                          (512, 256, 128, 1)])
+@pytest.mark.parametrize('tile256', [False, True])
+def test_gemm2_fast_path_matches_generic(ops, a_kc, b_kc, M, N, K, splitk, tile256):
     """bf16 direct-to-LDS / transposed-read kernel (+ split-K slabs) vs fp64 and vs the generic kernel."""
     g = torch.Generator(device='cuda').manual_seed(M + N + K)
     A = torch.randn(M, K, device='cuda', generator=g)
@@ -319,16 +321,16 @@ def test_gemm2_fast_path_matches_generic(ops, a_kc, b_kc, M, N, K, splitk):
     C2 = torch.full((M, N), float('nan'), device='cuda')
     C1 = torch.full((M, N), float('nan'), device='cuda')
     slabs = torch.empty(splitk * M * N, device='cuda') if splitk > 1 else None
-    ops.gemm(Am, Bm, C2, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=True, splitk=splitk, slabs=slabs)
+    ops.gemm(Am, Bm, C2, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=True, splitk=splitk, slabs=slabs, tile256=tile256)
     ops.gemm(Am, Bm, C1, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=True, force_v1=True)
     assert _rel(C2, ref) < 1e-5 and _rel(C1, ref) < 1e-5
     # bf16 output + epilogues on the fast path
     bias = torch.randn(N, device='cuda', generator=g)
     Cb = torch.empty(M, N, device='cuda', dtype=dt); U = torch.empty_like(Cb)
-    ops.gemm(Am, Bm, Cb, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, bias=bias, alpha=0.125, gelu_aux_out=U)
+    ops.gemm(Am, Bm, Cb, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, bias=bias, alpha=0.125, gelu_aux_out=U, tile256=tile256)
     pre = 0.125 * ref + bias.double()
     assert _rel(U, pre) < 1e-2 and _rel(Cb, torch.nn.functional.gelu(pre)) < 1e-2
     acc0 = torch.randn(M, N, device='cuda', generator=g).to(dt)
     acc = acc0.clone()
-    ops.gemm(Am, Bm, acc, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, alpha=0.01, accum=True)
+    ops.gemm(Am, Bm, acc, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, alpha=0.01, accum=True, tile256=tile256)
     assert _rel(acc, acc0.double() + 0.01 * ref) < 1e-2

@@ -13,13 +13,14 @@ shapes = [('NT fc1', T, 3072, 768, True, True), ('NT fc2', T, 768, 3072, True, T
           ('TN wo', 768, 768, T, False, False)]
 
 
-def run(name, M, N, K, a_kc, b_kc, force_v1, splitk=1):
+def run(name, M, N, K, a_kc, b_kc, force_v1, splitk=1, tile128=False):
+    tile256 = not tile128
     A = torch.randn((M, K) if a_kc else (K, M), device=dev).to(torch.bfloat16)
     B = torch.randn((N, K) if b_kc else (K, N), device=dev).to(torch.bfloat16)
     c32 = not (a_kc)
     C = torch.empty(M, N, device=dev, dtype=torch.float32 if c32 else torch.bfloat16)
     slabs = torch.empty(splitk * M * N, device=dev) if splitk > 1 else None
-    f = lambda: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, force_v1=force_v1, splitk=splitk, slabs=slabs)
+    f = lambda: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, force_v1=force_v1, splitk=splitk, slabs=slabs, tile256=tile256)
     for _ in range(3):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,13 +34,15 @@ def run(name, M, N, K, a_kc, b_kc, force_v1, splitk=1):
 
 
 for name, M, N, K, a_kc, b_kc in shapes:
-    ms1, tf1 = run(name, M, N, K, a_kc, b_kc, True)
-    ms2, tf2 = run(name, M, N, K, a_kc, b_kc, False)
-    line = '%-8s M=%6d N=%5d K=%6d  v1 %7.3f ms %6.0f TF | v2 %7.3f ms %6.0f TF' % (name, M, N, K, ms1, tf1, ms2, tf2)
+    ms2, tf2 = run(name, M, N, K, a_kc, b_kc, False, tile128=True)
+    ms3, tf3 = run(name, M, N, K, a_kc, b_kc, False)
+    line = '%-8s M=%6d N=%5d K=%6d  t128 %7.3f ms %6.0f TF | t256 %7.3f ms %6.0f TF' % (name, M, N, K, ms2, tf2, ms3, tf3)
     if not a_kc:
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        for sk in (4, 8, 16):
-            if tiles * sk <= 2048:
-                ms3, tf3 = run(name, M, N, K, a_kc, b_kc, False, sk)
-                line += ' | sk%d %6.3f ms %5.0f TF' % (sk, ms3, tf3)
+        for big in (False, True):
+            tl = 256 if big else 128
+            tiles = ((M + tl - 1) // tl) * ((N + tl - 1) // tl)
+            for blocks in (256, 512, 1024):
+                sk = max(1, min(32, round(blocks / tiles)))
+                ms4, tf4 = run(name, M, N, K, a_kc, b_kc, False, sk, tile128=not big)
+                line += ' | t%d sk%d %5.3f ms %4.0f TF' % (tl, sk, ms4, tf4)
     print(line, flush=True)
