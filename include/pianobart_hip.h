@@ -59,12 +59,18 @@ int pb_embed_ln_fwd(const int16_t* ids16 /*(T,8)*/, const float* P, const int32_
                     const float* lin_bias, const float* pos /*(S+2,d)*/, const float* ln_w, const float* ln_b,
                     void* y /*(T,d) dtype*/, float* mean, float* rstd, int32_t T, int32_t S, int32_t d,
                     int32_t dtype, float eps, uint64_t seed, uint32_t site, float p_drop, void* stream);
-/* backward: dy -> dP (scatter-add, f32 atomics), dpos (S+2,d), dbias (d), dgamma/dbeta (d). */
+/* backward: dy -> dbias (d), dgamma/dbeta (d) and either (dz_out == NULL) dP / dpos by f32 atomic scatter-add
+ * (exact-f32 path), or (dz_out != NULL) dz (T,d) in dtype for the atomic-free route:
+ * dP = Onehot^T dz through pb_gemm (pb_onehot_build) and dpos through pb_batch_sum. */
 int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float* P, const int32_t* seg_off,
                     const float* lin_bias, const float* pos, const float* ln_w, const float* mean,
                     const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
-                    float* partials /*workspace, pb_ln_partials_floats()*/, int32_t T, int32_t S, int32_t d,
+                    float* partials /*workspace, pb_ln_partials_floats()*/, void* dz_out, int32_t T, int32_t S, int32_t d,
                     int32_t dtype, uint64_t seed, uint32_t site, float p_drop, void* stream);
+/* onehot (T,V) bf16 with ones at columns seg_off[i] + ids16[t][i] */
+int pb_onehot_build(const int16_t* ids16, const int32_t* seg_off /*host 8*/, void* out, int64_t T, int32_t V, void* stream);
+/* out[i] += sum_b x[b*Sd + i], i < Sd */
+int pb_batch_sum(const void* x, float* out, int32_t B, int64_t Sd, int32_t dtype, void* stream);
 
 /* ---- K5/K6 tail: y = LayerNorm(res + dropout(a)) ------------------------------------------------
  * Replaces dropout + residual + LayerNorm of modeling_bart.py:292-294,300-302,362-364,377-379,386-388. */

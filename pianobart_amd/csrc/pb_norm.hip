@@ -215,11 +215,14 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_fwd_kernel(const int16_t*
     }
 }
 
+// dz_out == NULL: scatter-add dz into dP / dpos with f32 atomics (exact-f32 path).
+// dz_out != NULL: write dz (T,d) instead; dP and dpos are then produced without atomics by a one-hot MFMA GEMM
+// (dP = Onehot^T dz) and pb_batch_sum (bf16 throughput path).
 template <typename T, int NIT>
 __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(const T* __restrict__ dy, const int16_t* __restrict__ ids16,
         const float* __restrict__ P, const SegOff so, const float* __restrict__ lin_bias, const float* __restrict__ pos,
         const float* __restrict__ w, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-        float* __restrict__ dP, float* __restrict__ dpos, float* __restrict__ partials,
+        float* __restrict__ dP, float* __restrict__ dpos, float* __restrict__ partials, T* __restrict__ dz_out,
         int rows, int S, int d, uint64_t seed, uint32_t site, float p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds = reinterpret_cast<float*>(smem);
@@ -250,6 +253,18 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(const T* __res
             }
         }
         s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d; nz = wave_sum(nz);
+        if (dz_out) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c4 = lane + 64 * it;
+                if (c4 < d4) {
+                    const f32x4 dz = (g[it] - s1 - z[it] * s2) * rstd;
+                    acc[2][it] += dz;
+                    store4(dz_out + row * d + 4 * c4, dz);
+                }
+            }
+            continue;
+        }
         if (nz == 0.f) continue;        // rows that received no gradient (PAD tail) add exact zeros: skip the atomics
         const uint4 raw = *reinterpret_cast<const uint4*>(ids16 + row * 8);
         int id[8];
@@ -399,7 +414,7 @@ extern "C" int pb_embed_ln_fwd(const int16_t* ids16, const float* P, const int32
 extern "C" int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float* P, const int32_t* seg_off,
                                const float* lin_bias, const float* pos, const float* ln_w, const float* mean,
                                const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
-                               float* partials, int32_t T, int32_t S, int32_t d, int32_t dtype, uint64_t seed,
+                               float* partials, void* dz_out, int32_t T, int32_t S, int32_t d, int32_t dtype, uint64_t seed,
                                uint32_t site, float p_drop, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_ln_dims("pb_embed_ln_bwd", T, d)) return -2;
@@ -412,10 +427,10 @@ extern "C" int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float
     PB_LN_DISPATCH(nit_for(d),
         if (dtype == PB_BF16)
             hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream, (const bf16_t*)dy,
-                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, T, S, d, seed, site, p_drop);
+                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, (bf16_t*)dz_out, T, S, d, seed, site, p_drop);
         else
             hipLaunchKernelGGL((embed_ln_bwd_kernel<float, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream, (const float*)dy,
-                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, T, S, d, seed, site, p_drop));
+                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, (float*)dz_out, T, S, d, seed, site, p_drop));
     PB_LAUNCH_CHECK();
     return launch_finalize(partials, grid, 3, d, dgamma, dbeta, dbias, nullptr, stream);
 }
@@ -440,6 +455,34 @@ extern "C" int pb_colsum(const void* dy, int64_t ld, float* out, float* partials
 
 extern "C" int pb_ids_to_i16(const int64_t* ids, int16_t* out, int64_t n, void* stream_);
 namespace {
+// onehot (T, V) bf16: row t has ones at the 8 columns off_i + id_i[t]. One wave per row, 16-byte stores.
+__global__ __launch_bounds__(256) void onehot_kernel(const int16_t* __restrict__ ids16, const SegOff so, bf16_t* __restrict__ out, long T, int V) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long row = (long)blockIdx.x * 4 + wave; row < T; row += (long)gridDim.x * 4) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(ids16 + row * 8);
+        int col[8];
+        col[0] = so.off[0] + (int)(raw.x & 0xffff); col[1] = so.off[1] + (int)(raw.x >> 16);
+        col[2] = so.off[2] + (int)(raw.y & 0xffff); col[3] = so.off[3] + (int)(raw.y >> 16);
+        col[4] = so.off[4] + (int)(raw.z & 0xffff); col[5] = so.off[5] + (int)(raw.z >> 16);
+        col[6] = so.off[6] + (int)(raw.w & 0xffff); col[7] = so.off[7] + (int)(raw.w >> 16);
+        for (int c8 = lane; c8 * 8 < V; c8 += 64) {
+            bf16x8 v = {};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((col[i] >> 3) == c8) v[col[i] & 7] = (bf16_t)1.0f;
+            *reinterpret_cast<bf16x8*>(out + row * V + c8 * 8) = v;
+        }
+    }
+}
+// out[s][c] += sum_b x[(b*S + s)*d + c]   (position-table gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void batch_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int B, long Sd) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < Sd; i += (long)gridDim.x * 1024) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) s += load4(x + b * Sd + i);
+        store4(out + i, load4(out + i) + s);
+    }
+}
 __global__ void ids_to_i16_kernel(const int64_t* __restrict__ ids, int16_t* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (int16_t)ids[i];
 }
@@ -465,6 +508,26 @@ extern "C" int pb_shift_right(const int16_t* ids, const int16_t* sos_row, int16_
     if (n <= 0) return 0;
     const int grid = (int)min((long)2048, (n + 255) / 256);
     hipLaunchKernelGGL(shift_right_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, ids, sos_row, out, B, S);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_onehot_build(const int16_t* ids16, const int32_t* seg_off, void* out, int64_t T, int32_t V, void* stream_) {
+    PB_REQUIRE(V % 8 == 0, "pb_onehot_build: V must be a multiple of 8");
+    if (T <= 0) return 0;
+    SegOff so;
+    for (int i = 0; i < 8; ++i) so.off[i] = seg_off[i];
+    const int grid = (int)min((long)4096, (long)((T + 3) / 4));
+    hipLaunchKernelGGL(onehot_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, ids16, so, (bf16_t*)out, (long)T, V);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pb_batch_sum(const void* x, float* out, int32_t B, int64_t Sd, int32_t dtype, void* stream_) {
+    PB_REQUIRE(Sd % 4 == 0, "pb_batch_sum: S*d must be a multiple of 4");
+    if (B <= 0 || Sd <= 0) return 0;
+    const int grid = (int)min((long)2048, (long)((Sd / 4 + 255) / 256));
+    if (dtype == PB_BF16) hipLaunchKernelGGL((batch_sum_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)x, out, B, (long)Sd);
+    else hipLaunchKernelGGL((batch_sum_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const float*)x, out, B, (long)Sd);
     PB_LAUNCH_CHECK();
     return 0;
 }

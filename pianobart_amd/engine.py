@@ -222,7 +222,8 @@ class Engine:
                   logits=f(T, ops.VOCAB) if self.mlm is not None else None,
                   scores=None if self.use_flash else f(B, H, S, S), dS=None if self.use_flash else e(B, H, S, S), delta=f(B, H, S),
                   gy=[e(T, d), e(T, d)], gA=e(T, d), gB=e(T, d), gC=e(T, d), dqkv=e(T, 3 * d), dq=e(T, d), dkv=e(T, 2 * d),
-                  du=e(T, max(self.fe, self.fd)), genc=e(T, d), dlogits=e(T, ops.VOCAB) if self.mlm is not None else None)
+                  du=e(T, max(self.fe, self.fd)), genc=e(T, d), dlogits=e(T, ops.VOCAB) if self.mlm is not None else None,
+                  dz=e(2 * T, d) if self.code == PB_BF16 else None, onehot=e(2 * T, ops.VOCAB) if self.code == PB_BF16 else None)
         self._ws_cache = {key: ws}          # keep one shape resident
         return ws
 
@@ -405,6 +406,7 @@ class Engine:
         emask, dmask = sv['emask'], sv['dmask']
         gy, galt = ws['gy']
         genc = ws['genc']
+        onehot_route = self.code == PB_BF16 and (B * S) % 64 == 0
         if gy_dec is not None:
             cur = gy_dec
             for l in reversed(range(self.ND)):
@@ -433,7 +435,10 @@ class Engine:
                 cur = g2
                 self._ready(pf + 'wqkv', pf + 'w2')
             ops.embed_ln_bwd(cur, sv['dec16'], self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], ws['md'], ws['rd'], self.dptab,
-                             g['dec.pos'], g['lin.b'], g['dec.lne.w'], g['dec.lne.b'], self.partials, S, seed, self._site('dec_emb'), p)
+                             g['dec.pos'], g['lin.b'], g['dec.lne.w'], g['dec.lne.b'], self.partials, S, seed, self._site('dec_emb'), p,
+                             dz_out=ws['dz'][T:] if onehot_route else None)
+            if onehot_route:
+                ops.batch_sum(ws['dz'][T:], g['dec.pos'][2:2 + S], B, S * d)
             cur = genc
             if gy_enc_extra is not None:
                 cur = genc.add_(gy_enc_extra)
@@ -453,7 +458,20 @@ class Engine:
             cur = g2
             self._ready(pf + 'wqkv', pf + 'w2')
         ops.embed_ln_bwd(cur, sv['enc16'], self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], ws['me'], ws['re'], self.dptab,
-                         g['enc.pos'], g['lin.b'], g['enc.lne.w'], g['enc.lne.b'], self.partials, S, seed, self._site('enc_emb'), p)
+                         g['enc.pos'], g['lin.b'], g['enc.lne.w'], g['enc.lne.b'], self.partials, S, seed, self._site('enc_emb'), p,
+                         dz_out=ws['dz'][:T] if onehot_route else None)
+        if onehot_route:
+            # dP = Onehot^T dz over the encoder AND decoder tokens in one split-K MFMA GEMM (K = 2T): no atomics
+            ops.batch_sum(ws['dz'][:T], g['enc.pos'][2:2 + S], B, S * d)
+            ops.onehot_build(sv['enc16'], ws['onehot'][:T])
+            K2 = 2 * T if gy_dec is not None else T
+            if gy_dec is not None:
+                ops.onehot_build(sv['dec16'], ws['onehot'][T:])
+            need = 16 * ops.VOCAB * d
+            if self._slabs is None or self._slabs.numel() < need:
+                self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
+            ops.gemm(ws['onehot'], ws['dz'], self.dptab, M=ops.VOCAB, N=d, K=K2, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.VOCAB, ldb=d,
+                     ldc=d, c_f32=True, splitk=16, slabs=self._slabs, tile256=True)
         # projected-table gradient -> embedding tables and the shared merge Linear (exact f32)
         E, W = self.wf['emb'], self.wf['lin.w']
         for i in range(8):

@@ -94,11 +94,20 @@ def embed_ln_fwd(ids16, P, lin_bias, pos, ln_w, ln_b, y, mean, rstd, S, eps, see
              _p(rstd), T, S, d, dtype_code(y.dtype), eps, seed, site, p_drop, _stream())
 
 
-def embed_ln_bwd(dy, ids16, P, lin_bias, pos, ln_w, mean, rstd, dP, dpos, dbias, dgamma, dbeta, partials, S, seed, site, p_drop):
+def embed_ln_bwd(dy, ids16, P, lin_bias, pos, ln_w, mean, rstd, dP, dpos, dbias, dgamma, dbeta, partials, S, seed, site, p_drop,
+                 dz_out=None):
     T, d = dy.shape
     LIB.call('pb_embed_ln_bwd', _p(dy), _p(ids16), _p(P), _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(mean), _p(rstd),
-             _p(dP), _p(dpos), _p(dbias), _p(dgamma), _p(dbeta), _p(partials), T, S, d, dtype_code(dy.dtype), seed, site,
+             _p(dP), _p(dpos), _p(dbias), _p(dgamma), _p(dbeta), _p(partials), _p(dz_out), T, S, d, dtype_code(dy.dtype), seed, site,
              p_drop, _stream())
+
+
+def onehot_build(ids16, out):
+    LIB.call('pb_onehot_build', _p(ids16), _SEG9, _p(out), ids16.numel() // 8, VOCAB, _stream())
+
+
+def batch_sum(x, out, B, Sd):
+    LIB.call('pb_batch_sum', _p(x), _p(out), B, Sd, dtype_code(x.dtype), _stream())
 
 
 def add_ln_fwd(res, a, ln_w, ln_b, y, mean, rstd, eps, seed, site, p_drop):

@@ -334,3 +334,26 @@ def test_gemm2_fast_path_matches_generic(ops, a_kc, b_kc, M, N, K, splitk, tile2
     acc = acc0.clone()
     ops.gemm(Am, Bm, acc, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, alpha=0.01, accum=True, tile256=tile256)
     assert _rel(acc, acc0.double() + 0.01 * ref) < 1e-2
+
+
+def test_onehot_route_matches_atomic_scatter(ops):
+    """dP via Onehot^T dz (MFMA, split-K) and dpos via batch_sum == the atomic scatter-add path."""
+    g = torch.Generator(device='cuda').manual_seed(12)
+    B, S, d = 4, 32, 128
+    T = B * S
+    ids = torch.stack([torch.randint(0, n, (T,), device='cuda', generator=g) for n in ops.SEG_SIZES], dim=1)
+    ids16 = ops.ids_to_i16(ids)
+    oh = torch.empty(T, ops.VOCAB, device='cuda', dtype=torch.bfloat16)
+    ops.onehot_build(ids16, oh)
+    ref = torch.zeros(T, ops.VOCAB, device='cuda')
+    ref.scatter_(1, ids + torch.tensor(ops.SEG_OFF[:8], device='cuda'), 1.0)
+    assert torch.equal(oh.float(), ref)
+    dz = torch.randn(T, d, device='cuda', generator=g).to(torch.bfloat16)
+    dP = torch.empty(ops.VOCAB, d, device='cuda')
+    slabs = torch.empty(2 * ops.VOCAB * d, device='cuda')
+    ops.gemm(oh, dz, dP, M=ops.VOCAB, N=d, K=T, dtype=ops.PB_BF16, a_kc=False, b_kc=False, lda=ops.VOCAB, ldb=d, ldc=d, c_f32=True,
+             splitk=2, slabs=slabs, tile256=True)
+    assert _rel(dP, ref.double().t() @ dz.double()) < 1e-5
+    out = torch.ones(S, d, device='cuda')
+    ops.batch_sum(dz, out, B, S * d)
+    assert _rel(out, 1 + dz.double().reshape(B, S, d).sum(0)) < 1e-5
