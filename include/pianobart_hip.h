@@ -147,6 +147,13 @@ int pb_fill_f32(float* dst, float value, int64_t n, void* stream);
 /* ---- device-side corruption for the pre-train step (distributional counterpart of gen_mask's
  * TokenMask n=0 branch, pretrain.py:276-295) and decoder shift-right (pretrain.py:132-139) ---------*/
 int pb_shift_right(const int16_t* ids, const int16_t* sos_row /*device 8*/, int16_t* out, int32_t B, int32_t S, void* stream);
+/* Replaces Pretrainer.gen_mask (pretrain.py:211-546): one workgroup corrupts one (S,8) sequence in LDS.
+ * choice (B) int32 device, 1..5 (other values / NULL: drawn uniformly in-kernel, reported in choice_out if given);
+ * out (B,S,8) int16, loss_mask (B,S,8) f32 (per-position mask repeated over the 8 columns, pretrain.py:141-142).
+ * pad_row / mask_row / n_tokens: HOST arrays of 8. Same distributions as the reference, Philox instead of MT19937. */
+int pb_corrupt(const int16_t* ids, int16_t* out, float* loss_mask, const int32_t* choice, int32_t* choice_out, int32_t B,
+               int32_t S, float mask_percent, uint64_t seed, const int16_t* pad_row, const int16_t* mask_row,
+               const int32_t* n_tokens, void* stream);
 
 #ifdef __cplusplus
 }

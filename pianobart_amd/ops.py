@@ -194,3 +194,12 @@ def flash_bwd(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, 
     LIB.call('pb_flash_bwd', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), _p(key_mask), pp(dqt, dqo),
              pp(dkt, dko), pp(dvt, dvo), _p(delta), B, H, Sq, Sk, hd, qb, qs, kb, ks, vb, vs, ob, os_, dqb, dqs, dkb, dks, dvb, dvs,
              scale, int(causal) | (2 if force_generic else 0), _stream())
+
+
+def corrupt(ids16, out16, loss_mask, choice, choice_out, mask_percent, seed, pad_row, mask_row, n_tokens):
+    """ids16/out16 (B,S,8) int16 device; loss_mask (B,S,8) f32; choice/choice_out (B,) int32 device or None."""
+    B, S = ids16.shape[:2]
+    pr = (ctypes.c_int16 * 8)(*[int(x) for x in pad_row])
+    mr = (ctypes.c_int16 * 8)(*[int(x) for x in mask_row])
+    nt = (ctypes.c_int32 * 8)(*[int(x) for x in n_tokens])
+    LIB.call('pb_corrupt', _p(ids16), _p(out16), _p(loss_mask), _p(choice), _p(choice_out), B, S, mask_percent, seed, pr, mr, nt, _stream())
