@@ -1,0 +1,276 @@
+"""Pre-training harness on MI355X: the counterpart of the reference's `pretrain.py` (Pretrainer,
+get_args_pretrain, load_data_pretrain) and `main.pretrain()` (main.py:17-100).
+
+Same CLI flags and defaults (pretrain.py:18-48), same BartConfig field mapping (main.py:39-47), same
+per-epoch train -> valid flow, weighted avg-acc best tracking (main.py:72-82), checkpoint dict keys and
+file names (pretrain.py:96-110), log line formats (pretrain.py:199-204, main.py:84-92). What differs is
+where the work runs: the reference's per-sample Python `gen_mask` + 8 logits D2H copies + >= 17 host syncs
+per step become: one corruption kernel per batch, the fused HIP step (Engine.loss_and_grads +
+optimizer_step), and ONE device->host copy of 24 floats per step for the log lines.
+
+Multi-GPU: launch one process per GPU (torch.distributed.run); `--cuda_devices` keeps its meaning of
+"which device(s)" for a single process, but more than one id is rejected with a pointer to torchrun,
+because nn.DataParallel (pretrain.py:63-65) is exactly what this engine replaces.
+"""
+import argparse
+import os
+import random
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import PBError
+from .model import BartConfig, PianoBart, PianoBartLM
+
+
+def get_args_pretrain(argv=None):
+    """pretrain.py:18-48, flag for flag."""
+    parser = argparse.ArgumentParser(description='')
+    parser.add_argument('--dict_file', type=str, default='./Data/Octuple.pkl')
+    parser.add_argument('--name', type=str, default='pianobart')
+    parser.add_argument("--datasets", type=str, nargs='+', default=['asap', 'EMOPIA', 'Pianist8', 'POP1K7', 'POP909'])
+    parser.add_argument('--num_workers', type=int, default=5)
+    parser.add_argument('--batch_size', type=int, default=16)
+    parser.add_argument('--mask_percent', type=float, default=0.15,
+                        help="Up to `valid_seq_len * target_max_percent` tokens will be masked out for prediction")
+    parser.add_argument('--max_seq_len', type=int, default=1024, help='all sequences are padded to `max_seq_len`')
+    parser.add_argument('--hs', type=int, default=1024)
+    parser.add_argument('--layers', type=int, default=8)
+    parser.add_argument('--ffn_dims', type=int, default=2048)
+    parser.add_argument('--heads', type=int, default=8)
+    parser.add_argument('--epochs', type=int, default=500, help='number of training epochs')
+    parser.add_argument('--lr', type=float, default=2e-5, help='initial learning rate')
+    parser.add_argument("--cpu", action="store_true")
+    parser.add_argument("--cuda_devices", type=int, nargs='+', default=[0], help="HIP device ids (one per process)")
+    # build-only additions (absent from the reference)
+    parser.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'fp32'])
+    parser.add_argument('--data_root', type=str, default='Data/output_pretrain')
+    parser.add_argument('--quiet', action='store_true', help='do not print the two per-step Loss/Acc lines')
+    return parser.parse_args(argv)
+
+
+def load_data_pretrain(datasets, mode, root='Data/output_pretrain'):
+    """pretrain.py:548-576: <root>/<ds>/<ds>_{train,test,valid}_split.npy -> vstack, shuffle, 85/15 split."""
+    if mode != "pretrain":
+        return None
+    to_concat = []
+    for dataset in datasets:
+        parts = [np.load(os.path.join(root, dataset, dataset + '_%s_split.npy' % s), allow_pickle=True) for s in ('train', 'test', 'valid')]
+        data = np.concatenate(parts, axis=0)
+        print(f'   {dataset}: {data.shape}')
+        to_concat.append(data)
+    training_data = np.vstack(to_concat)
+    print('   > all training data:', training_data.shape)
+    index = np.arange(len(training_data))
+    np.random.shuffle(index)
+    training_data = training_data[index]
+    split = int(len(training_data) * 0.85)
+    return training_data[:split], training_data[split:]
+
+
+class MidiDataset(torch.utils.data.Dataset):
+    """dataset.py:4-16."""
+
+    def __init__(self, X):
+        self.data = X
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, index):
+        return torch.tensor(self.data[index])
+
+
+class Pretrainer:
+    """pretrain.py:51-546. Same constructor arguments and public methods."""
+
+    def __init__(self, pianobart: PianoBart, train_dataloader, valid_dataloader, lr, batch, max_seq_len, mask_percent, cpu,
+                 cuda_devices=None):
+        if cpu or not torch.cuda.is_available():
+            raise PBError('pianobart_amd has no CPU execution path: run on an MI355X (got cpu=%s, cuda available=%s)'
+                          % (cpu, torch.cuda.is_available()))
+        if cuda_devices is not None and len(cuda_devices) > 1:
+            raise PBError('nn.DataParallel is replaced by one process per GPU: launch with '
+                          '`python -m torch.distributed.run --nproc-per-node N ...` (see INTEGRATION.md)')
+        dev_id = cuda_devices[0] if cuda_devices else 0
+        if 'LOCAL_RANK' in os.environ:
+            dev_id = int(os.environ['LOCAL_RANK'])
+        self.device = torch.device('cuda', dev_id)
+        torch.cuda.set_device(self.device)
+        self.pianobart = pianobart.to(self.device)          # saved alone in the checkpoint (pretrain.py:100)
+        self.model = PianoBartLM(pianobart).to(self.device)
+        self.total_params = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
+        print('# total parameters:', self.total_params)
+        print("Use GPU", self.device)
+        self.engine = self.model._get_engine()
+        self.engine.bind(self.device)
+        self.train_data = train_dataloader
+        self.valid_data = valid_dataloader
+        self.lr = lr
+        self.batch = batch
+        self.max_seq_len = max_seq_len
+        self.mask_percent = mask_percent
+        self.quiet = False
+        self.world = int(os.environ.get('WORLD_SIZE', 1))
+        self.reducer = None
+        if self.world > 1:
+            import torch.distributed as dist
+            from .parallel import GradReducer
+            if not dist.is_initialized():
+                dist.init_process_group('nccl', device_id=self.device)
+            self.reducer = GradReducer(self.engine, self.world)
+        self._w = np.array([len(pianobart.e2w[k]) for k in pianobart.e2w], dtype=np.float64)   # e2w dict order (pretrain.py:185-189)
+        self._step_seed = 0x9E3779B97F4A7C15
+
+    # ---- reference API ------------------------------------------------------------------------------
+    def train(self):
+        self.model.train()
+        return self.iteration(self.train_data, self.max_seq_len)
+
+    def valid(self):
+        self.model.eval()
+        return self.iteration(self.valid_data, self.max_seq_len, train=False)
+
+    def save_checkpoint(self, epoch, best_acc, valid_acc, valid_loss, train_loss, is_best, filename):
+        """pretrain.py:96-110: same dict keys; 'state_dict' holds PianoBart only; optimizer = flat HF-AdamW state."""
+        eng = self.engine
+        opt = {'step': eng.step_count, 'lr': self.lr, 'betas': (0.9, 0.999), 'eps': 1e-6, 'weight_decay': 0.01,
+               'exp_avg': None if eng.opt_m is None else eng.opt_m.detach().cpu(),
+               'exp_avg_sq': None if eng.opt_v is None else eng.opt_v.detach().cpu()}
+        state = {'epoch': epoch + 1, 'state_dict': {k: v.detach().cpu() for k, v in self.pianobart.state_dict().items()},
+                 'best_acc': best_acc, 'valid_acc': valid_acc, 'valid_loss': valid_loss, 'train_loss': train_loss, 'optimizer': opt}
+        torch.save(state, filename)
+        best_mdl = filename.split('.')[0] + '_best.ckpt'
+        if is_best:
+            shutil.copyfile(filename, best_mdl)
+
+    def gen_mask(self, input_ids, choice=None):
+        """pretrain.py:211-546 for ONE sequence (S,8): returns (masked (S,8) long, mask (S,) long) on the input's device."""
+        ids = input_ids.to(self.device).long().reshape(1, -1, 8)
+        enc16, lm, _ = self._corrupt(ops.ids_to_i16(ids), None if choice is None else [choice])
+        return enc16[0].long().to(input_ids.device), lm[0, :, 0].long().to(input_ids.device)
+
+    # ---- the step ---------------------------------------------------------------------------------------
+    def _corrupt(self, ids16, choices=None):
+        B, S = ids16.shape[:2]
+        pb = self.pianobart
+        if choices is None:
+            choices = [random.randint(1, 5) for _ in range(B)]        # the reference's dispatcher draw (pretrain.py:520)
+        ch = torch.tensor(choices, dtype=torch.int32, device=self.device)
+        out = torch.empty_like(ids16)
+        lm = torch.empty(B, S, 8, dtype=torch.float32, device=self.device)
+        self._step_seed = (self._step_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        ops.corrupt(ids16, out, lm, ch, None, float(self.mask_percent), self._step_seed, pb.pad_word_np, pb.mask_word_np, pb.n_tokens)
+        return out, lm, ch
+
+    def prepare_batch(self, ori_seq_batch):
+        """pretrain.py:125-153 on the device: corrupted encoder ids, shift-right decoder ids, loss mask, attention masks."""
+        ori = ori_seq_batch.to(self.device, non_blocking=True)
+        tgt16 = ops.ids_to_i16(ori.long() if ori.dtype != torch.int64 else ori)
+        B, S = tgt16.shape[:2]
+        enc16, loss_mask, _ = self._corrupt(tgt16)
+        dec16 = torch.empty_like(tgt16)
+        ops.shift_right(tgt16, self.engine.sos16, dec16, B, S)
+        pad = int(self.pianobart.bar_pad_word)
+        emask = (enc16[:, :, 0] != pad).float()
+        dmask = (dec16[:, :, 0] != pad).float()
+        return enc16, dec16, tgt16, loss_mask, emask, dmask
+
+    def iteration(self, training_data, max_seq_len, train=True):
+        eng = self.engine
+        total_acc, total_losses, nb = np.zeros(8), 0.0, 0
+        for ori_seq_batch in training_data:
+            enc16, dec16, tgt16, loss_mask, emask, dmask = self.prepare_batch(ori_seq_batch)
+            sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=train,
+                                      count_hook=self.reducer.reduce_counts if self.reducer else None)
+            if train:
+                if self.reducer:
+                    self.reducer.all_reduce_grads()
+                eng.optimizer_step(lr=self.lr)
+            if self.reducer:
+                self.reducer.reduce_sums(sums)
+            s = sums.double().cpu().numpy()                          # the one host sync of the step
+            losses = s[0:8] / s[8:16]
+            accs = s[16:24] / s[8:16]
+            total_loss = float((losses * self._w).sum() / self._w.sum())
+            if not self.quiet:
+                sys.stdout.write('Loss: {:06f} | loss: {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}\n'.format(total_loss, *losses))
+                sys.stdout.write('Acc: {:06f} | acc: {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}\n'.format(np.average(accs), *accs))
+            total_acc += accs
+            total_losses += total_loss
+            nb += 1
+        n = max(1, len(training_data))
+        return round(total_losses / n, 3), [round(float(x) / n, 3) for x in total_acc]
+
+
+def pretrain(argv=None):
+    """main.py:17-100."""
+    import pickle
+    from torch.utils.data import DataLoader
+    args = get_args_pretrain(argv)
+    print("Loading Dictionary")
+    if args.dict_file.endswith('.json'):
+        import json
+        e2w = json.load(open(args.dict_file))['e2w']
+        w2e = {k: {v: w for w, v in d.items()} for k, d in e2w.items()}
+    else:
+        with open(args.dict_file, 'rb') as f:
+            e2w, w2e = pickle.load(f)
+    print("\nLoading Dataset", args.datasets)
+    X_train, X_val = load_data_pretrain(datasets=args.datasets, mode="pretrain", root=args.data_root)
+    train_loader = DataLoader(MidiDataset(X=X_train), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=True)
+    print("   len of train_loader", len(train_loader))
+    valid_loader = DataLoader(MidiDataset(X=X_val), batch_size=args.batch_size, num_workers=args.num_workers)
+    print("   len of valid_loader", len(valid_loader))
+    print("\nBuilding BART model")
+    configuration = BartConfig(max_position_embeddings=args.max_seq_len, d_model=args.hs, encoder_layers=args.layers,
+                               encoder_ffn_dim=args.ffn_dims, encoder_attention_heads=args.heads, decoder_layers=args.layers,
+                               decoder_ffn_dim=args.ffn_dims, decoder_attention_heads=args.heads)
+    pianobart = PianoBart(bartConfig=configuration, e2w=e2w, w2e=w2e, precision=args.precision)
+    print("\nCreating BART Trainer")
+    trainer = Pretrainer(pianobart, train_loader, valid_loader, args.lr, args.batch_size, args.max_seq_len, args.mask_percent,
+                         args.cpu, args.cuda_devices)
+    trainer.quiet = args.quiet
+    print("\nTraining Start")
+    save_dir = 'result/pretrain/' + args.name
+    os.makedirs(save_dir, exist_ok=True)
+    filename = os.path.join(save_dir, 'model.ckpt')
+    print("   save model at {}".format(filename))
+    best_acc, best_epoch, bad_cnt = 0, 0, 0
+    start_t = time.time()
+    rank0 = int(os.environ.get('RANK', 0)) == 0
+    for epoch in range(args.epochs):
+        if bad_cnt >= 30:
+            print('valid acc not improving for 30 epochs')
+            break
+        train_loss, train_acc = trainer.train()
+        valid_loss, valid_acc = trainer.valid()
+        weighted_score = [x * y for (x, y) in zip(valid_acc, pianobart.n_tokens)]
+        avg_acc = sum(weighted_score) / sum(pianobart.n_tokens)
+        is_best = avg_acc > best_acc
+        best_acc = max(avg_acc, best_acc)
+        if is_best:
+            bad_cnt, best_epoch = 0, epoch
+        else:
+            bad_cnt += 1
+        print('epoch: {}/{} | Train Loss: {} | Train acc: {} | Valid Loss: {} | Valid acc: {}'.format(
+            epoch + 1, args.epochs, train_loss, train_acc, valid_loss, valid_acc))
+        if rank0:
+            trainer.save_checkpoint(epoch, best_acc, valid_acc, valid_loss, train_loss, is_best, filename)
+            with open(os.path.join(save_dir, 'log'), 'a') as outfile:
+                outfile.write('Epoch {}: train_loss={}, train_acc={}, valid_loss={}, valid_acc={}\n'.format(
+                    epoch + 1, train_loss, train_acc, valid_loss, valid_acc))
+    end_t = time.time()
+    print(f'Time cost in pretrain of PianoBart is {end_t - start_t}, start_t = {start_t}, end_t = {end_t}')
+    if rank0:
+        with open(os.path.join(save_dir, 'log'), 'a') as outfile:
+            outfile.write(f'Time cost in pretrain of PianoBart is {end_t - start_t}, start_t = {start_t}, end_t = {end_t}')
+    return trainer
+
+
+if __name__ == '__main__':
+    pretrain()

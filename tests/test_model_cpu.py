@@ -75,3 +75,12 @@ def test_engine_flat_layout_covers_every_live_parameter():
     spans = sorted((eng._elem_off(s, r), eng._elem_off(s, r) + p.numel()) for p, s, r in pm)
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))      # no overlap
     assert spans[-1][1] <= eng.n_total
+
+
+def test_pretrain_cli_defaults_match_reference():
+    """pretrain.py:22-44 defaults."""
+    from pianobart_amd.pretrain import get_args_pretrain
+    a = get_args_pretrain([])
+    assert (a.dict_file, a.name, a.num_workers, a.batch_size, a.mask_percent, a.max_seq_len) == ('./Data/Octuple.pkl', 'pianobart', 5, 16, 0.15, 1024)
+    assert (a.hs, a.layers, a.ffn_dims, a.heads, a.epochs, a.lr, a.cpu) == (1024, 8, 2048, 8, 500, 2e-5, False)
+    assert a.datasets == ['asap', 'EMOPIA', 'Pianist8', 'POP1K7', 'POP909']

@@ -1,0 +1,86 @@
+"""GPU: the pre-train harness (counterpart of pretrain.py / main.pretrain) end to end on cfg-1 shape."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import ROOT, load_vocab, synth_octuple_batch
+
+pytestmark = pytest.mark.gpu
+E2W, W2E = load_vocab()
+VOCAB_JSON = os.path.join(ROOT, 'pianobart_amd', 'data', 'octuple_vocab.json')
+
+
+def _write_dataset(root, n=12, S=128):
+    os.makedirs(os.path.join(root, 'syn'), exist_ok=True)
+    seqs = synth_octuple_batch(n, S, seed=77)[5].numpy().astype(np.int64)
+    for name, part in (('train', seqs[:8]), ('test', seqs[8:10]), ('valid', seqs[10:])):
+        np.save(os.path.join(root, 'syn', 'syn_%s_split.npy' % name), part)
+
+
+def test_main_pretrain_cfg1_end_to_end(tmp_path, capsys):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from oracle import pianobart_oracle as O
+    from pianobart_amd.pretrain import pretrain
+    data_root = str(tmp_path / 'Data' / 'output_pretrain')
+    _write_dataset(data_root)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        np.random.seed(0); torch.manual_seed(0)
+        tr = pretrain(['--dict_file', VOCAB_JSON, '--name', 't', '--datasets', 'syn', '--num_workers', '0', '--batch_size', '2',
+                       '--max_seq_len', '128', '--hs', '128', '--layers', '2', '--ffn_dims', '512', '--heads', '4', '--epochs', '3',
+                       '--lr', '1e-3', '--cuda_devices', '0', '--precision', 'fp32', '--data_root', data_root])
+        out = capsys.readouterr().out
+        log = open('result/pretrain/t/log').read().splitlines()
+        ck = torch.load('result/pretrain/t/model.ckpt', weights_only=False)
+        best_exists = os.path.exists('result/pretrain/t/model_best.ckpt')
+    finally:
+        os.chdir(cwd)
+    # log + stdout formats of main.py:84-92 and pretrain.py:199-204
+    assert len(log) == 4 and all(re.match(r'Epoch \d+: train_loss=[\d.]+, train_acc=\[.*\], valid_loss=[\d.]+, valid_acc=\[.*\]$', l) for l in log[:3])
+    assert log[3].startswith('Time cost in pretrain of PianoBart is ')
+    assert re.search(r'^Loss: \d+\.\d{6} \| loss: ' + ', '.join([r'\d+\.\d{6}'] * 8) + '$', out, re.M)
+    assert re.search(r'^Acc: \d+\.\d{6} \| acc: ', out, re.M) and 'epoch: 3/3 | Train Loss: ' in out
+    # checkpoint layout of pretrain.py:96-110
+    assert set(ck.keys()) == {'epoch', 'state_dict', 'best_acc', 'valid_acc', 'valid_loss', 'train_loss', 'optimizer'}
+    assert ck['epoch'] == 3 and len(ck['state_dict']) == 105 and best_exists
+    cfg = O.BartConfig(max_position_embeddings=128, d_model=128, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512,
+                       decoder_ffn_dim=512, encoder_attention_heads=4, decoder_attention_heads=4)
+    O.PianoBart(cfg, E2W, W2E).load_state_dict(ck['state_dict'], strict=True)        # loads into the reference layout
+    losses = [float(re.search(r'train_loss=([\d.]+)', l).group(1)) for l in log[:3]]
+    assert losses[-1] < losses[0]                                                       # it learns
+
+
+def test_pretrainer_step_matches_oracle_on_its_own_batch():
+    """One Pretrainer batch (device corruption + shift-right + masks) -> fused loss == oracle loss on the same tensors."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from oracle import pianobart_oracle as O
+    from pianobart_amd.model import BartConfig, PianoBart
+    from pianobart_amd.pretrain import Pretrainer
+    from tests.golden_util import randomize_params
+    kw = dict(max_position_embeddings=64, d_model=64, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=128,
+              decoder_ffn_dim=128, encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.0)
+    pb = PianoBart(BartConfig(**kw), E2W, W2E, precision='fp32')
+    tr = Pretrainer(pb, None, None, 2e-5, 4, 64, 0.15, False, [0])
+    randomize_params(tr.model, 3)
+    tr.engine.bind(tr.device)
+    batch = synth_octuple_batch(4, 64, seed=8)[5]
+    enc16, dec16, tgt16, lm, em, dm = tr.prepare_batch(batch)
+    # decoder input = shift-right with SOS (pretrain.py:132-139); masks = bar column != 256 (:151-153)
+    assert torch.equal(dec16.long().cpu(), O.shift_right(batch, pb.sos_word_np))
+    assert torch.equal(em.cpu(), (enc16[:, :, 0].long().cpu() != 256).float())
+    sums = tr.engine.loss_and_grads(enc16, dec16, tgt16, lm, em, dm, train=False).double().cpu()
+    w = torch.tensor(O.loss_weights(E2W), dtype=torch.double)
+    mine = float(((sums[0:8] / sums[8:16]) * w).sum() / w.sum())
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(**kw), E2W, W2E)).eval()
+    o.load_state_dict({k: v.cpu() for k, v in tr.model.state_dict().items()}, strict=True)
+    with torch.no_grad():
+        total, *_ = O.pretrain_loss(o(enc16.long().cpu(), dec16.long().cpu(), em.cpu(), dm.cpu()), batch, lm.cpu(), E2W)
+    assert abs(mine - float(total)) / float(total) < 1e-4
+    masked, pos = tr.gen_mask(batch[0], 2)
+    assert masked.shape == (64, 8) and pos.shape == (64,) and int(pos.sum()) == round(64 * 0.15)
