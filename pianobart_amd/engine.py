@@ -581,9 +581,70 @@ class Engine:
             self._versions = sum(p._version for p in self.params)
 
     # ------------------------------------------------------------------ generate (model.py:28-66)
-    def generate(self, enc_ids, emask, sample_row):
-        """Autoregressive decode. Encoder runs once; the decoder is re-evaluated per position (round 1: no KV cache
-        yet -- same tokens as the reference, which re-runs encoder AND decoder per position)."""
+    def generate(self, enc_ids, emask, sample_row, use_cache=True):
+        """Autoregressive decode with the reference's control flow (SOS start, host-side nucleus sampling, early stop on
+        any special token). The reference re-runs encoder AND decoder over all S positions for every generated position
+        (model.py:42-45); here the encoder runs once, the cross-attention K/V of every decoder layer are projected once,
+        and each step feeds ONE decoder token through the layers against a self-attention K/V cache. Position-i logits
+        only depend on decoder inputs <= i (causal), so the tokens are identical (tests/test_model_gpu.py)."""
+        if not use_cache:
+            return self._generate_nocache(enc_ids, emask, sample_row)
+        pb, d, H, X = self.pb, self.d, self.H, self.xdt
+        self.bind(enc_ids.device)
+        S, dev = enc_ids.shape[1], enc_ids.device
+        pad = torch.from_numpy(pb.pad_word_np).to(dev)
+        pad_cpu = torch.from_numpy(pb.pad_word_np)
+        result = pad.repeat(1, S, 1)
+        em = emask.to(torch.float32).contiguous() if emask is not None else None
+        enc16 = ops.ids_to_i16(enc_ids)
+        e = lambda *shape, dt=X: torch.empty(*shape, dtype=dt, device=dev)
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            _, enc_out = self.forward_hidden(enc16, None, em, None, False, 0)
+            wf, ff = self.wf, self.fd
+            kvc = [e(S, 2 * d) for _ in range(self.ND)]
+            for l in range(self.ND):
+                self._linear(enc_out, 'dec.%d.wkv_c' % l, 'dec.%d.bkv_c' % l, kvc[l], S, 2 * d, d)
+            kvs = [e(S, 2 * d) for _ in range(self.ND)]
+            x, q, ctx, a, y1, qc, ctxc, yc, y2 = (e(1, d) for _ in range(9))
+            u, g = e(1, ff), e(1, ff)
+            mr = f(8)
+            logits = f(1, ops.VOCAB)
+            save = dict(lse=f(1, H, 1)) if self.use_flash else dict(P=e(1, H, 1, S))
+            cur = torch.tensor(pb.sos_word_np, device=dev).reshape(1, 1, 8)
+            for i in range(S):
+                tok16 = ops.ids_to_i16(cur)
+                ops.embed_ln_fwd(tok16.reshape(1, 8), self.ptab, wf['lin.b'], wf['dec.pos'][i:], wf['dec.lne.w'], wf['dec.lne.b'], x,
+                                 mr[0:1], mr[1:2], 1, LN_EPS, 0, 0, 0.0)
+                h = x
+                for l in range(self.ND):
+                    pf = 'dec.%d.' % l
+                    wqkv, bqkv = self.w[pf + 'wqkv'], wf[pf + 'bqkv']
+                    ops.gemm(h, wqkv, q, M=1, N=d, K=d, dtype=self.code, bias=bqkv[:d])
+                    ops.gemm(h, wqkv, kvs[l], M=1, N=2 * d, K=d, dtype=self.code, bias=bqkv[d:], b_off=d * d, c_off=i * 2 * d)
+                    self._attn_fwd((q, 0, d), (kvs[l], 0, 2 * d), (kvs[l], d, 2 * d), (ctx, 0, d), None, False, 1, 1, i + 1, save)
+                    self._linear(ctx, pf + 'wo', pf + 'bo', a, 1, d, d)
+                    ops.add_ln_fwd(h, a, wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], y1, mr[2:3], mr[3:4], LN_EPS, 0, 0, 0.0)
+                    self._linear(y1, pf + 'wq_c', pf + 'bq_c', qc, 1, d, d)
+                    self._attn_fwd((qc, 0, d), (kvc[l], 0, 2 * d), (kvc[l], d, 2 * d), (ctxc, 0, d), em, False, 1, 1, S, save)
+                    self._linear(ctxc, pf + 'wo_c', pf + 'bo_c', a, 1, d, d)
+                    ops.add_ln_fwd(y1, a, wf[pf + 'lnc.w'], wf[pf + 'lnc.b'], yc, mr[4:5], mr[5:6], LN_EPS, 0, 0, 0.0)
+                    self._linear(yc, pf + 'w1', pf + 'b1', g, 1, ff, d, gelu_aux_out=u)
+                    self._linear(g, pf + 'w2', pf + 'b2', a, 1, d, ff)
+                    out = y2 if h is not y2 else x
+                    ops.add_ln_fwd(yc, a, wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], out, mr[6:7], mr[7:8], LN_EPS, 0, 0, 0.0)
+                    h = out
+                ops.gemm(h, self.w['head.w'], logits, M=1, N=ops.VOCAB, K=d, dtype=self.code, bias=wf['head.b'], c_f32=True)
+                tok = sample_row(logits[0].cpu())
+                if (tok >= pad_cpu).any():
+                    break
+                result[:, i, :] = tok.to(dev)
+                cur = tok.to(dev).reshape(1, 1, 8)
+        return result
+
+    def _generate_nocache(self, enc_ids, emask, sample_row):
+        """The reference's schedule minus the redundant encoder re-runs: full decoder pass per position (kept as the
+        cross-check of the cached path)."""
         pb = self.pb
         self.bind(enc_ids.device)
         S = enc_ids.shape[1]

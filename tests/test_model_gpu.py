@@ -233,3 +233,22 @@ def test_cpu_tensors_fail_loudly():
     enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(1, 24, seed=1)
     with pytest.raises(PBError):
         m(enc, dec, emask, dmask)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_generate_kv_cache_equals_full_rerun(precision):
+    """KV-cached decode (encoder once, cross K/V once, one token per step) == re-running the decoder over all positions."""
+    _need_gpu()
+    m = _lm(48, 128, 2, 256, 4, 77, precision).eval()
+    with torch.no_grad():                                   # make special tokens unsamplable: the decode runs all 48 steps
+        for i, p0 in enumerate([256, 128, 129, 256, 128, 32, 254, 49]):
+            m.mask_lm.proj[i].bias[p0:] = -30.0
+    m = m.cuda()
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(1, 48, seed=4, min_len=40)]
+    eng = m._get_engine()
+    np.random.seed(5)
+    a = eng.generate(enc, emask, m.sample_row, use_cache=True)
+    np.random.seed(5)
+    b = eng.generate(enc, emask, m.sample_row, use_cache=False)
+    assert torch.equal(a, b)
+    assert int((a[0, :, 0] != 256).sum()) == 48         # every position was generated
