@@ -40,17 +40,23 @@ def synth_batch(B, S, seed, device):
     return [t.to(device) for t in synth_octuple_batch(B, S, seed)]
 
 
-def cpu_baseline(cfgkw, S):
-    """The oracle (CPU restatement of the reference, kind "port") timed on this host's cores on a bounded
-    sample of the same workload: one full train step at the bench model shape with B=1 (tokens/s is
-    batch-insensitive on CPU; B=32 would take ~15 min). Checker code, timed only as the baseline."""
+def cpu_baseline_child(cfgkw, S):
+    """Runs in a child process (no GPU): the oracle (CPU restatement of the reference, kind "port") timed on this host's
+    cores on a BOUNDED sample of the same workload: one full train step (forward, 8-head masked CE, backward, clip,
+    HF AdamW) at the bench model shape with B=1 and S=256 positions of the S=1024 table (tokens/s is batch-insensitive
+    on CPU; a B=32, S=1024 step would take ~15 min). Checker code, timed only as the reported baseline."""
     from oracle import pianobart_oracle as O
     from tests.golden_util import load_vocab, synth_octuple_batch
     e2w, w2e = load_vocab()
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
     torch.set_num_threads(cores)
     m = O.PianoBartLM(O.PianoBart(O.BartConfig(**cfgkw), e2w, w2e)).train()
-    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(1, S, seed=3)
+    Ss = min(S, 256)
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(1, Ss, seed=3)
     params = [p for p in m.parameters()]
     opt_m = opt_v = None
     times = []
@@ -68,12 +74,66 @@ def cpu_baseline(cfgkw, S):
         with torch.no_grad():
             O.hf_adamw_step([p.data for p in live], grads, opt_m, opt_v, step=it + 1, lr=2e-5)
         times.append(time.time() - t0)
+        if times[-1] > 45:
+            break
     t = min(times)
-    return {"value": S / t, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": "oracle (torch fp32 restatement of the reference) full train step, same model shape, B=1 S=%d, best of 2 (%.1f s/step)" % (S, t)}
+    print(json.dumps({"value": Ss / t, "unit": "tokens/s", "cores": cores, "kind": "port",
+                      "sample": "oracle (torch fp32 restatement of the reference) full train step, same model shape, B=1, %d of the %d positions, "
+                                "best of %d (%.1f s/step), %d threads" % (Ss, S, len(times), t, cores)}), flush=True)
+
+
+def cpu_baseline(cfgkw, S, timeout=170):
+    """Bounded: the child is killed after `timeout` seconds so the default bench run always finishes within minutes."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', json.dumps(cfgkw), str(S)],
+                           capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return {"value": None, "unit": "tokens/s", "cores": None, "kind": "port", "sample": "child failed: " + r.stderr[-200:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "tokens/s", "cores": None, "kind": "port", "sample": "oracle train step did not finish within %d s on this host" % timeout}
+
+
+def decode_bench(args, model, eng, dev, rank):
+    """BASELINE configs[3]: prompt (1,S,8) with L_enc ~ S/2 then EOS + PAD, KV-cached decode; special tokens are made
+    unsamplable so that every run generates `--steps` positions (random-init weights would stop at once)."""
+    import numpy as np
+    from tests.golden_util import synth_octuple_batch
+    model.eval()
+    with torch.no_grad():
+        for i, p0 in enumerate([256, 128, 129, 256, 128, 32, 254, 49]):
+            model.mask_lm.proj[i].bias[p0:] = -30.0
+    S = args.seq
+    enc = synth_octuple_batch(1, S, seed=7, min_len=S // 2)[5].to(dev)
+    emask = (enc[:, :, 0] != 256).float()
+    nsteps = min(args.steps, S)
+    count = {'n': 0}
+
+    def sample_row(row):
+        count['n'] += 1
+        if count['n'] > nsteps:
+            return torch.tensor([256, 128, 129, 256, 128, 32, 254, 49])          # PAD row: stops the loop
+        return model.sample_row(row)
+
+    np.random.seed(0)
+    eng.generate(enc[:, :64].contiguous(), emask[:, :64].contiguous(), lambda r: torch.tensor([256, 128, 129, 256, 128, 32, 254, 49]))  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = eng.generate(enc, emask, sample_row)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "generate tokens/s (KV-cached decode, B=1, S=%d)" % S, "value": nsteps / dt, "unit": "tokens/s", "n_gpus": 1,
+                          "steps": nsteps, "warmup": 1, "ms_per_step": dt / nsteps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                          "config": {"workload": "decode %dL/%dd S=%d B=1, encoder + cross-K/V once (included in the time)" % (args.layers, args.hs, S)}}), flush=True)
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == '--cpu-baseline-child':
+        return cpu_baseline_child(json.loads(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -87,6 +147,7 @@ def main():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dropout', action='store_true')
+    ap.add_argument('--mode', default='pretrain', choices=['pretrain', 'decode'], help='decode = BASELINE configs[3]: KV-cached generate, B=1')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); local_rank = int(os.environ.get('LOCAL_RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
@@ -110,6 +171,8 @@ def main():
     model = PianoBartLM(PianoBart(BartConfig(**cfgkw), e2w, w2e, precision=args.precision)).train().to(dev)
     eng = model._get_engine()
     eng.bind(dev)
+    if args.mode == 'decode':
+        return decode_bench(args, model, eng, dev, rank)
     B, S = args.batch, args.seq
     enc, dec, loss_mask, emask, dmask, target = synth_batch(B, S, seed=1234 + rank, device=dev)
     enc16, dec16, tgt16 = ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target)
