@@ -120,6 +120,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
         const char* ldsK = st; const char* ldsV = st + 8192;
         const float* ldsB = reinterpret_cast<const float*>(st + 16384);
         const int k0 = it * 64;
+        const bool diag = p.causal && (k0 + 63 > q0 + wave * 32);        // wave-uniform: only tiles that touch the diagonal compare
         f32x4 s[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -139,8 +140,8 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = s[qt][kt][r] * c + bias[r];
-                    if (p.causal && (k0 + kt * 16 + g * 4 + r) > myq[qt]) x = -INFINITY;
+                    float x = fmaf(s[qt][kt][r], c, bias[r]);
+                    if (diag && (k0 + kt * 16 + g * 4 + r) > myq[qt]) x = -INFINITY;
                     s[qt][kt][r] = x;
                     mx = fmaxf(mx, x);
                 }
@@ -148,12 +149,12 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
             mx = grp_max(mx);
             const float mnew = fmaxf(m[qt], mx);
             const float muse = mnew == -INFINITY ? 0.f : mnew;
-            const float alpha = exp2f(m[qt] - muse);
+            const float alpha = __builtin_amdgcn_exp2f(m[qt] - muse);
             float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = exp2f(s[qt][kt][r] - muse); s[qt][kt][r] = e; rs += e; }
+                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[qt][kt][r] - muse); s[qt][kt][r] = e; rs += e; }
             rs = grp_sum(rs);
             l[qt] = l[qt] * alpha + rs;
             m[qt] = mnew;
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         const char* ldsQ = st; const char* ldsO = st + 8192;
         const float* ldsL = reinterpret_cast<const float*>(st + 16384);
         const int q0 = it * 64;
+        const bool diag = p.causal && (k0 + wave * 32 + 31 > q0);          // wave-uniform: this q tile can be below some of the wave's keys
         bf16x8 pf[2][2], df[2][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {            // q tiles (2 half, 2 half + 1) -> one k-step of the dV/dK products
@@ -259,8 +261,8 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int q = q0 + qt * 16 + g * 4 + r;
-                        const bool vis = kvis[kt] && (!p.causal || mykey[kt] <= q);
-                        const float pr = vis ? exp2f(sv[r] * c - lse[r]) : 0.f;
+                        const bool vis = kvis[kt] && (!diag || mykey[kt] <= q);
+                        const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(sv[r], c, -lse[r])) : 0.f;
                         sv[r] = pr;
                         dv_[r] = pr * (dv_[r] - dl[r]) * p.scale;
                     }
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         const char* ldsK = st; const char* ldsV = st + 8192;
         const float* ldsB = reinterpret_cast<const float*>(st + 16384);
         const int k0 = it * 64;
+        const bool diag = p.causal && (k0 + 63 > q0 + wave * 32);
         bf16x8 df[2][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -366,8 +369,8 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = k0 + kt * 16 + g * 4 + r;
-                        const bool vis = vis4[r] != 0.f && (!p.causal || key <= myq[qt]);
-                        const float pr = vis ? exp2f(sv[r] * c - lse[qt]) : 0.f;
+                        const bool vis = vis4[r] != 0.f && (!diag || key <= myq[qt]);
+                        const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(sv[r], c, -lse[qt])) : 0.f;
                         dpv[r] = pr * (dpv[r] - dl[qt]) * p.scale;
                     }
                     ds_[qt][kk] = dpv;

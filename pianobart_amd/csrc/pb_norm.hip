@@ -158,10 +158,10 @@ __global__ __launch_bounds__(256) void finalize_partials_kernel(const float* __r
     if (!o) return;
     float s = 0.f;
     if (c < d)
-        for (int b = ry; b < nblk; b += 4) s += partials[((size_t)b * nacc + k) * d + c];
+        for (int b = blockIdx.z * 4 + ry; b < nblk; b += 4 * gridDim.z) s += partials[((size_t)b * nacc + k) * d + c];
     red[ry][cx] = s;
     __syncthreads();
-    if (ry == 0 && c < d) o[c] += red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+    if (ry == 0 && c < d) atomicAdd(o + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);   // <= 8 addends per element
 }
 
 // ------------------------------------------------------------------ Octuple embed + pos + LN
@@ -356,7 +356,7 @@ extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, 
 
 static int launch_finalize(const float* partials, int nblk, int nacc, int d, float* o0, float* o1, float* o2, float* o3,
                            hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_partials_kernel, dim3((d + 63) / 64, nacc), dim3(256), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
+    hipLaunchKernelGGL(finalize_partials_kernel, dim3((d + 63) / 64, nacc, nblk >= 64 ? 8 : 1), dim3(256), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
     PB_LAUNCH_CHECK();
     return 0;
 }
