@@ -147,6 +147,7 @@ def main():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dropout', action='store_true')
+    ap.add_argument('--force-reducer', action='store_true', help='install the RCCL gradient reducer even at world size 1 (test)')
     ap.add_argument('--mode', default='pretrain', choices=['pretrain', 'decode'], help='decode = BASELINE configs[3]: KV-cached generate, B=1')
     args = ap.parse_args()
 
@@ -155,9 +156,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU path): torch.cuda.is_available() is False')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
 
     from pianobart_amd import ops
     from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
@@ -177,7 +179,7 @@ def main():
     enc, dec, loss_mask, emask, dmask, target = synth_batch(B, S, seed=1234 + rank, device=dev)
     enc16, dec16, tgt16 = ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target)
     loss_mask = loss_mask.contiguous()
-    reducer = GradReducer(eng, world) if world > 1 else None
+    reducer = GradReducer(eng, world) if (world > 1 or args.force_reducer) else None
 
     def step():
         sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=True,
@@ -249,7 +251,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfgkw, S)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         dist.destroy_process_group()
 
 

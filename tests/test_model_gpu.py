@@ -252,3 +252,25 @@ def test_generate_kv_cache_equals_full_rerun(precision):
     b = eng.generate(enc, emask, m.sample_row, use_cache=False)
     assert torch.equal(a, b)
     assert int((a[0, :, 0] != 256).sum()) == 48         # every position was generated
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 8e-2)])
+def test_head_dim_96_falls_back_to_unfused_attention(precision, tol):
+    """Reference CLI default heads=8 gives head_dim 96 at d=768: not covered by the flash kernels -> GEMM + masked softmax."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    m = _lm(40, 192, 1, 256, 2, 5, precision, dropout=0.0).train()
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(max_position_embeddings=40, d_model=192, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=256,
+                                               decoder_ffn_dim=256, encoder_attention_heads=2, decoder_attention_heads=2, dropout=0.0), E2W, W2E)).train()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda()
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(2, 40, seed=6)
+    total_o, *_ = O.pretrain_loss(o(enc, dec, emask, dmask), target, loss_mask, E2W)
+    total_o.backward()
+    y = m(enc.cuda(), dec.cuda(), emask.cuda(), dmask.cuda())
+    total, *_ = O.pretrain_loss(y, target.cuda(), loss_mask.cuda(), E2W)
+    total.backward()
+    assert abs(float(total) - float(total_o)) / float(total_o) < tol
+    go = dict(o.named_parameters()); gm = dict(m.named_parameters())
+    for k in ('pianobart.bart.encoder.layers.0.self_attn.q_proj.weight', 'pianobart.bart.decoder.layers.0.encoder_attn.v_proj.weight', 'pianobart.word_emb.3.lut.weight'):
+        assert _rel(gm[k].grad, go[k].grad) < (1e-3 if precision == 'fp32' else 0.2), k
