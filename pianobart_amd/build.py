@@ -10,7 +10,10 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libpianobart_hip.so')
 ARCH = 'gfx950'
-FLAGS = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-ffp-contract=fast', '-Wno-unused-result']
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc parks them in AGPRs
+# and every VALU touch of an accumulator (softmax rescale, epilogues) costs a v_accvgpr_read/write pair.
+FLAGS = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-ffp-contract=fast', '-Wno-unused-result',
+         '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 
 
 def _hipcc():

@@ -262,7 +262,8 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // tile choice: 128x128 (4 waves, 2 blocks/CU) by default; 256x256 (8 waves, 128x64 per wave, half the L2->LDS
     // traffic per FLOP) when asked for (PB_GEMM_TILE256: the split-K wgrad GEMMs, whose output phase is negligible)
     const bool big = (d->flags & PB_GEMM_TILE256) && d->M >= 256 && d->N >= 256;
-    const int BMs = big ? 256 : 128, BNs = big ? 256 : 128;
+    const bool tall = !big && (d->flags & 512) && d->M >= 1024;   // measured: no gain over 128x128 (tools/gemm_bench.py), kept for experiments      // 256x128: 8 waves of 64x64, 25% less L2->LDS traffic per FLOP
+    const int BMs = (big || tall) ? 256 : 128, BNs = big ? 256 : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
     dim3 grid(a.tiles_m * a.tiles_n, nb1 * a.nb2, nsplit);
 #define PB_G2_LAUNCH(AK, BK_, WM_, WN_, TM_, TN_)                                                                       \
@@ -272,7 +273,12 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, stream, a);                                                \
     } while (0)
-    if (big) {
+    if (tall) {
+        if (a_kc && b_kc) PB_G2_LAUNCH(true, true, 4, 2, 4, 4);
+        else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 4, 2, 4, 4);
+        else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 4, 2, 4, 4);
+        else PB_G2_LAUNCH(false, false, 4, 2, 4, 4);
+    } else if (big) {
         if (a_kc && b_kc) PB_G2_LAUNCH(true, true, 2, 4, 8, 4);
         else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 2, 4, 8, 4);
         else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 2, 4, 8, 4);

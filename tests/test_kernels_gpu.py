@@ -309,7 +309,9 @@ def test_flash_attention_fwd_bwd(ops, hd, causal, S, generic):
                                           (768, 384, 2048, 4), (264, 72, 1024, 8), (3072, 768, 4096, 2), (1000, 520, 448, 3),
                                           (512, 256, 128, 1)])
 @pytest.mark.parametrize('tile256', [False, True])
-def test_gemm2_fast_path_matches_generic(ops, a_kc, b_kc, M, N, K, splitk, tile256):
+@pytest.mark.parametrize('Mx', [1, 5])
+def test_gemm2_fast_path_matches_generic(ops, a_kc, b_kc, M, N, K, splitk, tile256, Mx):
+    M = M * Mx            # Mx = 5 reaches the 256x128 tile (M >= 1024) on the larger shapes
     """bf16 direct-to-LDS / transposed-read kernel (+ split-K slabs) vs fp64 and vs the generic kernel."""
     g = torch.Generator(device='cuda').manual_seed(M + N + K)
     A = torch.randn(M, K, device='cuda', generator=g)

@@ -33,16 +33,24 @@ def run(name, M, N, K, a_kc, b_kc, force_v1, splitk=1, tile128=False):
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
+def run2(name, M, N, K, a_kc, b_kc, **kw):
+    A = torch.randn((M, K) if a_kc else (K, M), device=dev).to(torch.bfloat16)
+    B = torch.randn((N, K) if b_kc else (K, N), device=dev).to(torch.bfloat16)
+    C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    f = lambda: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, **kw)
+    for _ in range(3):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+
 for name, M, N, K, a_kc, b_kc in shapes:
-    ms2, tf2 = run(name, M, N, K, a_kc, b_kc, False, tile128=True)
-    ms3, tf3 = run(name, M, N, K, a_kc, b_kc, False)
-    line = '%-8s M=%6d N=%5d K=%6d  t128 %7.3f ms %6.0f TF | t256 %7.3f ms %6.0f TF' % (name, M, N, K, ms2, tf2, ms3, tf3)
     if not a_kc:
-        for big in (False, True):
-            tl = 256 if big else 128
-            tiles = ((M + tl - 1) // tl) * ((N + tl - 1) // tl)
-            for blocks in (256, 512, 1024):
-                sk = max(1, min(32, round(blocks / tiles)))
-                ms4, tf4 = run(name, M, N, K, a_kc, b_kc, False, sk, tile128=not big)
-                line += ' | t%d sk%d %5.3f ms %4.0f TF' % (tl, sk, ms4, tf4)
-    print(line, flush=True)
+        continue
+    r = [run2(name, M, N, K, a_kc, b_kc, tile128=True), run2(name, M, N, K, a_kc, b_kc), run2(name, M, N, K, a_kc, b_kc, tile256=True)]
+    print('%-8s M=%6d N=%5d K=%6d  128x128 %6.3f ms %5.0f TF | 256x128 %6.3f ms %5.0f TF | 256x256 %6.3f ms %5.0f TF' % (name, M, N, K, r[0][0], r[0][1], r[1][0], r[1][1], r[2][0], r[2][1]), flush=True)
