@@ -76,12 +76,25 @@ __device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 16, 64); 
 
 constexpr int STG = 2 * 8192 + 512;        // one stage: two 8 KiB images + 128 floats
 
+// 1-D grid -> (row block, head, batch). Workgroups are dealt round-robin over the 8 XCDs (id % 8): all row blocks of one
+// (batch, head) are given to ONE XCD, back to back, so the K/V (or Q/dO) tiles they all stream stay in that XCD's 4 MiB
+// L2 (measured before: FETCH_SIZE 705 MB per forward launch = K/V re-fetched from beyond L2 by each of the 8 q-blocks).
+__device__ __forceinline__ void block_map(int nrb, int H, int B, int& rb, int& h, int& b) {
+    const int L = blockIdx.x, BH = H * B;
+    int bh;
+    if ((BH & 7) == 0) { const int x = L & 7, slot = L >> 3; bh = (slot / nrb) * 8 + x; rb = slot % nrb; }
+    else { bh = L / nrb; rb = L % nrb; }
+    h = bh % H; b = bh / H;
+}
+
 // ================================================================== forward: block = 128 queries
 __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+    int rb, h, b;
+    block_map((p.Sq + 127) / 128, p.H, p.B, rb, h, b);
+    const int q0 = rb * 128;
     const bf16_t* Q = p.q + b * p.q_sb + h * HD;
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;
@@ -194,7 +207,9 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int k0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+    int rb, h, b;
+    block_map((p.Sk + 127) / 128, p.H, p.B, rb, h, b);
+    const int k0 = rb * 128;
     const bf16_t* Q = p.q + b * p.q_sb + h * HD;
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;
@@ -305,7 +320,9 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+    int rb, h, b;
+    block_map((p.Sq + 127) / 128, p.H, p.B, rb, h, b);
+    const int q0 = rb * 128;
     const bf16_t* Q = p.q + b * p.q_sb + h * HD;
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;
@@ -411,7 +428,7 @@ int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* 
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal;
-    hipLaunchKernelGGL(fa64_fwd_kernel, dim3((Sq + 127) / 128, H, B), dim3(FT), 2 * STG, stream, a);
+    hipLaunchKernelGGL(fa64_fwd_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), 2 * STG, stream, a);
     PB_LAUNCH_CHECK();
     return 0;
 }
@@ -426,9 +443,9 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
     a.scale = scale; a.causal = causal;
-    hipLaunchKernelGGL(fa64_bwd_dkv_kernel, dim3((Sk + 127) / 128, H, B), dim3(FT), 2 * STG, stream, a);
+    hipLaunchKernelGGL(fa64_bwd_dkv_kernel, dim3(((Sk + 127) / 128) * H * B), dim3(FT), 2 * STG, stream, a);
     PB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fa64_bwd_dq_kernel, dim3((Sq + 127) / 128, H, B), dim3(FT), 2 * STG, stream, a);
+    hipLaunchKernelGGL(fa64_bwd_dq_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), 2 * STG, stream, a);
     PB_LAUNCH_CHECK();
     return 0;
 }

@@ -31,7 +31,7 @@ struct Gemm2Args {
     int M, N, K, Kc;                      // Kc = K range per split (multiple of 64)
     long lda, ldb, ldc, ldaux;
     int nb2; long sA1, sA2, sB1, sB2, sC1, sC2, sCz;
-    float alpha; int flags; int tiles_m, tiles_n;
+    float alpha; int flags; int tiles_m, tiles_n, nsplit;
 };
 
 __device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
@@ -111,11 +111,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    int bid = blockIdx.x;
     const int ntiles = p.tiles_m * p.tiles_n;
+    // 1-D grid over (split, tile). XCD x (= id % 8) takes a CONTIGUOUS chunk of the (split-major, tile-minor) list, so with
+    // split-K the workgroups of one XCD work on (nearly) one K slice: its A/B rows are fetched into that L2 once and
+    // shared by all its tiles (wgrad measured ~2x its algorithmic bytes from beyond L2 with the tile-only remap).
+    int bid, zs;
     {
-        const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, idx = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+        const int total = ntiles * p.nsplit, L = blockIdx.x;
+        const int q = total >> 3, r = total & 7, x = L & 7, idx = L >> 3;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+        zs = lin / ntiles; bid = lin - zs * ntiles;
     }
     // grouped tile order inside an XCD's chunk: super-rows of GM M-tiles x all N-tiles, M fastest. The ~64 workgroups an
     // XCD runs at once then cover ~8 x 8 tiles: 8 A row-panels + 8 B panels are fetched into its L2 and shared, instead
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
     const int gm = min(GM, p.tiles_m - first_m), rem = bid - grp * gsz;
     const int tm = first_m + rem % gm, tn = rem / gm;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2, zs = blockIdx.z;
+    const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
     const long coff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
@@ -272,7 +277,8 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     const bool tall = !big && (d->flags & 512) && d->M >= 1024;   // measured: no gain over 128x128 (tools/gemm_bench.py), kept for experiments      // 256x128: 8 waves of 64x64, 25% less L2->LDS traffic per FLOP
     const int BMs = (big || tall) ? 256 : 128, BNs = big ? 256 : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
-    dim3 grid(a.tiles_m * a.tiles_n, nb1 * a.nb2, nsplit);
+    a.nsplit = nsplit;
+    dim3 grid(a.tiles_m * a.tiles_n * nsplit, nb1 * a.nb2, 1);
 #define PB_G2_LAUNCH(AK, BK_, WM_, WN_, TM_, TN_)                                                                       \
     do {                                                                                                                 \
         auto kfn = gemm2_kernel<AK, BK_, WM_, WN_, TM_, TN_>;                                                              \
