@@ -206,12 +206,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
                 if (do_gelu) {
                     store4(p.aux_out + (long)row * p.ldaux + colb, v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                 }
                 if (mul_gg) {
                     const f32x4 u = load4(p.aux_in + (long)row * p.ldaux + colb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(u[e]);
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u[e]);
                 }
                 const long ci = (long)row * p.ldc + colb;
                 if (c32) {
