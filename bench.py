@@ -96,6 +96,18 @@ def cpu_baseline(cfgkw, S, timeout=170):
         return {"value": None, "unit": "tokens/s", "cores": None, "kind": "port", "sample": "oracle train step did not finish within %d s on this host" % timeout}
 
 
+def pmc_traffic(M, N, K):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_gemm_fc1_pmc.json,
+    FETCH_SIZE x2 + WRITE_SIZE, collected offline: counters cannot be read from inside this process). None if the shape differs."""
+    try:
+        j = json.load(open(os.path.join(ROOT, 'profiles', 'r01_gemm_fc1_pmc.json')))
+        if 'M=%d N=%d K=%d' % (M, N, K) in j['kernel']:
+            return j['hbm_bytes_per_launch']
+    except Exception:
+        pass
+    return None
+
+
 def decode_bench(args, model, eng, dev, rank):
     """BASELINE configs[3]: prompt (1,S,8) with L_enc ~ S/2 then EOS + PAD, KV-cached decode; special tokens are made
     unsamplable so that every run generates `--steps` positions (random-init weights would stop at once)."""
@@ -245,7 +257,7 @@ def main():
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world,
                        "flops_per_token_train": fpt},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
-                         "traffic": None, "kernel": "gemm_kernel<%s,NT> fc1 shape M=%d N=%d K=%d" % (args.precision, T, args.ffn, args.hs),
+                         "traffic": pmc_traffic(T, args.ffn, args.hs), "kernel": "gemm_kernel<%s,NT> fc1 shape M=%d N=%d K=%d" % (args.precision, T, args.ffn, args.hs),
                          "avg_launch_ms": gemm_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
