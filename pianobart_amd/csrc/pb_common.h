@@ -49,6 +49,13 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
     *reinterpret_cast<bf16x4*>(p) = r;
 }
 
+// non-temporal variants (streaming outputs that are not re-read by this kernel)
+__device__ __forceinline__ void store4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+__device__ __forceinline__ void store4_nt(bf16_t* p, f32x4 v) {
+    bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    __builtin_nontemporal_store(r, reinterpret_cast<bf16x4*>(p));
+}
+
 // ---- wave64 reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

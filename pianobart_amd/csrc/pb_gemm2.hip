@@ -102,7 +102,9 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int rbase /*multiple of 
 // WM x WN waves, each TM x TN MFMA tiles of 16x16: block tile BM = 16*WM*TM by BN = 16*WN*TN.
 // Measured (tools/gemm_probe.py, MI355X): the 128x128 main loop is bound by the L2 -> LDS load path (~60 GB/s per CU,
 // 64 FLOP per loaded byte -> ~1 PF ceiling), the 256x256 one reaches 1.1-1.2 PF; the output write (HBM write rate,
-// ~3.1 TB/s) is NOT overlapped with the main loop yet (next: deferred stores under the following tile's K loop).
+// ~3.1 TB/s) is NOT overlapped with the main loop. Tried and measured (tools/gemm_probe.py history): persistent tiles with
+// stores left in flight, register epilogue with swapped MFMA operands, non-temporal stores, and the store traffic spread
+// over the K loop of the same launch (hides only ~1/3 of it) -- none pays; the 8-phase counted-vmcnt pipeline is next.
 template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
             if (row < p.M && colb < p.N) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(panel + prow * PW + pcol) * p.alpha + bv;
                 if (do_gelu) {
-                    store4(p.aux_out + (long)row * p.ldaux + colb, v);
+                    if (p.flags & 1024) store4_nt(p.aux_out + (long)row * p.ldaux + colb, v); else store4(p.aux_out + (long)row * p.ldaux + colb, v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                 }
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
                     store4(C32 + ci, v);
                 } else {
                     if (accum) v += load4(CT + ci);
-                    store4(CT + ci, v);
+                    if (p.flags & 1024) store4_nt(CT + ci, v); else store4(CT + ci, v);
                 }
             }
         }
@@ -255,7 +257,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % 4 != 0 || d->sC1 % 4 != 0 || d->sC2 % 4 != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 4 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 256)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 256 | 1024)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue");
         return -2;
     }

@@ -19,3 +19,4 @@ for (M, N) in ((T, 768), (T, 3072)):
         for t128 in (True, False):
             full, nost, nolp = run(M, N, K, 0, t128), run(M, N, K, 128, t128), run(M, N, K, 256, t128)
             print('M=%d N=%d K=%d tile%s: full %.1f us (%.0f TF) | no-store %.1f | epilogue-only %.1f' % (M, N, K, 256 if t128 else 128, full, 2.0*M*N*K/full/1e6, nost, nolp), flush=True)
+
