@@ -274,3 +274,48 @@ def test_head_dim_96_falls_back_to_unfused_attention(precision, tol):
     go = dict(o.named_parameters()); gm = dict(m.named_parameters())
     for k in ('pianobart.bart.encoder.layers.0.self_attn.q_proj.weight', 'pianobart.bart.decoder.layers.0.encoder_attn.v_proj.weight', 'pianobart.word_emb.3.lut.weight'):
         assert _rel(gm[k].grad, go[k].grad) < (1e-3 if precision == 'fp32' else 0.2), k
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 6e-2)])
+def test_ragged_length_and_fully_padded_sample(precision, tol):
+    """S = 200 (not a multiple of the 64/128-row attention tiles), head_dim 64 (flash64 path in bf16), one sample that is
+    PAD from the first row on (every encoder key masked -> zero-row rule), B = 3: logits, loss and grad norm vs the oracle."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    kw = dict(max_position_embeddings=200, d_model=256, encoder_layers=1, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+              encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.0)
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    m = PianoBartLM(PianoBart(BartConfig(**kw), E2W, W2E, precision=precision)).train()
+    randomize_params(m, 21)
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(**kw), E2W, W2E)).train()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda()
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(3, 200, seed=14)
+    pad = torch.tensor([256, 128, 129, 256, 128, 32, 254, 49])
+    enc[2] = pad; target[2] = pad; dec[2, 1:] = pad                      # sample 2: nothing but PAD (decoder keeps its SOS row)
+    emask = (enc[:, :, 0] != 256).float(); dmask = (dec[:, :, 0] != 256).float()
+    assert float(emask[2].sum()) == 0
+    yo = o(enc, dec, emask, dmask)
+    total_o, *_ = O.pretrain_loss(yo, target, loss_mask, E2W)
+    total_o.backward()
+    y = m(enc.cuda(), dec.cuda(), emask.cuda(), dmask.cuda())
+    assert _rel(torch.cat(y, -1), torch.cat(yo, -1).detach()) < tol
+    assert not torch.isnan(torch.cat(y, -1)).any()
+    total, *_ = O.pretrain_loss(y, target.cuda(), loss_mask.cuda(), E2W)
+    total.backward()
+    assert abs(float(total) - float(total_o)) / float(total_o) < tol
+    gn = lambda mod: float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in mod.parameters() if p.grad is not None)))
+    assert abs(gn(m) - gn(o)) / gn(o) < (1e-3 if precision == 'fp32' else 5e-2)
+
+
+def test_tiny_batch_one_short_sequence():
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    m = _lm(8, 64, 1, 64, 2, 9, 'fp32').eval()
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(max_position_embeddings=8, d_model=64, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=64,
+                                               decoder_ffn_dim=64, encoder_attention_heads=2, decoder_attention_heads=2), E2W, W2E)).eval()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda()
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(1, 8, seed=1, min_len=5)
+    with torch.no_grad():
+        assert _rel(torch.cat(m(enc.cuda(), dec.cuda(), emask.cuda(), dmask.cuda()), -1), torch.cat(o(enc, dec, emask, dmask), -1)) < 1e-4
