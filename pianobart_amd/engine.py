@@ -74,7 +74,7 @@ class Engine:
             cur[0] += _r4(int(np.prod(shape)))
 
         # region A: matrices whose gradients are OVERWRITTEN by one wgrad GEMM each step
-        add('emb', ops.VOCAB, 256)
+        add('emb', ops.TAB_TOTAL, 256)                 # 8 slots of 264 rows (pad rows stay zero: zero grad, zero decay)
         add('lin.w', d, 2048)
         for l in range(self.NE):
             p = 'enc.%d.' % l
@@ -107,7 +107,7 @@ class Engine:
         out = []
         off = 0
         for i in range(8):
-            out.append((pb.word_emb[i].lut.weight, 'emb', off)); off += ops.SEG_SIZES[i]
+            out.append((pb.word_emb[i].lut.weight, 'emb', ops.TAB_OFF[i]))
         out.append((pb.encoder_linear.weight, 'lin.w', 0)); out.append((pb.encoder_linear.bias, 'lin.b', 0))
         for side, stack, n in (('enc', pb.bart.encoder, self.NE), ('dec', pb.bart.decoder, self.ND)):
             out.append((stack.embed_positions.weight, side + '.pos', 0))
@@ -175,8 +175,8 @@ class Engine:
         self.opt_m = self.opt_v = None
         self._versions = None
         self._ws_cache = {}
-        self.ptab = torch.empty(ops.VOCAB, self.d, dtype=torch.float32, device=device)
-        self.dptab = torch.empty(ops.VOCAB, self.d, dtype=torch.float32, device=device)
+        self.ptab = torch.zeros(ops.TAB_TOTAL, self.d, dtype=torch.float32, device=device)
+        self.dptab = torch.zeros(ops.TAB_TOTAL, self.d, dtype=torch.float32, device=device)
         npart = max(int(LIB.query('pb_ln_partials_floats', self.d)), int(LIB.query('pb_colsum_partials_floats', max(3 * self.d, self.fe, self.fd, ops.VOCAB))),
                     int(LIB.query('pb_ce_partials_floats')), int(LIB.query('pb_norm_partials_floats')))
         self.partials = torch.empty(npart, dtype=torch.float32, device=device)
@@ -223,7 +223,7 @@ class Engine:
                   scores=None if self.use_flash else f(B, H, S, S), dS=None if self.use_flash else e(B, H, S, S), delta=f(B, H, S),
                   gy=[e(T, d), e(T, d)], gA=e(T, d), gB=e(T, d), gC=e(T, d), dqkv=e(T, 3 * d), dq=e(T, d), dkv=e(T, 2 * d),
                   du=e(T, max(self.fe, self.fd)), genc=e(T, d), dlogits=e(T, ops.VOCAB) if self.mlm is not None else None,
-                  dz=e(2 * T, d) if self.code == PB_BF16 else None, onehot=e(2 * T, ops.VOCAB) if self.code == PB_BF16 else None)
+                  dz=e(2 * T, d) if self.code == PB_BF16 else None, onehot=e(2 * T, ops.TAB_TOTAL) if self.code == PB_BF16 else None)
         self._ws_cache = {key: ws}          # keep one shape resident
         return ws
 
@@ -276,11 +276,9 @@ class Engine:
 
     def build_ptab(self):
         """P[off_i + v] = 16 * E_i[v] @ W_lin[:, 256 i : 256 i + 256]^T in exact f32 (PianoBart.py:16,67-71)."""
-        E, W = self.wf['emb'], self.wf['lin.w']
-        for i in range(8):
-            o, n = ops.SEG_OFF[i], ops.SEG_SIZES[i]
-            ops.gemm(E, W, self.ptab, M=n, N=self.d, K=256, dtype=PB_F32, lda=256, ldb=2048, ldc=self.d, alpha=16.0, c_f32=True,
-                     a_off=o * 256, b_off=256 * i, c_off=o * self.d)
+        R = ops.TAB_ROWS
+        ops.gemm(self.wf['emb'], self.wf['lin.w'], self.ptab, M=R, N=self.d, K=256, dtype=PB_F32, lda=256, ldb=2048, ldc=self.d, alpha=16.0,
+                 c_f32=True, nb1=8, sA=(R * 256, 0), sB=(256, 0), sC=(R * self.d, 0))
 
     # ------------------------------------------------------------------ forward
     def forward_hidden(self, enc16, dec16, emask, dmask, train, seed, reuse_encoder=False):
@@ -298,7 +296,7 @@ class Engine:
         x = ws['x_enc']
         if not reuse_encoder:
             ops.embed_ln_fwd(enc16, self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], wf['enc.lne.b'], x, ws['me'], ws['re'], S,
-                             LN_EPS, seed, self._site('enc_emb'), p)
+                             LN_EPS, seed, self._site('enc_emb'), p, padded=True)
         for l in range(self.NE if not reuse_encoder else 0):
             L, pf = ws['enc'][l], 'enc.%d.' % l
             self._linear(x, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
@@ -314,7 +312,7 @@ class Engine:
             return None, enc_out
         y = ws['x_dec']
         ops.embed_ln_fwd(dec16, self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], wf['dec.lne.b'], y, ws['md'], ws['rd'], S,
-                         LN_EPS, seed, self._site('dec_emb'), p)
+                         LN_EPS, seed, self._site('dec_emb'), p, padded=True)
         for l in range(self.ND):
             L, pf = ws['dec'][l], 'dec.%d.' % l
             self._linear(y, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
@@ -436,7 +434,7 @@ class Engine:
                 self._ready(pf + 'wqkv', pf + 'w2')
             ops.embed_ln_bwd(cur, sv['dec16'], self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], ws['md'], ws['rd'], self.dptab,
                              g['dec.pos'], g['lin.b'], g['dec.lne.w'], g['dec.lne.b'], self.partials, S, seed, self._site('dec_emb'), p,
-                             dz_out=ws['dz'][T:] if onehot_route else None)
+                             dz_out=ws['dz'][T:] if onehot_route else None, padded=True)
             if onehot_route:
                 ops.batch_sum(ws['dz'][T:], g['dec.pos'][2:2 + S], B, S * d)
             cur = genc
@@ -459,27 +457,25 @@ class Engine:
             self._ready(pf + 'wqkv', pf + 'w2')
         ops.embed_ln_bwd(cur, sv['enc16'], self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], ws['me'], ws['re'], self.dptab,
                          g['enc.pos'], g['lin.b'], g['enc.lne.w'], g['enc.lne.b'], self.partials, S, seed, self._site('enc_emb'), p,
-                         dz_out=ws['dz'][:T] if onehot_route else None)
+                         dz_out=ws['dz'][:T] if onehot_route else None, padded=True)
         if onehot_route:
             # dP = Onehot^T dz over the encoder AND decoder tokens in one split-K MFMA GEMM (K = 2T): no atomics
             ops.batch_sum(ws['dz'][:T], g['enc.pos'][2:2 + S], B, S * d)
-            ops.onehot_build(sv['enc16'], ws['onehot'][:T])
+            ops.onehot_build(sv['enc16'], ws['onehot'][:T], padded=True)
             K2 = 2 * T if gy_dec is not None else T
             if gy_dec is not None:
-                ops.onehot_build(sv['dec16'], ws['onehot'][T:])
-            need = 16 * ops.VOCAB * d
+                ops.onehot_build(sv['dec16'], ws['onehot'][T:], padded=True)
+            need = 16 * ops.TAB_TOTAL * d
             if self._slabs is None or self._slabs.numel() < need:
                 self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
-            ops.gemm(ws['onehot'], ws['dz'], self.dptab, M=ops.VOCAB, N=d, K=K2, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.VOCAB, ldb=d,
+            ops.gemm(ws['onehot'], ws['dz'], self.dptab, M=ops.TAB_TOTAL, N=d, K=K2, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.TAB_TOTAL, ldb=d,
                      ldc=d, c_f32=True, splitk=16, slabs=self._slabs, tile256=True)
         # projected-table gradient -> embedding tables and the shared merge Linear (exact f32)
-        E, W = self.wf['emb'], self.wf['lin.w']
-        for i in range(8):
-            o, n = ops.SEG_OFF[i], ops.SEG_SIZES[i]
-            ops.gemm(self.dptab, W, g['emb'], M=n, N=256, K=d, dtype=PB_F32, b_kc=False, lda=d, ldb=2048, ldc=256, alpha=16.0, c_f32=True,
-                     a_off=o * d, b_off=256 * i, c_off=o * 256)
-            ops.gemm(self.dptab, E, g['lin.w'], M=d, N=256, K=n, dtype=PB_F32, a_kc=False, b_kc=False, lda=d, ldb=256, ldc=2048, alpha=16.0,
-                     c_f32=True, a_off=o * d, b_off=o * 256, c_off=256 * i)
+        E, W, R = self.wf['emb'], self.wf['lin.w'], ops.TAB_ROWS
+        ops.gemm(self.dptab, W, g['emb'], M=R, N=256, K=d, dtype=PB_F32, b_kc=False, lda=d, ldb=2048, ldc=256, alpha=16.0, c_f32=True,
+                 nb1=8, sA=(R * d, 0), sB=(256, 0), sC=(R * 256, 0))
+        ops.gemm(self.dptab, E, g['lin.w'], M=d, N=256, K=R, dtype=PB_F32, a_kc=False, b_kc=False, lda=d, ldb=256, ldc=2048, alpha=16.0,
+                 c_f32=True, nb1=8, sA=(R * d, 0), sB=(R * 256, 0), sC=(256, 0))
         self._ready('emb', 'lin.w')
         if self.grad_hook is not None and self.Gcur is self.G32:
             self.grad_hook(self.n_matrix, self.n_total)          # vectors / position tables (accumulated region)
@@ -615,7 +611,7 @@ class Engine:
             for i in range(S):
                 tok16 = ops.ids_to_i16(cur)
                 ops.embed_ln_fwd(tok16.reshape(1, 8), self.ptab, wf['lin.b'], wf['dec.pos'][i:], wf['dec.lne.w'], wf['dec.lne.b'], x,
-                                 mr[0:1], mr[1:2], 1, LN_EPS, 0, 0, 0.0)
+                                 mr[0:1], mr[1:2], 1, LN_EPS, 0, 0, 0.0, padded=True)
                 h = x
                 for l in range(self.ND):
                     pf = 'dec.%d.' % l

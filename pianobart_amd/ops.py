@@ -14,6 +14,12 @@ for _n in SEG_SIZES:
     SEG_OFF.append(SEG_OFF[-1] + _n)
 VOCAB = SEG_OFF[-1]                                         # 1280
 _SEG9 = (ctypes.c_int32 * 9)(*SEG_OFF)
+# the projected Octuple table keeps every stream in a fixed 264-row slot (max vocabulary 262, padded to a multiple of 8) so the
+# per-stream table GEMMs are ONE batched launch with uniform strides
+TAB_ROWS = 264
+TAB_OFF = [TAB_ROWS * i for i in range(9)]
+TAB_TOTAL = TAB_OFF[8]                                      # 2112
+_TAB9 = (ctypes.c_int32 * 9)(*TAB_OFF)
 
 
 def seg_array(offsets):
@@ -88,22 +94,22 @@ def ids_to_i16(ids):
     return out
 
 
-def embed_ln_fwd(ids16, P, lin_bias, pos, ln_w, ln_b, y, mean, rstd, S, eps, seed, site, p_drop):
+def embed_ln_fwd(ids16, P, lin_bias, pos, ln_w, ln_b, y, mean, rstd, S, eps, seed, site, p_drop, padded=False):
     T, d = y.shape
-    LIB.call('pb_embed_ln_fwd', _p(ids16), _p(P), _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(ln_b), _p(y), _p(mean),
+    LIB.call('pb_embed_ln_fwd', _p(ids16), _p(P), _TAB9 if padded else _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(ln_b), _p(y), _p(mean),
              _p(rstd), T, S, d, dtype_code(y.dtype), eps, seed, site, p_drop, _stream())
 
 
 def embed_ln_bwd(dy, ids16, P, lin_bias, pos, ln_w, mean, rstd, dP, dpos, dbias, dgamma, dbeta, partials, S, seed, site, p_drop,
-                 dz_out=None):
+                 dz_out=None, padded=False):
     T, d = dy.shape
-    LIB.call('pb_embed_ln_bwd', _p(dy), _p(ids16), _p(P), _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(mean), _p(rstd),
+    LIB.call('pb_embed_ln_bwd', _p(dy), _p(ids16), _p(P), _TAB9 if padded else _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(mean), _p(rstd),
              _p(dP), _p(dpos), _p(dbias), _p(dgamma), _p(dbeta), _p(partials), _p(dz_out), T, S, d, dtype_code(dy.dtype), seed, site,
              p_drop, _stream())
 
 
-def onehot_build(ids16, out):
-    LIB.call('pb_onehot_build', _p(ids16), _SEG9, _p(out), ids16.numel() // 8, VOCAB, _stream())
+def onehot_build(ids16, out, padded=False):
+    LIB.call('pb_onehot_build', _p(ids16), _TAB9 if padded else _SEG9, _p(out), ids16.numel() // 8, TAB_TOTAL if padded else VOCAB, _stream())
 
 
 def batch_sum(x, out, B, Sd):
