@@ -301,5 +301,47 @@ if __name__ == '__main__':
     fns = dict(vocab=g_vocab, g1=g1_forward, g4=g4_grads, g6=g6_gen_mask, g7=g7_sampling, g8=g8_generate,
                g9=g9_state_dict, g10=g10_cfg2_spot)
     for w in which:
+        if w == 'g11':
+            continue
         print('==', w)
         fns[w]()
+
+
+def g11_pretrain_artifacts():
+    """G11: run the reference's own main.pretrain() (cfg 1: 2L/128d, S=128, B=2, 10 synthetic sequences, 1 epoch, CPU) in a
+    temp cwd and record the artefacts a drop-in harness must reproduce: log line, stdout line formats, checkpoint keys."""
+    import contextlib, io, re, tempfile
+    from tests.golden_util import synth_octuple_batch
+    import main as ref_main            # reference
+    tmp = tempfile.mkdtemp()
+    root = os.path.join(tmp, 'Data', 'output_pretrain', 'syn')
+    os.makedirs(root)
+    seqs = synth_octuple_batch(10, 128, seed=77)[5].numpy().astype(np.int64)
+    for name, part in (('train', seqs[:6]), ('test', seqs[6:8]), ('valid', seqs[8:])):
+        np.save(os.path.join(root, 'syn_%s_split.npy' % name), part)
+    cwd, argv = os.getcwd(), sys.argv
+    os.chdir(tmp)
+    sys.argv = ['main.py', '--dict_file', os.path.join(REF, 'Data', 'Octuple.pkl'), '--name', 't', '--datasets', 'syn', '--num_workers', '0',
+                '--batch_size', '2', '--max_seq_len', '128', '--hs', '128', '--layers', '2', '--ffn_dims', '512', '--heads', '4',
+                '--epochs', '1', '--cpu', '--cuda_devices', '0']
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            ref_main.pretrain()
+        log = open('result/pretrain/t/log').read()
+        ck = torch.load('result/pretrain/t/model.ckpt', weights_only=False)
+    finally:
+        os.chdir(cwd); sys.argv = argv
+    out = buf.getvalue()
+    rec = {'log': log, 'ckpt_keys': sorted(ck.keys()), 'n_state_dict': len(ck['state_dict']), 'state_dict_keys': list(ck['state_dict'].keys()),
+           'files': sorted(os.listdir(os.path.join(tmp, 'result', 'pretrain', 't'))),
+           'stdout_loss_line': [l for l in out.splitlines() if l.startswith('Loss: ')][0],
+           'stdout_acc_line': [l for l in out.splitlines() if l.startswith('Acc: ')][0],
+           'stdout_epoch_line': [l for l in out.splitlines() if l.startswith('epoch: ')][0]}
+    with open(os.path.join(GOLD, 'g11_pretrain_artifacts.json'), 'w') as f:
+        json.dump(rec, f, indent=1)
+    print('wrote g11_pretrain_artifacts.json'); print(rec['log'][:200]); print(rec['stdout_loss_line']); print(rec['ckpt_keys'], rec['files'])
+
+
+if __name__ == '__main__' and 'g11' in sys.argv[1:]:
+    g11_pretrain_artifacts()

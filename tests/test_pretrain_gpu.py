@@ -51,6 +51,15 @@ def test_main_pretrain_cfg1_end_to_end(tmp_path, capsys):
     cfg = O.BartConfig(max_position_embeddings=128, d_model=128, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512,
                        decoder_ffn_dim=512, encoder_attention_heads=4, decoder_attention_heads=4)
     O.PianoBart(cfg, E2W, W2E).load_state_dict(ck['state_dict'], strict=True)        # loads into the reference layout
+    # golden artefacts of the REFERENCE's own main.pretrain() run (oracle/make_goldens.py g11): same structure, number for number
+    import json
+    g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g11_pretrain_artifacts.json')))
+    shape = lambda line: re.sub(r'[-+]?\d+\.?\d*(?:e[-+]?\d+)?', '#', line)
+    assert sorted(ck.keys()) == g['ckpt_keys'] and list(ck['state_dict'].keys()) == g['state_dict_keys']
+    assert shape(log[0]) == shape(g['log'].splitlines()[0])
+    first = lambda pre: [l for l in out.splitlines() if l.startswith(pre)][0]
+    assert shape(first('Loss: ')) == shape(g['stdout_loss_line']) and shape(first('Acc: ')) == shape(g['stdout_acc_line'])
+    assert shape(first('epoch: ')) == shape(g['stdout_epoch_line'])
     losses = [float(re.search(r'train_loss=([\d.]+)', l).group(1)) for l in log[:3]]
     assert losses[-1] < losses[0]                                                       # it learns
 
