@@ -104,12 +104,15 @@ int pb_softmax_bwd(const float* dP, const void* P, void* dS, int64_t rows, int32
  * Replaces modeling_bart.py:115-140 (eager) / F.scaled_dot_product_attention and its autograd backward.
  * q,k,v,o,dout,dq,dk,dv: bf16, element (b,s,h,c) at ptr[b*sb + s*ss + h*hd + c]; lse, delta: (B,H,Sq) f32.
  * dout must have o's strides. Backward = delta + dKV + dQ kernels (no atomics, deterministic). */
-int pb_flash_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask,
+/* kmax (B) int32, optional: 1 + index of the last visible key of each batch row (pb_key_extent); key tiles at or beyond
+ * it are skipped (they are masked for every query). NULL = no skipping. Used by the head_dim-64 kernels. */
+int pb_key_extent(const float* key_mask, int32_t* kmax, int32_t B, int32_t Sk, void* stream);
+int pb_flash_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int32_t* kmax,
                  int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss,
                  int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss,
                  float scale, int32_t causal, void* stream);
 int pb_flash_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                 const float* key_mask, void* dq, void* dk, void* dv, float* delta,
+                 const float* key_mask, const int32_t* kmax, void* dq, void* dk, void* dv, float* delta,
                  int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss,
                  int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss,
                  int64_t dq_sb, int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss,

@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 struct Fa64Args {
     const bf16_t *q, *k, *v, *o, *dout;
     bf16_t *out, *dq, *dk, *dv;
-    float* lse; const float* delta; const float* key_mask;
+    float* lse; const float* delta; const float* key_mask; const int* kmax;
     int B, H, Sq, Sk;
     long q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
     float scale; int causal;
@@ -113,7 +113,9 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
         for (int i = 0; i < 4; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     const float c = p.scale * LOG2E;
-    const int kend = p.causal ? min(p.Sk, q0 + 128) : p.Sk;
+    // keys at and beyond kmax[b] (1 + last visible key of this batch row: the PAD tail) are masked for every query: skip their tiles
+    const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
+    const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
     const int nt = (kend + 63) / 64;
     auto stage = [&](int it, int sidx) {
         char* st = smem + sidx * STG;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
             reinterpret_cast<float*>(st + 16384)[t] = vis ? 0.f : -INFINITY;
         }
     };
-    stage(0, 0);
+    if (nt > 0) stage(0, 0);
     __syncthreads();
     for (int it = 0; it < nt; ++it) {
         const char* st = smem + (it & 1) * STG;
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         for (int i = 0; i < 4; ++i) { dk[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float c = p.scale * LOG2E;
     const int it0 = p.causal ? k0 / 64 : 0;
-    const int nt = (p.Sq + 63) / 64;
+    // a key block that lies entirely in the masked tail receives no gradient: skip its whole query loop (zeros are written)
+    const int nt = (p.kmax && k0 >= p.kmax[b]) ? 0 : (p.Sq + 63) / 64;
     auto stage = [&](int it, int sidx) {
         char* st = smem + sidx * STG;
         stage64(Q, p.q_ss, it * 64, p.Sq, st, wave, lane);
@@ -347,7 +350,8 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dq[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c = p.scale * LOG2E;
-    const int kend = p.causal ? min(p.Sk, q0 + 128) : p.Sk;
+    const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
+    const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
     const int nt = (kend + 63) / 64;
     auto stage = [&](int it, int sidx) {
         char* st = smem + sidx * STG;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
             reinterpret_cast<float*>(st + 16384)[t] = (key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f)) ? 1.f : 0.f;
         }
     };
-    stage(0, 0);
+    if (nt > 0) stage(0, 0);
     __syncthreads();
     for (int it = 0; it < nt; ++it) {
         const char* st = smem + (it & 1) * STG;
@@ -422,10 +426,10 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 }  // namespace
 
 // entry points used by pb_flash.hip's dispatch (same argument meaning as pb_flash_fwd / pb_flash_bwd, hd == 64)
-int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, int B, int H, int Sq, int Sk,
+int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int* kmax, int B, int H, int Sq, int Sk,
                    long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream) {
     Fa64Args a = {};
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal;
     hipLaunchKernelGGL(fa64_fwd_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), 2 * STG, stream, a);
@@ -434,12 +438,12 @@ int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* 
 }
 
 int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, const float* key_mask,
-                   void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
+                   const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
                    int causal, hipStream_t stream) {
     Fa64Args a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
-    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
     a.scale = scale; a.causal = causal;

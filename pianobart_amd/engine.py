@@ -62,6 +62,7 @@ class Engine:
         self._versions = None
         self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 128))
         self._slabs = None
+        self._kmax = {}
         self.grad_hook = None          # callable(lo, hi): flat gradient range is final (data-parallel bucketing)
 
     # ------------------------------------------------------------------ flat parameter layout
@@ -237,7 +238,8 @@ class Engine:
         ws = self._cur_ws
         if self.use_flash:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
-            ops.flash_fwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), save['lse'], key_mask, B, H, Sq, Sk, hd, hd ** -0.5, causal)
+            ops.flash_fwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), save['lse'], key_mask, B, H, Sq, Sk, hd, hd ** -0.5, causal,
+                          kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None)
             return
         scores, P = ws['scores'], save['P']
         (qt, qo, ql), (kt, ko, kl), (vt, vo, vl), (ot, oo, ol) = q, k, v, out
@@ -254,7 +256,7 @@ class Engine:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
             assert dout[1] == 0 and dout[2] == out[2]
             ops.flash_bwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
-                          ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal)
+                          ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal, kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None)
             return
         dP, dS, P = ws['scores'], ws['dS'], save['P']
         (qt, qo, ql), (kt, ko, kl), (vt, vo, vl) = q, k, v
@@ -292,6 +294,15 @@ class Engine:
         p = self.p_drop if train else 0.0
         self.refresh_shadow()
         self.build_ptab()
+        # per-batch-row key extents (1 + last visible key): the attention kernels skip the masked PAD tail tile-wise
+        self._kmax = {}
+        if self.use_flash and self.hd == 64:
+            for msk in (emask, dmask):
+                if msk is not None and id(msk) not in self._kmax:
+                    km = torch.empty(msk.shape[0], dtype=torch.int32, device=msk.device)
+                    ops.key_extent(msk, km)
+                    self._kmax[id(msk)] = km
+        self._kmax_keep = (emask, dmask)          # keep the mask objects alive while their ids are keys
         wf = self.wf
         x = ws['x_enc']
         if not reuse_encoder:

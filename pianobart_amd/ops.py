@@ -185,19 +185,19 @@ def shift_right(ids16, sos_row16, out, B, S):
     LIB.call('pb_shift_right', _p(ids16), _p(sos_row16), _p(out), B, S, _stream())
 
 
-def flash_fwd(q, k, v, o, lse, key_mask, B, H, Sq, Sk, hd, scale, causal, force_generic=False):
+def flash_fwd(q, k, v, o, lse, key_mask, B, H, Sq, Sk, hd, scale, causal, force_generic=False, kmax=None):
     """q,k,v,o: (tensor, element offset, row stride, batch stride) bf16."""
     (qt, qo, qs, qb), (kt, ko, ks, kb), (vt, vo, vs, vb), (ot, oo, os_, ob) = q, k, v, o
     pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 2 * off)
-    LIB.call('pb_flash_fwd', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(lse), _p(key_mask), B, H, Sq, Sk, hd,
+    LIB.call('pb_flash_fwd', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(lse), _p(key_mask), _p(kmax), B, H, Sq, Sk, hd,
              qb, qs, kb, ks, vb, vs, ob, os_, scale, int(causal) | (2 if force_generic else 0), _stream())
 
 
-def flash_bwd(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal, force_generic=False):
+def flash_bwd(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal, force_generic=False, kmax=None):
     (qt, qo, qs, qb), (kt, ko, ks, kb), (vt, vo, vs, vb), (ot, oo, os_, ob) = q, k, v, o
     (dqt, dqo, dqs, dqb), (dkt, dko, dks, dkb), (dvt, dvo, dvs, dvb) = dq, dk, dv
     pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 2 * off)
-    LIB.call('pb_flash_bwd', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), _p(key_mask), pp(dqt, dqo),
+    LIB.call('pb_flash_bwd', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), _p(key_mask), _p(kmax), pp(dqt, dqo),
              pp(dkt, dko), pp(dvt, dvo), _p(delta), B, H, Sq, Sk, hd, qb, qs, kb, ks, vb, vs, ob, os_, dqb, dqs, dkb, dks, dvb, dvs,
              scale, int(causal) | (2 if force_generic else 0), _stream())
 
@@ -209,3 +209,8 @@ def corrupt(ids16, out16, loss_mask, choice, choice_out, mask_percent, seed, pad
     mr = (ctypes.c_int16 * 8)(*[int(x) for x in mask_row])
     nt = (ctypes.c_int32 * 8)(*[int(x) for x in n_tokens])
     LIB.call('pb_corrupt', _p(ids16), _p(out16), _p(loss_mask), _p(choice), _p(choice_out), B, S, mask_percent, seed, pr, mr, nt, _stream())
+
+
+def key_extent(key_mask, kmax):
+    B, Sk = key_mask.shape
+    LIB.call('pb_key_extent', _p(key_mask), _p(kmax), B, Sk, _stream())
