@@ -101,7 +101,7 @@ def pmc_traffic(M, N, K):
     FETCH_SIZE x2 + WRITE_SIZE, collected offline: counters cannot be read from inside this process). None if the shape differs."""
     try:
         j = json.load(open(os.path.join(ROOT, 'profiles', 'r01_gemm_fc1_pmc.json')))
-        if 'M=%d N=%d K=%d' % (M, N, K) in j['kernel']:
+        if 'M=%d N=%d K=%d' % (M, N, K) in j['kernel']:     # same kernel, same shape, same tile as the live timing above
             return j['hbm_bytes_per_launch']
     except Exception:
         pass
