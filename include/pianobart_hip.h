@@ -130,8 +130,9 @@ int pb_ce_fwd_bwd(const float* logits, const int16_t* target, const float* loss_
 int64_t pb_ce_partials_floats(void);
 /* counts[i] = sum_t loss_mask[t,i]  (f32, 8) -- the M_i of pretrain.py:117 */
 int pb_mask_count(const float* loss_mask, float* counts, float* partials /* >= pb_ce_partials_floats() */, int64_t T, void* stream);
-/* coef[i] = w[i] / (sum_w * counts[i]) */
-int pb_loss_coef(const float* counts, const float* w /*device 8*/, float* coef, void* stream);
+/* coef[i] = scale * w[i] / (sum_w * counts[i])   (scale = 1 for pretrain.py:185-189; finetune_generation.py:241-250 uses
+ * w_i = weight_i * n_tok_i with the denominator sum(n_tok), i.e. scale = sum_w / sum(n_tok)) */
+int pb_loss_coef(const float* counts, const float* w /*device 8*/, float* coef, float scale, void* stream);
 
 /* ---- K10/K11: global grad norm, clip, HF-AdamW, bf16 shadow refresh --------------------------------
  * Replaces clip_grad_norm_(.,3.0) (pretrain.py:195) and transformers.AdamW.step (pretrain.py:76,196;

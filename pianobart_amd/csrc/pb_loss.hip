@@ -101,12 +101,12 @@ __global__ void mask_count_finalize_kernel(const float* __restrict__ part, int n
     }
 }
 
-__global__ void loss_coef_kernel(const float* __restrict__ counts, const float* __restrict__ w, float* __restrict__ coef) {
+__global__ void loss_coef_kernel(const float* __restrict__ counts, const float* __restrict__ w, float* __restrict__ coef, float scale) {
     const int i = threadIdx.x;
     if (i >= 8) return;
     float sw = 0.f;
     for (int k = 0; k < 8; ++k) sw += w[k];
-    coef[i] = w[i] / (sw * counts[i]);
+    coef[i] = scale * w[i] / (sw * counts[i]);
 }
 
 }  // namespace
@@ -142,8 +142,8 @@ extern "C" int pb_mask_count(const float* loss_mask, float* counts, float* parti
     return 0;
 }
 
-extern "C" int pb_loss_coef(const float* counts, const float* w, float* coef, void* stream_) {
-    hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, counts, w, coef);
+extern "C" int pb_loss_coef(const float* counts, const float* w, float* coef, float scale, void* stream_) {
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, counts, w, coef, scale);
     PB_LAUNCH_CHECK();
     return 0;
 }

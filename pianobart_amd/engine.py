@@ -550,7 +550,8 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ fused pre-train step (bench / Pretrainer)
-    def loss_and_grads(self, enc16, dec16, tgt16, loss_mask, emask, dmask, train=True, count_hook=None):
+    def loss_and_grads(self, enc16, dec16, tgt16, loss_mask, emask, dmask, train=True, count_hook=None, head_w=None, w_scale=1.0,
+                       argmax_out=None):
         """Forward + fused CE/argmax/acc + full backward. Returns the (24,) device tensor of sums
         {sum ce*m, sum m, sum correct*m} x 8 heads. `count_hook(counts)` may all-reduce the 8 mask counts (DP)."""
         B, S = enc16.shape[:2]
@@ -566,8 +567,8 @@ class Engine:
         ops.mask_count(lm, counts, self.partials)
         if count_hook is not None:
             count_hook(counts)
-        ops.loss_coef(counts, self.loss_w, coef)
-        ops.ce_fwd_bwd(logits, tgt16.reshape(T, 8), lm, sums, self.partials, coef, ws['dlogits'] if train else None, None)
+        ops.loss_coef(counts, self.loss_w if head_w is None else head_w, coef, w_scale)
+        ops.ce_fwd_bwd(logits, tgt16.reshape(T, 8), lm, sums, self.partials, coef, ws['dlogits'] if train else None, argmax_out)
         if train:
             self.zero_accumulated_grads()
             gy = self.heads_backward(ws['dlogits'], dec_h)

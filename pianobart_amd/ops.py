@@ -152,8 +152,8 @@ def mask_count(loss_mask, counts, partials):
     LIB.call('pb_mask_count', _p(loss_mask), _p(counts), _p(partials), loss_mask.numel() // 8, _stream())
 
 
-def loss_coef(counts, w, coef):
-    LIB.call('pb_loss_coef', _p(counts), _p(w), _p(coef), _stream())
+def loss_coef(counts, w, coef, scale=1.0):
+    LIB.call('pb_loss_coef', _p(counts), _p(w), _p(coef), scale, _stream())
 
 
 def grad_sqnorm(g, partials, out_sq):

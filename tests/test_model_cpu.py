@@ -84,3 +84,16 @@ def test_pretrain_cli_defaults_match_reference():
     assert (a.dict_file, a.name, a.num_workers, a.batch_size, a.mask_percent, a.max_seq_len) == ('./Data/Octuple.pkl', 'pianobart', 5, 16, 0.15, 1024)
     assert (a.hs, a.layers, a.ffn_dims, a.heads, a.epochs, a.lr, a.cpu) == (1024, 8, 2048, 8, 500, 2e-5, False)
     assert a.datasets == ['asap', 'EMOPIA', 'Pianist8', 'POP1K7', 'POP909']
+
+
+def test_int16_shards_roundtrip(tmp_path):
+    import numpy as np
+    from pianobart_amd.data import MidiDataset, convert_to_int16
+    from tests.golden_util import synth_octuple_batch
+    a = synth_octuple_batch(5, 32, seed=1)[5].numpy()
+    np.save(tmp_path / 'a.npy', a)
+    assert convert_to_int16(str(tmp_path / 'a.npy'), str(tmp_path / 'a16.npy')) == (5, 32, 8)
+    ds = MidiDataset(str(tmp_path / 'a16.npy'))
+    assert len(ds) == 5 and ds[3].dtype == torch.int16 and np.array_equal(ds[3].numpy(), a[3])
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
+    assert batch.shape == (2, 32, 8)

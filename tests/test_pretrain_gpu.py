@@ -93,3 +93,40 @@ def test_pretrainer_step_matches_oracle_on_its_own_batch():
     assert abs(mine - float(total)) / float(total) < 1e-4
     masked, pos = tr.gen_mask(batch[0], 2)
     assert masked.shape == (64, 8) and pos.shape == (64,) and int(pos.sum()) == round(64 * 0.15)
+
+
+def test_generation_trainer_step_matches_reference_formula():
+    """GenerationTrainer (finetune_generation.py:118-272): weighted teacher-forced loss, accuracy and argmax vs the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from oracle import pianobart_oracle as O
+    from pianobart_amd.finetune_generation import GenerationTrainer
+    from pianobart_amd.model import BartConfig, PianoBart
+    from tests.golden_util import randomize_params
+    kw = dict(max_position_embeddings=64, d_model=64, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=128,
+              decoder_ffn_dim=128, encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.0)
+    x = synth_octuple_batch(4, 64, seed=31)[5]
+    y = synth_octuple_batch(4, 64, seed=32)[5]
+    tr = GenerationTrainer(PianoBart(BartConfig(**kw), E2W, W2E, precision='fp32'), [(x[:2], y[:2]), (x[2:], y[2:])], None,
+                           [(x, y)], 1e-3, (4, 64, 8), False, [0])
+    randomize_params(tr.model, 13)
+    tr.engine.bind(tr.device)
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(**kw), E2W, W2E)).eval()
+    o.load_state_dict({k: v.cpu() for k, v in tr.model.state_dict().items()}, strict=True)
+    loss, accs, fb, fa, all_out = tr.test()
+    with torch.no_grad():
+        mask = (x[:, :, 0] != 256).float()
+        yh = o(x, x, mask, mask)
+    n_tok = [len(E2W[k]) for k in E2W]
+    wts = [1, 1, 0.3, 1.5, 1, 1, 0.3, 0.3]
+    ref_losses, ref_accs = [], []
+    for i in range(8):
+        ce = torch.nn.functional.cross_entropy(yh[i].permute(0, 2, 1), y[..., i], reduction='none')
+        ref_losses.append(float((ce * mask).sum() / mask.sum()) * wts[i])
+        ref_accs.append(float(((yh[i].argmax(-1) == y[..., i]).float() * mask).sum() / mask.sum()))
+    ref = sum(l * n for l, n in zip(ref_losses, n_tok)) / sum(n_tok)
+    assert abs(loss - ref) < 2e-4 * ref + 1e-4 and np.allclose(accs, ref_accs, atol=2e-4)
+    assert torch.equal(all_out.long(), torch.stack([t.argmax(-1) for t in yh], dim=-1))
+    l0 = tr.train()[0]
+    l1 = tr.train()[0]
+    assert l1 < l0
