@@ -159,6 +159,37 @@ int pb_corrupt(const int16_t* ids, int16_t* out, float* loss_mask, const int32_t
                int32_t S, float mask_percent, uint64_t seed, const int16_t* pad_row, const int16_t* mask_row,
                const int32_t* n_tokens, void* stream);
 
+/* ---- K13: batch-1 KV-cached decode (model.py:28-66) --------------------------------------------------------------
+ * pb_gemv: y[n] = act(sum_k W[n][k] x[k] + bias[n]), W (N,K) row-major in dtype, x (K) dtype, y dtype or f32, gelu = exact erf GELU.
+ * pb_attn_decode: one query (H*hd) against cached K/V rows (element (j,h,c) at ptr[j*ss + h*hd + c]), keys 0..Sk-1, optional
+ * key mask (Sk) float; a row with no visible key gives zeros.
+ * pb_decode_step: one decoder token through all layers: embed(tok16) + pos[i] -> ND x [self-attn with K/V appended at row i,
+ * cross-attn on the cached encoder K/V, FFN] -> logits (vocab) f32. All pointers device pointers, weights in dtype storage,
+ * biases / LayerNorm / tables f32. */
+int pb_gemv(const void* W, const void* x, const float* bias, void* y, int32_t N, int32_t K, int32_t dtype, int32_t y_f32, int32_t gelu, void* stream);
+int pb_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const float* key_mask, int32_t H, int32_t Sk,
+                   int32_t hd, int64_t k_ss, int64_t v_ss, float scale, int32_t dtype, void* stream);
+#define PB_DECODE_MAX_LAYERS 48
+typedef struct pb_decode_layer {
+    const void* wqkv; const float* bqkv; const void* wo; const float* bo; const float* ln1_w; const float* ln1_b;
+    const void* wq_c; const float* bq_c; const void* wo_c; const float* bo_c; const float* lnc_w; const float* lnc_b;
+    const void* w1; const float* b1; const void* w2; const float* b2; const float* ln2_w; const float* ln2_b;
+    void* kv_self;            /* (S, 2d) dtype: k | v rows of the tokens decoded so far */
+    const void* kv_cross;     /* (S_enc, 2d) dtype: encoder keys | values of this layer */
+} pb_decode_layer;
+typedef struct pb_decode_plan {
+    int32_t dtype, d, H, ffn, S, S_enc, n_layers, vocab;
+    int32_t tab_off[9]; int32_t _pad;
+    const int16_t* tok16;     /* (8) current decoder input token */
+    const float* ptab; const float* lin_b; const float* pos; const float* lne_w; const float* lne_b; const float* enc_mask;
+    void* x; void* y1; void* yc; void* y2; void* q; void* ctx; void* a; void* g;   /* scratch rows: d (g: ffn) elements of dtype */
+    float* stat;              /* 8 floats */
+    float* logits;            /* (vocab) f32 */
+    const void* head_w; const float* head_b;
+    pb_decode_layer layers[PB_DECODE_MAX_LAYERS];
+} pb_decode_plan;
+int pb_decode_step(const pb_decode_plan* plan, int32_t i, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,19 @@ class GemmDesc(ctypes.Structure):
                 ('splitk', ctypes.c_int32), ('_pad3', ctypes.c_int32), ('slabs', ctypes.c_void_p)]
 
 
+class DecodeLayer(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ('wqkv', 'bqkv', 'wo', 'bo', 'ln1_w', 'ln1_b', 'wq_c', 'bq_c', 'wo_c', 'bo_c', 'lnc_w', 'lnc_b',
+                                               'w1', 'b1', 'w2', 'b2', 'ln2_w', 'ln2_b', 'kv_self', 'kv_cross')]
+
+
+class DecodePlan(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('dtype', 'd', 'H', 'ffn', 'S', 'S_enc', 'n_layers', 'vocab')] + \
+               [('tab_off', ctypes.c_int32 * 9), ('_pad', ctypes.c_int32)] + \
+               [(n, ctypes.c_void_p) for n in ('tok16', 'ptab', 'lin_b', 'pos', 'lne_w', 'lne_b', 'enc_mask', 'x', 'y1', 'yc', 'y2', 'q', 'ctx', 'a', 'g',
+                                               'stat', 'logits', 'head_w', 'head_b')] + \
+               [('layers', DecodeLayer * 48)]
+
+
 _SCALARS = {'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64,
             'uint32_t': ctypes.c_uint32, 'float': ctypes.c_float, 'int': ctypes.c_int}
 

@@ -1,0 +1,237 @@
+// K13: batch-1 KV-cached decode (PianoBartLM.forward(generate=True), /root/reference/model.py:28-66).
+// The reference re-runs the full encoder + decoder over all S positions for every generated position; here one decoder
+// token goes through the layers against cached keys/values. At batch 1 every op is a weight-streaming GEMV (HBM-bound:
+// ~203 MB of bf16 decoder weights per token at cfg 2) or a tiny row op, so the kernels are:
+//   * gemv_kernel    y = act(W x + b): 2 output rows per workgroup, K split over its 4 waves, 16-byte weight loads straight
+//                    to VGPRs (no LDS: the operand is streamed once and not shared, cdna_hip_programming.md "GEMV" row);
+//   * attn_decode    one workgroup per head: q.k over the cached keys, block softmax, p.V -- no MFMA padding;
+//   * pb_decode_step a native host function that issues the 8*ND + 2 launches of one token (embed -> ND x [q|k|v (+LN2 of the
+//                    layer below), self-attn, out, q_c (+LN1), cross-attn, out_c, fc1+GELU (+LNc), fc2] -> heads (+LN2))
+//                    without Python between; the post-LNs ride in the prologue of the GEMV that consumes them.
+#include "pb_common.h"
+#include "pb_api_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------- GEMV: y[n] = act(sum_k W[n][k] x'[k] + b[n])
+// One workgroup = 4 waves = 2 output rows; the 4 waves split K (16-byte loads, each weight byte read once), partial sums meet in
+// LDS. N/2 workgroups keep every CU streaming even at N = 768. Rows n >= n_split go to y2 (the K|V cache row) instead of y.
+// With `res` set the input is the post-LN residual row x' = LayerNorm(res + x) * gamma + beta, recomputed by every workgroup
+// (d reads from L2, two block reductions) so that the BART post-LN needs no launch of its own; workgroup 0 also stores x'
+// to ln_out, where the next residual add finds it.
+__device__ __forceinline__ float block_sum4(float v, float* red, int lane, int wave) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, const T* __restrict__ x, const float* __restrict__ bias,
+                                                   TO* __restrict__ y, TO* __restrict__ y2, int n_split, int N, int K, int gelu,
+                                                   const T* __restrict__ res, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, T* __restrict__ ln_out, float eps) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red[4][2];
+    __shared__ float red1[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 2;
+    const bool two = n0 + 1 < N;
+    float mean = 0.f, rstd = 1.f;
+    if (res) {
+        float s = 0.f;
+        for (int c = threadIdx.x * EPV; c < K; c += 256 * EPV) {
+            T xv[EPV], rv[EPV];
+            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + c);
+            *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res + c);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) s += to_f(rv[j]) + to_f(xv[j]);
+        }
+        mean = block_sum4(s, red1, lane, wave) / (float)K;
+        float q = 0.f;
+        for (int c = threadIdx.x * EPV; c < K; c += 256 * EPV) {
+            T xv[EPV], rv[EPV];
+            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + c);
+            *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res + c);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) { const float z = to_f(rv[j]) + to_f(xv[j]) - mean; q = fmaf(z, z, q); }
+        }
+        rstd = rsqrtf(block_sum4(q, red1, lane, wave) / (float)K + eps);
+    }
+    float a0 = 0.f, a1 = 0.f;
+    const T* w0 = W + (long)n0 * K;
+    const T* w1 = W + (long)(two ? n0 + 1 : n0) * K;
+    for (int c = threadIdx.x * EPV; c < K; c += 256 * EPV) {
+        T xv[EPV], u0[EPV], u1[EPV];
+        *reinterpret_cast<uint4*>(u0) = *reinterpret_cast<const uint4*>(w0 + c);
+        *reinterpret_cast<uint4*>(u1) = *reinterpret_cast<const uint4*>(w1 + c);
+        *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + c);
+        if (res) {
+            T rv[EPV];
+            *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res + c);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j)      // rounded to T exactly like the stored LayerNorm output the unfused path would read back
+                xv[j] = from_f<T>((to_f(rv[j]) + to_f(xv[j]) - mean) * rstd * gamma[c + j] + beta[c + j]);
+            if (blockIdx.x == 0) *reinterpret_cast<uint4*>(ln_out + c) = *reinterpret_cast<const uint4*>(xv);
+        }
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { const float xf = to_f(xv[j]); a0 = fmaf(to_f(u0[j]), xf, a0); a1 = fmaf(to_f(u1[j]), xf, a1); }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; }
+    __syncthreads();
+    if (threadIdx.x < 2 && (threadIdx.x == 0 || two)) {
+        const int n = n0 + threadIdx.x;
+        float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] + (bias ? bias[n] : 0.f);
+        if (gelu) v = gelu_f(v);
+        if (n < n_split) y[n] = from_f<TO>(v); else y2[n - n_split] = from_f<TO>(v);
+    }
+}
+
+// ---------------------------------------------------------------- single-query attention over a K/V cache
+// one workgroup (1024 threads = 16 waves) per head; keys strided over threads; scores kept in LDS.
+template <typename T>
+__global__ __launch_bounds__(1024) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                          T* __restrict__ out, const float* __restrict__ key_mask, int Sk, int hd,
+                                                          long k_ss, long v_ss, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);            // [Sk] scores -> probabilities
+    float* red = sc + ((Sk + 3) & ~3);                     // [16] reductions, then [16][64] partial outputs
+    const int h = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const T* qh = q + h * hd;
+    float mx = -INFINITY;
+    for (int j = t; j < Sk; j += 1024) {
+        float s = -INFINITY;
+        if (!key_mask || key_mask[j] != 0.f) {
+            const T* kr = kc + (long)j * k_ss + h * hd;
+            float a = 0.f;
+            constexpr int EPV = 16 / sizeof(T);
+            for (int c = 0; c < hd; c += EPV) {                      // 16-byte chunks
+                T kv[EPV], qv[EPV];
+                *reinterpret_cast<uint4*>(kv) = *reinterpret_cast<const uint4*>(kr + c);
+                *reinterpret_cast<uint4*>(qv) = *reinterpret_cast<const uint4*>(qh + c);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) a = fmaf(to_f(kv[e]), to_f(qv[e]), a);
+            }
+            s = a * scale;
+        }
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w2 = 1; w2 < 16; ++w2) mx = fmaxf(mx, red[w2]);
+    __syncthreads();
+    float sum = 0.f;
+    if (mx != -INFINITY)
+        for (int j = t; j < Sk; j += 1024) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) sum += red[w2];
+    const float inv = (mx != -INFINITY && sum > 0.f) ? 1.0f / sum : 0.f;       // nothing visible -> zero row (oracle header)
+    __syncthreads();
+    // o[c] = sum_j p_j V[j][c]: wave w takes keys w, w+16, ...; lane owns column(s) c = lane (+64)
+    for (int c0 = 0; c0 < hd; c0 += 64) {
+        const int c = c0 + lane;
+        float acc = 0.f;
+        if (c < hd && inv > 0.f)
+            for (int j = wave; j < Sk; j += 16) acc = fmaf(sc[j], to_f(vc[(long)j * v_ss + h * hd + c]), acc);
+        red[wave * 64 + lane] = acc;
+        __syncthreads();
+        if (wave == 0 && c < hd) {
+            float o = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) o += red[w2 * 64 + lane];
+            out[h * hd + c] = from_f<T>(o * inv);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+struct LnIn { const void* res; const float* gamma; const float* beta; void* out; };
+
+static int gemv_launch(const void* W, const void* x, const float* bias, void* y, void* y2, int n_split, int N, int K, int dtype, int y_f32,
+                       int gelu, hipStream_t stream, LnIn ln = LnIn{nullptr, nullptr, nullptr, nullptr}) {
+    const int epv = dtype == PB_BF16 ? 8 : 4;
+    PB_REQUIRE(N > 0 && K > 0 && K % epv == 0, "pb_gemv: K=%d must be a multiple of %d", K, epv);
+    PB_REQUIRE(((uintptr_t)W % 16 == 0) && ((uintptr_t)x % 16 == 0), "pb_gemv: operands must be 16-byte aligned");
+    dim3 grid((N + 1) / 2), block(256);
+    const float eps = 1e-5f;
+    if (dtype == PB_BF16) {
+        if (y_f32) hipLaunchKernelGGL((gemv_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)W, (const bf16_t*)x, bias, (float*)y, (float*)y2, n_split, N, K, gelu,
+                                      (const bf16_t*)ln.res, ln.gamma, ln.beta, (bf16_t*)ln.out, eps);
+        else hipLaunchKernelGGL((gemv_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)W, (const bf16_t*)x, bias, (bf16_t*)y, (bf16_t*)y2, n_split, N, K, gelu,
+                                (const bf16_t*)ln.res, ln.gamma, ln.beta, (bf16_t*)ln.out, eps);
+    } else {
+        hipLaunchKernelGGL((gemv_kernel<float, float>), grid, block, 0, stream, (const float*)W, (const float*)x, bias, (float*)y, (float*)y2, n_split, N, K, gelu,
+                           (const float*)ln.res, ln.gamma, ln.beta, (float*)ln.out, eps);
+    }
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_gemv(const void* W, const void* x, const float* bias, void* y, int32_t N, int32_t K, int32_t dtype, int32_t y_f32,
+                       int32_t gelu, void* stream_) {
+    return gemv_launch(W, x, bias, y, nullptr, N, N, K, dtype, y_f32, gelu, (hipStream_t)stream_);
+}
+
+extern "C" int pb_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const float* key_mask, int32_t H,
+                              int32_t Sk, int32_t hd, int64_t k_ss, int64_t v_ss, float scale, int32_t dtype, void* stream_) {
+    const int epv = dtype == PB_BF16 ? 8 : 4;
+    PB_REQUIRE(H > 0 && Sk > 0 && Sk <= 8192 && hd % epv == 0 && k_ss % epv == 0, "pb_attn_decode: bad shape (Sk=%d hd=%d)", Sk, hd);
+    const size_t lds = (size_t)(((Sk + 3) & ~3) + 1024) * sizeof(float);
+    if (dtype == PB_BF16)
+        hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(H), dim3(1024), lds, (hipStream_t)stream_, (const bf16_t*)q, (const bf16_t*)k_cache,
+                           (const bf16_t*)v_cache, (bf16_t*)out, key_mask, Sk, hd, (long)k_ss, (long)v_ss, scale);
+    else
+        hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(H), dim3(1024), lds, (hipStream_t)stream_, (const float*)q, (const float*)k_cache,
+                           (const float*)v_cache, (float*)out, key_mask, Sk, hd, (long)k_ss, (long)v_ss, scale);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- one decoder token, natively sequenced
+extern "C" int pb_decode_step(const pb_decode_plan* p, int32_t i, void* stream) {
+    PB_REQUIRE(p && p->n_layers > 0 && p->n_layers <= PB_DECODE_MAX_LAYERS, "pb_decode_step: bad plan");
+    PB_REQUIRE(i >= 0 && i < p->S, "pb_decode_step: step %d outside 0..%d", i, p->S - 1);
+    const int d = p->d, H = p->H, hd = d / H, f = p->ffn, dt = p->dtype;
+    const size_t esz = dt == PB_BF16 ? 2 : 4;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int32_t* seg = p->tab_off;
+    char* x = (char*)p->x; char* alt = (char*)p->y2;
+    // token embedding + position i + LayerNorm (S = 1 with the position table advanced by i rows)
+    if (pb_embed_ln_fwd(p->tok16, p->ptab, seg, p->lin_b, p->pos + (size_t)i * d, p->lne_w, p->lne_b, x, p->stat, p->stat + 1, 1, 1, d, dt,
+                        1e-5f, 0, 0, 0.f, stream)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    LnIn ln{nullptr, nullptr, nullptr, nullptr};            // pending post-LN of the previous sub-layer, applied by the next GEMV
+    char* h = x;
+    for (int l = 0; l < p->n_layers; ++l) {
+        const pb_decode_layer& L = p->layers[l];
+        char* kvs = (char*)L.kv_self;
+        // q | k|v in one launch; k|v land in row i of the self-attention cache. Input: h (layer 0) or LN2 of the layer below.
+        if (gemv_launch(L.wqkv, ln.res ? (const void*)p->a : (const void*)h, L.bqkv, p->q, kvs + (size_t)i * 2 * d * esz, d, 3 * d, d, dt, 0, 0, st, ln)) return -1;
+        if (ln.res) h = alt;
+        if (pb_attn_decode(p->q, kvs, kvs + (size_t)d * esz, p->ctx, nullptr, H, i + 1, hd, 2 * d, 2 * d, scale, dt, stream)) return -1;
+        if (pb_gemv(L.wo, p->ctx, L.bo, p->a, d, d, dt, 0, 0, stream)) return -1;
+        // cross attention against the cached encoder K/V; the q projection applies LN1(h + a) -> y1
+        ln = LnIn{h, L.ln1_w, L.ln1_b, p->y1};
+        if (gemv_launch(L.wq_c, p->a, L.bq_c, p->q, nullptr, d, d, d, dt, 0, 0, st, ln)) return -1;
+        if (pb_attn_decode(p->q, L.kv_cross, (const char*)L.kv_cross + (size_t)d * esz, p->ctx, p->enc_mask, H, p->S_enc, hd, 2 * d, 2 * d, scale, dt, stream)) return -1;
+        if (pb_gemv(L.wo_c, p->ctx, L.bo_c, p->a, d, d, dt, 0, 0, stream)) return -1;
+        // FFN; fc1 applies LNc(y1 + a) -> yc
+        ln = LnIn{p->y1, L.lnc_w, L.lnc_b, p->yc};
+        if (gemv_launch(L.w1, p->a, L.b1, p->g, nullptr, f, f, d, dt, 0, 1, st, ln)) return -1;
+        if (pb_gemv(L.w2, p->g, L.b2, p->a, d, f, dt, 0, 0, stream)) return -1;
+        ln = LnIn{p->yc, L.ln2_w, L.ln2_b, alt};            // LN2(yc + a) -> next layer's h, applied by its q|k|v GEMV (or the heads)
+    }
+    return gemv_launch(p->head_w, p->a, p->head_b, p->logits, nullptr, p->vocab, p->vocab, d, dt, 1, 0, st, ln);
+}

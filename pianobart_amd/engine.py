@@ -597,6 +597,61 @@ class Engine:
         only depend on decoder inputs <= i (causal), so the tokens are identical (tests/test_model_gpu.py)."""
         if not use_cache:
             return self._generate_nocache(enc_ids, emask, sample_row)
+        import ctypes
+        from ._lib import DecodePlan
+        pb, d, X = self.pb, self.d, self.xdt
+        self.bind(enc_ids.device)
+        S, dev = enc_ids.shape[1], enc_ids.device
+        pad = torch.from_numpy(pb.pad_word_np).to(dev)
+        pad_cpu = torch.from_numpy(pb.pad_word_np)
+        result = pad.repeat(1, S, 1)
+        em = emask.to(torch.float32).contiguous() if emask is not None else None
+        enc16 = ops.ids_to_i16(enc_ids)
+        e = lambda *shape, dt=X: torch.empty(*shape, dtype=dt, device=dev)
+        with torch.no_grad():
+            _, enc_out = self.forward_hidden(enc16, None, em, None, False, 0)
+            wf, ff = self.wf, self.fd
+            kvc = [e(S, 2 * d) for _ in range(self.ND)]
+            for l in range(self.ND):
+                self._linear(enc_out, 'dec.%d.wkv_c' % l, 'dec.%d.bkv_c' % l, kvc[l], S, 2 * d, d)
+            kvs = [torch.zeros(S, 2 * d, dtype=X, device=dev) for _ in range(self.ND)]
+            rows = {n: e(1, d) for n in ('x', 'y1', 'yc', 'y2', 'q', 'ctx', 'a')}
+            rows['g'] = e(1, ff)
+            stat = torch.empty(8, dtype=torch.float32, device=dev)
+            logits = torch.empty(1, ops.VOCAB, dtype=torch.float32, device=dev)
+            tok16 = torch.tensor(pb.sos_word_np, dtype=torch.int16, device=dev)
+            plan = DecodePlan()
+            plan.dtype, plan.d, plan.H, plan.ffn, plan.S, plan.S_enc, plan.n_layers, plan.vocab = self.code, d, self.H, ff, S, S, self.ND, ops.VOCAB
+            for k in range(9):
+                plan.tab_off[k] = ops.TAB_OFF[k]
+            P = lambda t: t.data_ptr()
+            plan.tok16, plan.ptab, plan.lin_b, plan.pos = P(tok16), P(self.ptab), P(wf['lin.b']), P(wf['dec.pos'])
+            plan.lne_w, plan.lne_b, plan.enc_mask = P(wf['dec.lne.w']), P(wf['dec.lne.b']), (P(em) if em is not None else None)
+            for n, t in rows.items():
+                setattr(plan, n, P(t))
+            plan.stat, plan.logits, plan.head_w, plan.head_b = P(stat), P(logits), P(self.w['head.w']), P(wf['head.b'])
+            for l in range(self.ND):
+                pf, L = 'dec.%d.' % l, plan.layers[l]
+                L.wqkv, L.bqkv, L.wo, L.bo = P(self.w[pf + 'wqkv']), P(wf[pf + 'bqkv']), P(self.w[pf + 'wo']), P(wf[pf + 'bo'])
+                L.ln1_w, L.ln1_b = P(wf[pf + 'ln1.w']), P(wf[pf + 'ln1.b'])
+                L.wq_c, L.bq_c, L.wo_c, L.bo_c = P(self.w[pf + 'wq_c']), P(wf[pf + 'bq_c']), P(self.w[pf + 'wo_c']), P(wf[pf + 'bo_c'])
+                L.lnc_w, L.lnc_b = P(wf[pf + 'lnc.w']), P(wf[pf + 'lnc.b'])
+                L.w1, L.b1, L.w2, L.b2 = P(self.w[pf + 'w1']), P(wf[pf + 'b1']), P(self.w[pf + 'w2']), P(wf[pf + 'b2'])
+                L.ln2_w, L.ln2_b = P(wf[pf + 'ln2.w']), P(wf[pf + 'ln2.b'])
+                L.kv_self, L.kv_cross = P(kvs[l]), P(kvc[l])
+            pref = ctypes.byref(plan)
+            for i in range(S):
+                LIB.call('pb_decode_step', pref, i, ops._stream())
+                tok = sample_row(logits[0].cpu())
+                if (tok >= pad_cpu).any():
+                    break
+                result[:, i, :] = tok.to(dev)
+                tok16.copy_(tok.to(torch.int16))
+        return result
+
+    def _generate_pyloop(self, enc_ids, emask, sample_row):
+        """KV-cached decode sequenced from Python with the training kernels (M = 1 GEMMs, flash attention with one query):
+        kept as a cross-check of the native pb_decode_step path."""
         pb, d, H, X = self.pb, self.d, self.H, self.xdt
         self.bind(enc_ids.device)
         S, dev = enc_ids.shape[1], enc_ids.device
