@@ -4,7 +4,7 @@
 // ~203 MB of bf16 decoder weights per token at cfg 2) or a tiny row op, so the kernels are:
 //   * gemv_kernel    y = act(W x + b): 2 output rows per workgroup, K split over its 4 waves, 16-byte weight loads straight
 //                    to VGPRs (no LDS: the operand is streamed once and not shared, cdna_hip_programming.md "GEMV" row);
-//   * attn_decode    one workgroup per head: q.k over the cached keys, block softmax, p.V -- no MFMA padding;
+//   * attn_decode    single-query attention, one 16-wave workgroup per head, coalesced row-chunk loads of the cached K/V;
 //   * pb_decode_step a native host function that issues the 8*ND + 2 launches of one token (embed -> ND x [q|k|v (+LN2 of the
 //                    layer below), self-attn, out, q_c (+LN1), cross-attn, out_c, fc1+GELU (+LNc), fc2] -> heads (+LN2))
 //                    without Python between; the post-LNs ride in the prologue of the GEMV that consumes them.
@@ -90,68 +90,112 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, cons
 }
 
 // ---------------------------------------------------------------- single-query attention over a K/V cache
-// one workgroup (1024 threads = 16 waves) per head; keys strided over threads; scores kept in LDS.
-template <typename T>
-__global__ __launch_bounds__(1024) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
-                                                          T* __restrict__ out, const float* __restrict__ key_mask, int Sk, int hd,
-                                                          long k_ss, long v_ss, float scale) {
+// One workgroup of 16 waves per head. A key row (hd elements) is CPR = hd*sizeof(T)/16 consecutive 16-byte chunks, one per
+// lane, so one wave load covers 64/CPR whole rows as fully used 128/256-byte segments (a row-per-thread layout touched 64
+// cache lines per instruction and took 17 us at Sk = 1024). Splitting the keys of a head over several workgroups was
+// measured too: the agent-scope release/acquire its last-block merge needs costs an L2 write-back + invalidate per launch
+// on this multi-XCD part (20 us), more than the parallelism returns at these sizes.
+constexpr int AD_WAVES = 16;
+
+template <typename T, int CPR>
+__global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+                                                                    const T* __restrict__ vc, T* __restrict__ out,
+                                                                    const float* __restrict__ key_mask, int Sk, long k_ss, long v_ss,
+                                                                    float scale) {
+    constexpr int EPV = 16 / sizeof(T), HD = CPR * EPV, KPW = 64 / CPR;       // keys per wave-wide load
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem);            // [Sk] scores -> probabilities
-    float* red = sc + ((Sk + 3) & ~3);                     // [16] reductions, then [16][64] partial outputs
-    const int h = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const T* qh = q + h * hd;
-    float mx = -INFINITY;
-    for (int j = t; j < Sk; j += 1024) {
-        float s = -INFINITY;
-        if (!key_mask || key_mask[j] != 0.f) {
-            const T* kr = kc + (long)j * k_ss + h * hd;
-            float a = 0.f;
-            constexpr int EPV = 16 / sizeof(T);
-            for (int c = 0; c < hd; c += EPV) {                      // 16-byte chunks
-                T kv[EPV], qv[EPV];
-                *reinterpret_cast<uint4*>(kv) = *reinterpret_cast<const uint4*>(kr + c);
-                *reinterpret_cast<uint4*>(qv) = *reinterpret_cast<const uint4*>(qh + c);
+    float* red = sc + ((Sk + 3) & ~3);                     // [16] reductions, then [16][HD] partial outputs
+    const int h = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, sub = lane % CPR, grp = lane / CPR;
+    float qv[EPV];
+    {
+        T qq[EPV];
+        *reinterpret_cast<uint4*>(qq) = *reinterpret_cast<const uint4*>(q + h * HD + sub * EPV);
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) a = fmaf(to_f(kv[e]), to_f(qv[e]), a);
-            }
-            s = a * scale;
+        for (int e = 0; e < EPV; ++e) qv[e] = to_f(qq[e]) * scale;
+    }
+    float mx = -INFINITY;
+    constexpr int UR = 8, STEP = AD_WAVES * KPW;           // UR row-chunk loads in flight per lane before the first use
+    for (int jb = wave * KPW; jb < Sk; jb += UR * STEP) {
+        uint4 kraw[UR];
+#pragma unroll
+        for (int r = 0; r < UR; ++r) {
+            const int j = jb + r * STEP + grp;
+            if (j < Sk) kraw[r] = *reinterpret_cast<const uint4*>(kc + (long)j * k_ss + h * HD + sub * EPV);
         }
-        sc[j] = s;
-        mx = fmaxf(mx, s);
+#pragma unroll
+        for (int r = 0; r < UR; ++r) {
+            const int j = jb + r * STEP + grp;
+            float a = 0.f;
+            if (j < Sk) {
+                const T* kv = reinterpret_cast<const T*>(&kraw[r]);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) a = fmaf(to_f(kv[e]), qv[e], a);
+            }
+#pragma unroll
+            for (int o = 1; o < CPR; o <<= 1) a += __shfl_xor(a, o, 64);
+            if (j < Sk) {
+                const float sv = (!key_mask || key_mask[j] != 0.f) ? a : -INFINITY;
+                if (sub == 0) sc[j] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = red[0];
 #pragma unroll
-    for (int w2 = 1; w2 < 16; ++w2) mx = fmaxf(mx, red[w2]);
+    for (int w2 = 1; w2 < AD_WAVES; ++w2) mx = fmaxf(mx, red[w2]);
     __syncthreads();
     float sum = 0.f;
     if (mx != -INFINITY)
-        for (int j = t; j < Sk; j += 1024) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
+        for (int j = t; j < Sk; j += AD_WAVES * 64) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
     sum = 0.f;
 #pragma unroll
-    for (int w2 = 0; w2 < 16; ++w2) sum += red[w2];
+    for (int w2 = 0; w2 < AD_WAVES; ++w2) sum += red[w2];
     const float inv = (mx != -INFINITY && sum > 0.f) ? 1.0f / sum : 0.f;       // nothing visible -> zero row (oracle header)
     __syncthreads();
-    // o[c] = sum_j p_j V[j][c]: wave w takes keys w, w+16, ...; lane owns column(s) c = lane (+64)
-    for (int c0 = 0; c0 < hd; c0 += 64) {
-        const int c = c0 + lane;
-        float acc = 0.f;
-        if (c < hd && inv > 0.f)
-            for (int j = wave; j < Sk; j += 16) acc = fmaf(sc[j], to_f(vc[(long)j * v_ss + h * hd + c]), acc);
-        red[wave * 64 + lane] = acc;
-        __syncthreads();
-        if (wave == 0 && c < hd) {
-            float o = 0.f;
+    // o[c] = sum_j p_j V[j][c]: same row-chunk ownership; a lane keeps the EPV columns of its chunk
+    float acc[EPV];
 #pragma unroll
-            for (int w2 = 0; w2 < 16; ++w2) o += red[w2 * 64 + lane];
-            out[h * hd + c] = from_f<T>(o * inv);
+    for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
+    if (inv > 0.f)
+        for (int jb = wave * KPW; jb < Sk; jb += UR * STEP) {
+            uint4 vraw[UR];
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int j = jb + r * STEP + grp;
+                if (j < Sk) vraw[r] = *reinterpret_cast<const uint4*>(vc + (long)j * v_ss + h * HD + sub * EPV);
+            }
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int j = jb + r * STEP + grp;
+                if (j < Sk) {
+                    const T* vv = reinterpret_cast<const T*>(&vraw[r]);
+                    const float pj = sc[j];
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) acc[e] = fmaf(pj, to_f(vv[e]), acc[e]);
+                }
+            }
         }
-        __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPV; ++e)
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (grp == 0)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) red[wave * HD + sub * EPV + e] = acc[e];
+    __syncthreads();
+    if (t < HD) {
+        float o = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < AD_WAVES; ++w2) o += red[w2 * HD + t];
+        out[h * HD + t] = from_f<T>(o * inv);
     }
 }
 
@@ -184,17 +228,32 @@ extern "C" int pb_gemv(const void* W, const void* x, const float* bias, void* y,
     return gemv_launch(W, x, bias, y, nullptr, N, N, K, dtype, y_f32, gelu, (hipStream_t)stream_);
 }
 
-extern "C" int pb_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const float* key_mask, int32_t H,
-                              int32_t Sk, int32_t hd, int64_t k_ss, int64_t v_ss, float scale, int32_t dtype, void* stream_) {
+template <typename T, int CPR>
+static void attn_decode_launch(const void* q, const void* kc, const void* vc, void* out, const float* key_mask, int H, int Sk, long k_ss,
+                               long v_ss, float scale, hipStream_t stream) {
+    constexpr int HD = CPR * (16 / (int)sizeof(T));
+    const size_t lds = (size_t)(((Sk + 3) & ~3) + AD_WAVES * HD) * sizeof(float);
+    hipLaunchKernelGGL((attn_decode_kernel<T, CPR>), dim3(H), dim3(AD_WAVES * 64), lds, stream, (const T*)q, (const T*)kc, (const T*)vc, (T*)out,
+                       key_mask, Sk, k_ss, v_ss, scale);
+}
+
+extern "C" int pb_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const float* key_mask, int32_t H, int32_t Sk,
+                              int32_t hd, int64_t k_ss, int64_t v_ss, float scale, int32_t dtype, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PB_REQUIRE(H > 0 && Sk > 0 && Sk <= 8192 && (hd == 32 || hd == 64 || hd == 128),
+               "pb_attn_decode: H=%d Sk=%d hd=%d (head_dim must be 32, 64 or 128; Sk <= 8192)", H, Sk, hd);
     const int epv = dtype == PB_BF16 ? 8 : 4;
-    PB_REQUIRE(H > 0 && Sk > 0 && Sk <= 8192 && hd % epv == 0 && k_ss % epv == 0, "pb_attn_decode: bad shape (Sk=%d hd=%d)", Sk, hd);
-    const size_t lds = (size_t)(((Sk + 3) & ~3) + 1024) * sizeof(float);
-    if (dtype == PB_BF16)
-        hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(H), dim3(1024), lds, (hipStream_t)stream_, (const bf16_t*)q, (const bf16_t*)k_cache,
-                           (const bf16_t*)v_cache, (bf16_t*)out, key_mask, Sk, hd, (long)k_ss, (long)v_ss, scale);
-    else
-        hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(H), dim3(1024), lds, (hipStream_t)stream_, (const float*)q, (const float*)k_cache,
-                           (const float*)v_cache, (float*)out, key_mask, Sk, hd, (long)k_ss, (long)v_ss, scale);
+    PB_REQUIRE(k_ss % epv == 0 && v_ss % epv == 0 && ((uintptr_t)k_cache % 16 == 0) && ((uintptr_t)v_cache % 16 == 0) && ((uintptr_t)q % 16 == 0),
+               "pb_attn_decode: rows must be 16-byte aligned");
+    if (dtype == PB_BF16) {
+        if (hd == 32) attn_decode_launch<bf16_t, 4>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
+        else if (hd == 64) attn_decode_launch<bf16_t, 8>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
+        else attn_decode_launch<bf16_t, 16>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
+    } else {
+        if (hd == 32) attn_decode_launch<float, 8>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
+        else if (hd == 64) attn_decode_launch<float, 16>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
+        else attn_decode_launch<float, 32>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
+    }
     PB_LAUNCH_CHECK();
     return 0;
 }
