@@ -257,7 +257,7 @@ def main():
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world,
                        "flops_per_token_train": fpt},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
-                         "traffic": pmc_traffic(T, args.ffn, args.hs), "kernel": "gemm2_kernel<%s,NT> fc1 shape M=%d N=%d K=%d" % (args.precision, T, args.ffn, args.hs),
+                         "traffic": pmc_traffic(T, args.ffn, args.hs), "kernel": "gemm3_kernel<%s,NT> (256x256 ping-pong) fc1 shape M=%d N=%d K=%d" % (args.precision, T, args.ffn, args.hs),
                          "avg_launch_ms": gemm_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

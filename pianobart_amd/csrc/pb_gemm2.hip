@@ -11,7 +11,8 @@
 //     ds_read_b64_tr_b16 (hardware transpose), two reads per 8-k fragment, bank-conflict free;
 //   * split-K over blockIdx.z into f32 slabs (wgrad has K = B*S tokens but only 36..144 output tiles),
 //     summed by pb_reduce_slabs: deterministic, no atomics;
-//   * the epilogue goes through LDS so that global stores are 8/16-byte row segments.
+//   * the epilogue stays in registers: operand-swapped MFMAs + v_permlane16_swap give every lane 8 consecutive
+//     output columns, stored as 16-byte row segments (epilogue_regs).
 // Tile 128x128x64, 256 threads (2x2 waves of 64x64 = 4x4 MFMA 16x16x32), 2 LDS stages of 32 KiB;
 // per K tile: issue next tile's 8 DMA pieces -> 32 MFMAs on the current tile -> vmcnt(0) + barrier.
 // Requirements (else pb_gemm falls back to pb_gemm.hip): K % 64 == 0 per split, 16-byte aligned rows,
@@ -99,25 +100,24 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int rbase /*multiple of 
     }
 }
 
-// WM x WN waves, each TM x TN MFMA tiles of 16x16: block tile BM = 16*WM*TM by BN = 16*WN*TN.
-// Measured (tools/gemm_probe.py, MI355X): the 128x128 main loop is bound by the L2 -> LDS load path (~60 GB/s per CU,
-// 64 FLOP per loaded byte -> ~1 PF ceiling), the 256x256 one reaches 1.1-1.2 PF; the output write (HBM write rate,
-// ~3.1 TB/s) is NOT overlapped with the main loop. Tried and measured (tools/gemm_probe.py history): persistent tiles with
-// stores left in flight, register epilogue with swapped MFMA operands, non-temporal stores, and the store traffic spread
-// over the K loop of the same launch (hides only ~1/3 of it) -- none pays; the 8-phase counted-vmcnt pipeline is next.
-template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NW = WM * WN, BM = 16 * WM * TM, BN = 16 * WN * TN;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+__device__ __forceinline__ void store8(bf16_t* p, f32x4 a, f32x4 b) {
+    bf16x8 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    *reinterpret_cast<bf16x8*>(p) = r;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, f32x4& a, f32x4& b) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+    a = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    b = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+}
+
+// 1-D grid over (split, tile) -> (m0, n0, split).
+template <int BM, int BN>
+__device__ __forceinline__ void block_tile(const Gemm2Args& p, int& m0, int& n0, int& zs) {
     const int ntiles = p.tiles_m * p.tiles_n;
     // 1-D grid over (split, tile). XCD x (= id % 8) takes a CONTIGUOUS chunk of the (split-major, tile-minor) list, so with
     // split-K the workgroups of one XCD work on (nearly) one K slice: its A/B rows are fetched into that L2 once and
     // shared by all its tiles (wgrad measured ~2x its algorithmic bytes from beyond L2 with the tile-only remap).
-    int bid, zs;
+    int bid;
     {
         const int total = ntiles * p.nsplit, L = blockIdx.x;
         const int q = total >> 3, r = total & 7, x = L & 7, idx = L >> 3;
@@ -132,7 +132,90 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
     const int gsz = GM * p.tiles_n, grp = bid / gsz, first_m = grp * GM;
     const int gm = min(GM, p.tiles_m - first_m), rem = bid - grp * gsz;
     const int tm = first_m + rem % gm, tn = rem / gm;
-    const int m0 = tm * BM, n0 = tn * BN;
+    m0 = tm * BM; n0 = tn * BN;
+}
+
+// Register epilogue. Every kernel here issues its MFMAs operand-swapped (mfma(b, a)), so the lane (lr = lane & 15,
+// lg = lane >> 4) holds C[row i*16 + lr][columns j*16 + lg*4 .. +3]: four CONSECUTIVE columns. One v_permlane16_swap per
+// dword then hands the two column tiles (j, j+1) of a pair to the even / odd 16-lane rows: every lane owns 8 consecutive
+// columns of one output row, i.e. one 16-byte bf16 store (two for f32), 64 (128) contiguous bytes per row and
+// instruction, with bias / GELU / GELU-grad / accumulate applied in f32 in between. No LDS and no barrier: the f32 LDS
+// panel this replaces cost about a third of the store tail of a 256 x 256 tile, and its 8-byte stores another 6 %.
+template <int TM>
+__device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[TM][4], int mw /*wave's first row*/, int nw /*first column*/, long coff, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    const bool accum = p.flags & PB_GEMM_ACCUM, c32 = p.flags & PB_GEMM_C_F32;
+    const bool do_gelu = p.flags & PB_GEMM_GELU, mul_gg = p.flags & PB_GEMM_MUL_GELU_GRAD;
+    float* C32 = reinterpret_cast<float*>(p.C) + coff;
+    bf16_t* CT = reinterpret_cast<bf16_t*>(p.C) + coff;
+    // even 16-lane rows end up with tile j of the pair, columns lg*4 .. +7; odd rows with tile j+1, columns (lg-1)*4 .. +7
+    const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
+    f32x4 bv[2][2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        const int c = nw + jp * 32 + cb;
+        const bool has = p.bias && c < p.N;
+        bv[jp][0] = has ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[jp][1] = has ? *reinterpret_cast<const f32x4*>(p.bias + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = mw + i * 16 + lr;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xa = acc[i][2 * jp][r], xb = acc[i][2 * jp + 1][r];     // (a bit_cast applied directly to a vector element reads element 0)
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+                v0[r] = __uint_as_float(sw[0]);
+                v1[r] = __uint_as_float(sw[1]);
+            }
+            const int col = nw + jp * 32 + cb;
+            if (row < p.M && col < p.N) {
+                v0 = v0 * p.alpha + bv[jp][0];
+                v1 = v1 * p.alpha + bv[jp][1];
+                if (do_gelu) {
+                    store8(p.aux_out + (long)row * p.ldaux + col, v0, v1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = gelu_fast(v0[e]); v1[e] = gelu_fast(v1[e]); }
+                }
+                if (mul_gg) {
+                    f32x4 u0, u1;
+                    load8(p.aux_in + (long)row * p.ldaux + col, u0, u1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] *= gelu_grad_fast(u0[e]); v1[e] *= gelu_grad_fast(u1[e]); }
+                }
+                const long ci = (long)row * p.ldc + col;
+                if (c32) {
+                    if (accum) { v0 += *reinterpret_cast<const f32x4*>(C32 + ci); v1 += *reinterpret_cast<const f32x4*>(C32 + ci + 4); }
+                    *reinterpret_cast<f32x4*>(C32 + ci) = v0;
+                    *reinterpret_cast<f32x4*>(C32 + ci + 4) = v1;
+                } else {
+                    if (accum) { f32x4 c0, c1; load8(CT + ci, c0, c1); v0 += c0; v1 += c1; }
+                    store8(CT + ci, v0, v1);
+                }
+            }
+        }
+    }
+}
+
+// WM x WN waves, each TM x TN MFMA tiles of 16x16: block tile BM = 16*WM*TM by BN = 16*WN*TN.
+// Measured (tools/gemm_probe.py, MI355X): the 128x128 main loop is bound by the L2 -> LDS load path (~60 GB/s per CU,
+// 64 FLOP per loaded byte -> ~1 PF ceiling), the 256x256 one reaches 1.1-1.2 PF; the output write (HBM write rate,
+// ~3.1 TB/s) is NOT overlapped with the main loop. Tried and measured (tools/gemm_probe.py history): persistent tiles with
+// stores left in flight, register epilogue with swapped MFMA operands, non-temporal stores, and the store traffic spread
+// over the K loop of the same launch (hides only ~1/3 of it) -- none pays; the 8-phase counted-vmcnt pipeline is next.
+template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WM * WN, BM = 16 * WM * TM, BN = 16 * WN * TN;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int m0, n0, zs;
+    block_tile<BM, BN>(p, m0, n0, zs);
     const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
@@ -169,64 +252,142 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // swapped: see epilogue_regs
         }
         __syncthreads();          // hipcc adds s_waitcnt vmcnt(0) here: next tile has landed, current one is free
     }
     if (p.flags & 128) return;                                      // bit 7: profiling build without the epilogue
 
-    // ---- epilogue through LDS: per wave a 32 x (16 TN) f32 panel, TM/2 passes ----
-    constexpr int PW = 16 * TN + 4;                                 // panel row stride (floats)
-    constexpr int LPRW = (16 * TN) / 4;                             // lanes per panel row in the read-back phase
-    constexpr int RPI = 64 / LPRW;                                  // rows per read-back iteration
-    const int lr = lane & 15, lg = lane >> 4;
-    const bool accum = p.flags & PB_GEMM_ACCUM, c32 = p.flags & PB_GEMM_C_F32;
-    const bool do_gelu = p.flags & PB_GEMM_GELU, mul_gg = p.flags & PB_GEMM_MUL_GELU_GRAD;
-    float* panel = reinterpret_cast<float*>(smem) + wave * (32 * PW);
-    float* C32 = reinterpret_cast<float*>(p.C) + coff;
-    bf16_t* CT = reinterpret_cast<bf16_t*>(p.C) + coff;
-    const int pcol = (lane % LPRW) * 4;
-    const int colb = n0 + wn * (16 * TN) + pcol;                   // this lane's 4 output columns in the read-back phase
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && colb < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + colb);   // N % 4 == 0 checked on the host
+    static_assert(TN == 4, "epilogue_regs pairs the 4 column tiles of a wave");
+    epilogue_regs<TM>(p, acc, m0 + wm * (16 * TM), n0 + wn * (16 * TN), coff, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 per wave), ping-pong schedule with the DMA prefetch in flight across
+// barriers (cdna_hip_programming.md 5, "What does break it"): one workgroup per CU, 128 KiB of LDS = 2 K-tile slots x
+// {A0, A1, B0, B1} half-tiles of 16 KiB. Half h of an operand holds, for every wave row/column group, the h-th half of
+// that group's rows (A: 64 of its 128 rows, B: 32 of its 64 columns), so a K-tile is consumed in 4 phases of one C
+// quadrant each -- (A0,B0) (A0,B1) (A1,B1) (A1,B0): 16 MFMAs on K = 64 after 12 / 4 / 8 / 4 fragment reads -- and each
+// phase re-stages one half-tile (2 DMA instructions per wave) that went dead two phases earlier:
+//     phase 4t+0: A1(t+1)   4t+1: B0(t+1)   4t+2: A0(t+2)   4t+3: B1(t+2), then s_waitcnt vmcnt(4)
+// (everything but the two newest half-tiles has landed: K-tile t+1 is complete one phase before its first read). The two
+// wave rows run one barrier interval apart (the wr = 1 waves take one extra s_barrier up front, the wr = 0 waves one at
+// the end), and every phase is  reads + DMA | s_barrier | 16 MFMA | s_barrier : while one wave of a SIMD issues its
+// MFMAs the other one issues its LDS reads and DMA. Barriers are raw s_barrier (a __syncthreads() would drain vmcnt).
+// RAW: DMA data is read one phase after the counted wait (wait -> barrier -> barrier of the staggered group -> read);
+// WAR: a half-tile is re-staged two phases after its last read, whose lgkmcnt(0) sits one interval before.
+template <bool KC, int GS>
+__device__ __forceinline__ void stage_half(const bf16_t* __restrict__ base, long ld, int r0, int k0, int R, char* lds, int h, int wave, int lane) {
 #pragma unroll
-    for (int pass = 0; pass < TM / 2; ++pass) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) panel[(ii * 16 + lg * 4 + r) * PW + j * 16 + lr] = acc[pass * 2 + ii][j][r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the wave's own panel writes are done
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int prow = it * RPI + lane / LPRW;
-            const int row = m0 + wm * (16 * TM) + pass * 32 + prow;
-            if (row < p.M && colb < p.N) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(panel + prow * PW + pcol) * p.alpha + bv;
-                if (do_gelu) {
-                    if (p.flags & 1024) store4_nt(p.aux_out + (long)row * p.ldaux + colb, v); else store4(p.aux_out + (long)row * p.ldaux + colb, v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-                }
-                if (mul_gg) {
-                    const f32x4 u = load4(p.aux_in + (long)row * p.ldaux + colb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u[e]);
-                }
-                const long ci = (long)row * p.ldc + colb;
-                if (c32) {
-                    if (accum) v += load4(C32 + ci);
-                    store4(C32 + ci, v);
-                } else {
-                    if (accum) v += load4(CT + ci);
-                    if (p.flags & 1024) store4_nt(CT + ci, v); else store4(CT + ci, v);
-                }
-            }
+    for (int n = 0; n < 2; ++n) {
+        const int inst = wave * 2 + n;
+        if constexpr (KC) {
+            const int hr = inst * 8 + (lane >> 3);                                  // row of the half-tile image [128][128 B]
+            const int chunk = (lane & 7) ^ kswz(hr);
+            const int gr = min(r0 + (hr / GS) * (2 * GS) + h * GS + (hr % GS), R - 1);
+            glds16(base + (long)gr * ld + k0 + chunk * 8, lds + inst * 1024);
+        } else {
+            const int krow = inst * 4 + (lane >> 4);                                // image [64 k][128 columns = 256 B]
+            const int chunk = (lane & 15) ^ rswz(krow);
+            const int hc = chunk * 8;
+            const int gc = min(r0 + (hc / GS) * (2 * GS) + h * GS + (hc % GS), R - 8);
+            glds16(base + (long)(k0 + krow) * ld + gc, lds + inst * 1024);
         }
-        __builtin_amdgcn_wave_barrier();
     }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HALF = 16384, SLOT = 4 * HALF;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int m0, n0, zs;
+    block_tile<256, 256>(p, m0, n0, zs);
+    const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
+    const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
+    const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
+    const long coff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
+    const int kbeg = zs * p.Kc, kend = min(p.K, kbeg + p.Kc);
+    const int nk = max(0, kend - kbeg) / BK;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[4][2], b[2][2];
+
+#define G3_ISSUE_A(T, H) stage_half<A_KC, 64>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
+#define G3_ISSUE_B(T, H) stage_half<B_KC, 32>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
+#define G3_READ_A(SL, H)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                 \
+        a[i][ks] = frag<A_KC, 128>(smem + (SL) * SLOT + (H) * HALF, wr * 64 + i * 16, ks, lane)
+#define G3_READ_B(SL, H)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                 \
+        b[j][ks] = frag<B_KC, 128>(smem + (SL) * SLOT + (2 + (H)) * HALF, wc * 32 + j * 16, ks, lane)
+#define G3_MMA(MH, NH)                                                                                            \
+    do {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+
+    if (nk > 0) {
+        G3_ISSUE_A(0, 0); G3_ISSUE_B(0, 0); G3_ISSUE_B(0, 1); G3_ISSUE_A(0, 1);
+        if (nk > 1) {
+            G3_ISSUE_A(1, 0); G3_ISSUE_B(1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int sl = kt & 1;
+        // phase 0: quadrant (0,0)
+        G3_READ_B(sl, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        G3_READ_A(sl, 0);
+        if (kt + 1 < nk) G3_ISSUE_A(kt + 1, 1);
+        G3_MMA(0, 0);
+        // phase 1: quadrant (0,1)
+        G3_READ_B(sl, 1);
+        if (kt + 1 < nk) G3_ISSUE_B(kt + 1, 0);
+        G3_MMA(0, 1);
+        // phase 2: quadrant (1,1)
+        G3_READ_A(sl, 1);
+        if (kt + 2 < nk) G3_ISSUE_A(kt + 2, 0);
+        G3_MMA(1, 1);
+        // phase 3: quadrant (1,0)
+        G3_READ_B(sl, 0);
+        if (kt + 2 < nk) {
+            G3_ISSUE_B(kt + 2, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        G3_MMA(1, 0);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef G3_ISSUE_A
+#undef G3_ISSUE_B
+#undef G3_READ_A
+#undef G3_READ_B
+#undef G3_MMA
+    if (p.flags & 128) return;                                      // bit 7: profiling build without the epilogue
+    epilogue_regs<8>(p, acc, m0 + wr * 128, n0 + wc * 64, coff, lane);
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, long n, float* __restrict__ out) {
@@ -254,10 +415,11 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if (!a_kc && d->M < 8) return 1;
     if (!b_kc && d->N < 8) return 1;
     const bool c32 = d->flags & PB_GEMM_C_F32;
-    if ((uintptr_t)d->C % 16 != 0 || d->ldc % 4 != 0 || d->sC1 % 4 != 0 || d->sC2 % 4 != 0) return 1;
-    if ((d->aux_in || d->aux_out) && (d->ldaux % 4 != 0)) return 1;
+    const int cal = c32 ? 4 : 8;                                    // 16-byte output row segments
+    if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
+    if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 256 | 1024)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 256 | 2048 | 4096)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue");
         return -2;
     }
@@ -273,10 +435,14 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2; a.sC1 = d->sC1; a.sC2 = d->sC2;
     a.sCz = (long)d->M * d->N;
     a.alpha = d->alpha; a.flags = d->flags;
-    // tile choice: 128x128 (4 waves, 2 blocks/CU) by default; 256x256 (8 waves, 128x64 per wave, half the L2->LDS
-    // traffic per FLOP) when asked for (PB_GEMM_TILE256: the split-K wgrad GEMMs, whose output phase is negligible)
-    // 256x256 when asked for, and by default for wide outputs (N >= 1536: fc1, du, qkv): measured 842 vs 731 TF at the fc1 shape
-    const bool big = !(d->flags & PB_GEMM_TILE128) && d->M >= 256 && d->N >= 256 && ((d->flags & PB_GEMM_TILE256) || (d->N >= 1536 && d->M >= 2048 && nsplit == 1));
+    // Tile / kernel choice, from same-process A/B runs of every cfg-2 shape (tools/gemm_ab.py, T = 32768 tokens):
+    //   NT (forward):  256x256 ping-pong kernel whenever the output is at least 512 wide (fc1 910 vs 750 TF, fc2 1110 vs 1050);
+    //   NN (dgrad):    256x256 one-barrier kernel for wide outputs (N >= 1536: 910 vs 780 TF), 128x128 for N = 768, whose
+    //                  384 tiles of 256x256 would fill 1.5 rounds of 256 CUs (128x128: 977 vs 870 TF);
+    //   TN (wgrad):    the caller asks (PB_GEMM_TILE256) together with its split-K factor; one-barrier kernel (845 vs 765 TF).
+    const bool nt = a_kc && b_kc;
+    const bool big = !(d->flags & PB_GEMM_TILE128) && d->M >= 256 && d->N >= 256 &&
+                     ((d->flags & PB_GEMM_TILE256) || (nsplit == 1 && d->M >= 2048 && (d->N >= 1536 || (nt && d->N >= 512))));
     const bool tall = !big && (d->flags & 512) && d->M >= 1024;   // measured: no gain over 128x128 (tools/gemm_bench.py), kept for experiments      // 256x128: 8 waves of 64x64, 25% less L2->LDS traffic per FLOP
     const int BMs = (big || tall) ? 256 : 128, BNs = big ? 256 : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
@@ -294,6 +460,18 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 4, 2, 4, 4);
         else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 4, 2, 4, 4);
         else PB_G2_LAUNCH(false, false, 4, 2, 4, 4);
+    } else if (big && !(d->flags & 2048) && (nt || (d->flags & 4096))) {   // bit 11 / 12: force the one-barrier / ping-pong kernel (A/B runs)
+#define PB_G3_LAUNCH(AK, BK_)                                                                                              \
+    do {                                                                                                                 \
+        auto kfn = gemm3_kernel<AK, BK_>;                                                                                  \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);      \
+        hipLaunchKernelGGL(kfn, grid, dim3(512), 131072, stream, a);                                                      \
+    } while (0)
+        if (a_kc && b_kc) PB_G3_LAUNCH(true, true);
+        else if (a_kc && !b_kc) PB_G3_LAUNCH(true, false);
+        else if (!a_kc && b_kc) PB_G3_LAUNCH(false, true);
+        else PB_G3_LAUNCH(false, false);
+#undef PB_G3_LAUNCH
     } else if (big) {
         if (a_kc && b_kc) PB_G2_LAUNCH(true, true, 2, 4, 8, 4);
         else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 2, 4, 8, 4);

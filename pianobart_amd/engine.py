@@ -353,7 +353,7 @@ class Engine:
         """G[gname] (M,N) = dy(T,M)^T @ x(T,N)  (TN GEMM into the f32 gradient buffer)."""
         nsplit, slabs, big = 1, None, False
         if self.code == PB_BF16 and T % 64 == 0:
-            big = M >= 256 and N >= 256                       # 256x256 tiles: one block per CU, ~256 blocks in flight
+            big = M >= 256 and N >= 256 and M * N > 768 * 768     # 256x256 tiles, one block per CU (768x768: 128x128 tiles measured 712 vs 636 TF)
             tl = 256 if big else 128
             tiles = ((M + tl - 1) // tl) * ((N + tl - 1) // tl)
             nsplit = max(1, min(32, T // 64, round((256 if big else 512) / tiles)))
