@@ -296,6 +296,40 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ base, long
     }
 }
 
+// Transposed fragment reads of the ping-pong kernel go through inline asm: for the ds_read_tr builtin hipcc (ROCm 7.2) cannot
+// tell the read apart from the LDS-DMA writes in flight and puts s_waitcnt vmcnt(0) in front of the first one of every
+// K-tile, which drains the prefetch this kernel exists for (+40 % wave cycles on the NN / TN layouts, found in the .s).
+// Form (ii) of cdna_hip_programming.md 5.7: "=v" loads, then ONE wait statement naming every destination "+v" before the
+// first consumer; the per-tile lane offset is computed once, (ks, +4 rows) are immediate offsets.
+template <int OFF>
+__device__ __forceinline__ void ds_tr(s16x4& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+__device__ __forceinline__ void ds_tr_frags(s16x4 (&d)[2][2], unsigned addr) {       // [ks][lo/hi] of one 16-row tile, image rows of 256 B
+    ds_tr<0>(d[0][0], addr); ds_tr<1024>(d[0][1], addr); ds_tr<8192>(d[1][0], addr); ds_tr<9216>(d[1][1], addr);
+}
+__device__ __forceinline__ unsigned tr_lane_off(int rbase, int lane) {                // frag<false, 128> minus (ks, +4 rows)
+    const int lr = lane & 15, g = lane >> 4, q = lr >> 2, pp = lr & 3;
+    const int chunk = (rbase >> 3) + (pp >> 1);
+    return (unsigned)((g * 8 + q) * 256 + ((chunk ^ rswz(g * 8 + q)) << 4) + ((pp & 1) << 3));
+}
+__device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+#define TRW4(X) "+v"(X[0][0]), "+v"(X[0][1]), "+v"(X[1][0]), "+v"(X[1][1])
+__device__ __forceinline__ void tr_wait_a(s16x4 (&ta)[4][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TRW4(ta[0]), TRW4(ta[1]), TRW4(ta[2]), TRW4(ta[3]));
+}
+__device__ __forceinline__ void tr_wait_b(s16x4 (&tb)[2][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TRW4(tb[0]), TRW4(tb[1]));
+}
+__device__ __forceinline__ void tr_wait_ab(s16x4 (&ta)[4][2][2], s16x4 (&tb)[2][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TRW4(ta[0]), TRW4(ta[1]), TRW4(ta[2]), TRW4(ta[3]), TRW4(tb[0]), TRW4(tb[1]));
+}
+#undef TRW4
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -318,20 +352,49 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 a[4][2], b[2][2];
+    s16x4 ta[4][2][2], tb[2][2][2];                                   // asm destinations of the transposed reads
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned aoff[4], boff[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff[i] = lds0 + tr_lane_off(wr * 64 + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) boff[j] = lds0 + tr_lane_off(wc * 32 + j * 16, lane);
 
 #define G3_ISSUE_A(T, H) stage_half<A_KC, 64>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
 #define G3_ISSUE_B(T, H) stage_half<B_KC, 32>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
 #define G3_READ_A(SL, H)                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                 \
-        a[i][ks] = frag<A_KC, 128>(smem + (SL) * SLOT + (H) * HALF, wr * 64 + i * 16, ks, lane)
+    do {                                                                                                          \
+        if constexpr (A_KC) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)         \
+                a[i][ks] = frag<true, 128>(smem + (SL) * SLOT + (H) * HALF, wr * 64 + i * 16, ks, lane);            \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) ds_tr_frags(ta[i], aoff[i] + (unsigned)((SL) * SLOT + (H) * HALF)); \
+        }                                                                                                         \
+    } while (0)
 #define G3_READ_B(SL, H)                                                                                          \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                 \
-        b[j][ks] = frag<B_KC, 128>(smem + (SL) * SLOT + (2 + (H)) * HALF, wc * 32 + j * 16, ks, lane)
-#define G3_MMA(MH, NH)                                                                                            \
+    do {                                                                                                          \
+        if constexpr (B_KC) {                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)         \
+                b[j][ks] = frag<true, 128>(smem + (SL) * SLOT + (2 + (H)) * HALF, wc * 32 + j * 16, ks, lane);      \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) ds_tr_frags(tb[j], boff[j] + (unsigned)((SL) * SLOT + (2 + (H)) * HALF)); \
+        }                                                                                                         \
+    } while (0)
+    // RA / RB: this phase read A / B fragments (the asm destinations among them are named in the wait)
+#define G3_MMA(MH, NH, RA, RB)                                                                                    \
     do {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_barrier();                                                                             \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                                                                       \
+        if constexpr ((RA) && !A_KC && (RB) && !B_KC) tr_wait_ab(ta, tb);                                         \
+        else if constexpr ((RA) && !A_KC) tr_wait_a(ta);                                                          \
+        else if constexpr ((RB) && !B_KC) tr_wait_b(tb);                                                          \
+        else __builtin_amdgcn_s_waitcnt(0xc07f);                                                                  \
+        if constexpr ((RA) && !A_KC) {                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) a[i][ks] = tr_join(ta[i][ks][0], ta[i][ks][1]); \
+        }                                                                                                         \
+        if constexpr ((RB) && !B_KC) {                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) b[j][ks] = tr_join(tb[j][ks][0], tb[j][ks][1]); \
+        }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)             \
@@ -361,15 +424,15 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         __builtin_amdgcn_sched_barrier(0);
         G3_READ_A(sl, 0);
         if (kt + 1 < nk) G3_ISSUE_A(kt + 1, 1);
-        G3_MMA(0, 0);
+        G3_MMA(0, 0, true, true);
         // phase 1: quadrant (0,1)
         G3_READ_B(sl, 1);
         if (kt + 1 < nk) G3_ISSUE_B(kt + 1, 0);
-        G3_MMA(0, 1);
+        G3_MMA(0, 1, false, true);
         // phase 2: quadrant (1,1)
         G3_READ_A(sl, 1);
         if (kt + 2 < nk) G3_ISSUE_A(kt + 2, 0);
-        G3_MMA(1, 1);
+        G3_MMA(1, 1, true, false);
         // phase 3: quadrant (1,0)
         G3_READ_B(sl, 0);
         if (kt + 2 < nk) {
@@ -378,7 +441,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        G3_MMA(1, 0);
+        G3_MMA(1, 0, false, true);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef G3_ISSUE_A
@@ -436,13 +499,11 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     a.sCz = (long)d->M * d->N;
     a.alpha = d->alpha; a.flags = d->flags;
     // Tile / kernel choice, from same-process A/B runs of every cfg-2 shape (tools/gemm_ab.py, T = 32768 tokens):
-    //   NT (forward):  256x256 ping-pong kernel whenever the output is at least 512 wide (fc1 910 vs 750 TF, fc2 1110 vs 1050);
-    //   NN (dgrad):    256x256 one-barrier kernel for wide outputs (N >= 1536: 910 vs 780 TF), 128x128 for N = 768, whose
-    //                  384 tiles of 256x256 would fill 1.5 rounds of 256 CUs (128x128: 977 vs 870 TF);
-    //   TN (wgrad):    the caller asks (PB_GEMM_TILE256) together with its split-K factor; one-barrier kernel (845 vs 765 TF).
-    const bool nt = a_kc && b_kc;
+    // the 256x256 ping-pong kernel wherever the output is at least 512 wide -- NT fc1 910 vs 750 TF (128x128), fc2 1110 vs 1050,
+    // NN dfc1 937 vs 899, TN w1 930 vs 820 (one-barrier 256x256) -- and 128x128 tiles (2 workgroups per CU) below that and for
+    // the small split-K wgrads (768 x 768: 692 vs 620 TF). TN callers pass PB_GEMM_TILE256 together with their split-K factor.
     const bool big = !(d->flags & PB_GEMM_TILE128) && d->M >= 256 && d->N >= 256 &&
-                     ((d->flags & PB_GEMM_TILE256) || (nsplit == 1 && d->M >= 2048 && (d->N >= 1536 || (nt && d->N >= 512))));
+                     ((d->flags & PB_GEMM_TILE256) || (nsplit == 1 && d->M >= 2048 && d->N >= 512));
     const bool tall = !big && (d->flags & 512) && d->M >= 1024;   // measured: no gain over 128x128 (tools/gemm_bench.py), kept for experiments      // 256x128: 8 waves of 64x64, 25% less L2->LDS traffic per FLOP
     const int BMs = (big || tall) ? 256 : 128, BNs = big ? 256 : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
@@ -460,7 +521,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 4, 2, 4, 4);
         else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 4, 2, 4, 4);
         else PB_G2_LAUNCH(false, false, 4, 2, 4, 4);
-    } else if (big && !(d->flags & 2048) && (nt || (d->flags & 4096))) {   // bit 11 / 12: force the one-barrier / ping-pong kernel (A/B runs)
+    } else if (big && !(d->flags & 2048)) {                          // bit 11: A/B against the one-barrier 256x256 kernel
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
         auto kfn = gemm3_kernel<AK, BK_>;                                                                                  \
