@@ -71,8 +71,22 @@ __device__ __forceinline__ bf16x8 frag_global(const bf16_t* __restrict__ g, long
     if (row < nvalid) z = *reinterpret_cast<const bf16x8*>(g + (long)row * ld + col);
     return z;
 }
-__device__ __forceinline__ float grp_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+// reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with v_permlane16/32_swap: after swap(v, v) one
+// of the two results is the lane's own value and the other its partner's, for either parity -- VALU only, where
+// __shfl_xor goes through ds_bpermute (an LDS round trip on the softmax's critical path).
+__device__ __forceinline__ float grp_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float grp_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <bool V> struct BoolTag { static constexpr bool value = V; };
 
 constexpr int STG = 2 * 8192 + 512;        // one stage: two 8 KiB images + 128 floats
 
@@ -87,7 +101,45 @@ __device__ __forceinline__ void block_map(int nrb, int H, int B, int& rb, int& h
     h = bh % H; b = bh / H;
 }
 
+// ---- pieces shared by the three kernels' pipelines ------------------------------------------------------------------------
+// Transposed fragments through inline asm (form (ii) of cdna_hip_programming.md 5.7: "=v" loads, one wait statement naming all
+// of them): in front of the ds_read_tr BUILTIN hipcc puts s_waitcnt vmcnt(0) whenever an LDS-DMA is in flight, i.e. in the
+// middle of every tile, which is exactly the prefetch these kernels live on (found in the .s; rocprof: 22 % MFMA busy).
+template <int OFF>
+__device__ __forceinline__ void ds_tr(s16x4& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+// lane part of frag_tr's address for column block c0 (the row part 32 s + 16 hi is an immediate: fsw() ignores row bits 4, 5)
+__device__ __forceinline__ unsigned tr_lane_off64(int c0, int lane) {
+    const int lr = lane & 15, g = lane >> 4, qq = lr >> 2, pp = lr & 3;
+    const int r0 = 4 * g + qq, chunk = (c0 >> 3) + (pp >> 1);
+    return (unsigned)(r0 * 128 + ((chunk ^ fsw(r0)) << 4) + ((pp & 1) << 3));
+}
+// the four 8-byte reads of one 16-column block: d[s][0/1] = rows 32 s + 4 g + qq (+16)
+__device__ __forceinline__ void ds_tr_block(s16x4 (&d)[2][2], unsigned addr) {
+    ds_tr<0>(d[0][0], addr); ds_tr<2048>(d[0][1], addr); ds_tr<4096>(d[1][0], addr); ds_tr<6144>(d[1][1], addr);
+}
+__device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+#define TRW4(X) "+v"(X[0][0]), "+v"(X[0][1]), "+v"(X[1][0]), "+v"(X[1][1])
+__device__ __forceinline__ void tr_wait4(s16x4 (&t)[4][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TRW4(t[0]), TRW4(t[1]), TRW4(t[2]), TRW4(t[3]));
+}
+__device__ __forceinline__ void tr_wait8(s16x4 (&t)[4][2][2], s16x4 (&u)[4][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TRW4(t[0]), TRW4(t[1]), TRW4(t[2]), TRW4(t[3]), TRW4(u[0]), TRW4(u[1]), TRW4(u[2]), TRW4(u[3]));
+}
+#undef TRW4
+__device__ __forceinline__ unsigned lds_u32(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+
+constexpr int NSTG = 3, TILE2 = 16384;     // 3-deep ring of {two 8 KiB images}
+
 // ================================================================== forward: block = 128 queries
+// LDS: 3 x {K tile, V tile} | key bias (0 / -inf) of every key this block visits | one "has a masked key" word per tile.
+// Pipeline: the DMA of tile it+2 is issued at the top of tile it and waited for, with a counted vmcnt(4), at the bottom of
+// tile it+1 in front of a raw s_barrier -- two tiles of flight time, nothing in the loop drains it (no ordinary global load,
+// no __syncthreads(), no ds_read_tr builtin). V's transposed fragments are requested before the softmax and collected after.
 __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
@@ -98,6 +150,20 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     const bf16_t* Q = p.q + b * p.q_sb + h * HD;
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;
+    const float c = p.scale * LOG2E;
+    // keys at and beyond kmax[b] (1 + last visible key of this batch row: the PAD tail) are masked for every query: skip their tiles
+    const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
+    const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
+    const int nt = (kend + 63) / 64;
+    float* ldsBias = reinterpret_cast<float*>(smem + NSTG * TILE2);
+    unsigned* ldsFlag = reinterpret_cast<unsigned*>(ldsBias + ((p.Sk + 63) / 64) * 64);
+    for (int tile = wave; tile < nt; tile += 4) {                        // one wave = one tile of keys
+        const int key = tile * 64 + lane;
+        const bool vis = key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
+        ldsBias[key] = vis ? 0.f : -INFINITY;
+        const bool allvis = __builtin_amdgcn_ballot_w64(vis) == ~0ull;
+        if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
+    }
     int myq[2];
     bf16x8 qf[2][2];
 #pragma unroll
@@ -106,36 +172,35 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8);
     }
+    asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]));   // ordinary loads are done before the first DMA
     f32x4 oacc[2][4];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-    const float c = p.scale * LOG2E;
-    // keys at and beyond kmax[b] (1 + last visible key of this batch row: the PAD tail) are masked for every query: skip their tiles
-    const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
-    const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
-    const int nt = (kend + 63) / 64;
+    unsigned voff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_u32(smem) + 8192 + tr_lane_off64(dt * 16, lane);
     auto stage = [&](int it, int sidx) {
-        char* st = smem + sidx * STG;
+        char* st = smem + sidx * TILE2;
         stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane);
         stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane);
-        if (t < 64) {
-            const int key = it * 64 + t;
-            const bool vis = key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
-            reinterpret_cast<float*>(st + 16384)[t] = vis ? 0.f : -INFINITY;
-        }
     };
     if (nt > 0) stage(0, 0);
-    __syncthreads();
+    if (nt > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                    // this wave's bias / flag stores
+    __builtin_amdgcn_s_barrier();
+    int sidx = 0;
     for (int it = 0; it < nt; ++it) {
-        const char* st = smem + (it & 1) * STG;
-        if (it + 1 < nt) stage(it + 1, (it + 1) & 1);
-        const char* ldsK = st; const char* ldsV = st + 8192;
-        const float* ldsB = reinterpret_cast<const float*>(st + 16384);
+        const char* st = smem + sidx * TILE2;
+        const int nidx = sidx == 0 ? 2 : sidx - 1;                         // (it + 2) % 3
+        if (it + 2 < nt) stage(it + 2, nidx);
+        const char* ldsK = st;
+        const float* ldsB = ldsBias + it * 64;
         const int k0 = it * 64;
         const bool diag = p.causal && (k0 + 63 > q0 + wave * 32);        // wave-uniform: only tiles that touch the diagonal compare
+        const bool masked = diag || __builtin_amdgcn_readfirstlane(ldsFlag[it]) != 0u;
         f32x4 s[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -146,48 +211,73 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
                 s[qt][kt] = MFMA16(kb, qf[qt][1], s[qt][kt]);
             }
         }
+        s16x4 tv[4][2][2];                                                // requested before the softmax, collected after it
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * TILE2));
         bf16x8 pf[2][2];
+        // Online softmax of the tile: the common tile -- no masked key, not on the causal diagonal -- takes a path without
+        // bias add, compare and select: max on the raw scores, then exp2(fma(s, c, -max)).
+        auto softmax_tile = [&](auto tag) {
+            constexpr bool MASKED = decltype(tag)::value;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float mx = -INFINITY;
+            for (int qt = 0; qt < 2; ++qt) {
+                float mx = -INFINITY;
+                if constexpr (MASKED) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
+                    for (int kt = 0; kt < 4; ++kt) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = fmaf(s[qt][kt][r], c, bias[r]);
-                    if (diag && (k0 + kt * 16 + g * 4 + r) > myq[qt]) x = -INFINITY;
-                    s[qt][kt][r] = x;
-                    mx = fmaxf(mx, x);
+                        for (int r = 0; r < 4; ++r) {
+                            float x = fmaf(s[qt][kt][r], c, bias[r]);
+                            if (diag && (k0 + kt * 16 + g * 4 + r) > myq[qt]) x = -INFINITY;
+                            s[qt][kt][r] = x;
+                            mx = fmaxf(mx, x);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+                    mx *= c;                                              // c > 0: scaling commutes with the max
                 }
+                mx = grp_max(mx);
+                const float mnew = fmaxf(m[qt], mx);
+                const float muse = mnew == -INFINITY ? 0.f : mnew;
+                const float alpha = __builtin_amdgcn_exp2f(m[qt] - muse);
+                float rs = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = MASKED ? __builtin_amdgcn_exp2f(s[qt][kt][r] - muse) : __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], c, -muse));
+                        s[qt][kt][r] = e; rs += e;
+                    }
+                rs = grp_sum(rs);
+                l[qt] = l[qt] * alpha + rs;
+                m[qt] = mnew;
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {      // no row of this wave moved its maximum: nothing to rescale
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) oacc[qt][i] *= alpha;
+                }
+                pf[qt][0] = pack_pair(s[qt][0], s[qt][1]);
+                pf[qt][1] = pack_pair(s[qt][2], s[qt][3]);
             }
-            mx = grp_max(mx);
-            const float mnew = fmaxf(m[qt], mx);
-            const float muse = mnew == -INFINITY ? 0.f : mnew;
-            const float alpha = __builtin_amdgcn_exp2f(m[qt] - muse);
-            float rs = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[qt][kt][r] - muse); s[qt][kt][r] = e; rs += e; }
-            rs = grp_sum(rs);
-            l[qt] = l[qt] * alpha + rs;
-            m[qt] = mnew;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) oacc[qt][i] *= alpha;
-            pf[qt][0] = pack_pair(s[qt][0], s[qt][1]);
-            pf[qt][1] = pack_pair(s[qt][2], s[qt][3]);
-        }
+        };
+        if (masked) softmax_tile(BoolTag<true>{}); else softmax_tile(BoolTag<false>{});
+        tr_wait4(tv);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 v0 = frag_tr(ldsV, dt * 16, 0, lane), v1 = frag_tr(ldsV, dt * 16, 1, lane);
+            const bf16x8 v0 = tr_join(tv[dt][0][0], tv[dt][0][1]), v1 = tr_join(tv[dt][1][0], tv[dt][1][1]);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 oacc[qt][dt] = MFMA16(v0, pf[qt][0], oacc[qt][dt]);
                 oacc[qt][dt] = MFMA16(v1, pf[qt][1], oacc[qt][dt]);
             }
         }
-        __syncthreads();
+        if (it + 2 < nt) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        sidx = sidx == 2 ? 0 : sidx + 1;
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -204,7 +294,21 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     }
 }
 
+// scale a bf16x8 fragment by c (operand prescale: S = (c K) Q^T comes out of the MFMA in log2 units)
+__device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float c) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((float)v[e] * c);
+    return r;
+}
+
 // ================================================================== backward dK, dV: block = 128 keys
+// Per score the backward needs p = exp(s - lse) and ds = p (dp - delta). With K prescaled by c = scale * log2(e) and the
+// row constants -lse * log2(e) and -delta loaded as the INITIAL ACCUMULATORS of the S and dP MFMA chains, that is one
+// v_exp_f32 and one multiply: no fma, no subtract, no per-score mask (a masked key only dirties its own dK / dV rows, which
+// are zeroed in the epilogue; a fully masked or out-of-range query row has -lse = -inf, so p = 0), and the softmax scale is
+// applied once to dK. Only tiles on the causal diagonal compare. Pipeline as in the forward: 3-deep DMA ring of {Q, dO}
+// tiles behind a counted vmcnt, raw barriers, transposed fragments by asm; -lse, -delta of the whole row sit in LDS.
 __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
@@ -216,93 +320,122 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;
     const bf16_t* DO = p.dout + b * p.o_sb + h * HD;
-    int mykey[2]; bool kvis[2];
+    const float c = p.scale * LOG2E;
+    const int it0 = p.causal ? k0 / 64 : 0;
+    // a key block that lies entirely in the masked tail receives no gradient: skip its whole query loop (zeros are written)
+    const int nt = (p.kmax && k0 >= p.kmax[b]) ? 0 : (p.Sq + 63) / 64;
+    const int sqp = ((p.Sq + 63) / 64) * 64;
+    float* ldsNL = reinterpret_cast<float*>(smem + NSTG * TILE2);         // -lse * log2(e) per query (-inf: row contributes nothing)
+    float* ldsND = ldsNL + sqp;                                          // -delta per query
+    for (int q = it0 * 64 + t; q < nt * 64; q += FT) {
+        const long li = ((long)b * p.H + h) * p.Sq + q;
+        const float ls = q < p.Sq ? p.lse[li] : INFINITY;
+        ldsNL[q] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
+        ldsND[q] = q < p.Sq ? -p.delta[li] : 0.f;
+    }
+    int mykey[2];
     bf16x8 kf[2][2], vf[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         mykey[kt] = k0 + wave * 32 + kt * 16 + lr;
-        kvis[kt] = mykey[kt] < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + mykey[kt]] != 0.f);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            kf[kt][ks] = frag_global(K, p.k_ss, mykey[kt], p.Sk, ks * 32 + g * 8);
+            kf[kt][ks] = scale_frag(frag_global(K, p.k_ss, mykey[kt], p.Sk, ks * 32 + g * 8), c);
             vf[kt][ks] = frag_global(V, p.v_ss, mykey[kt], p.Sk, ks * 32 + g * 8);
         }
     }
+    asm volatile("" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));
     f32x4 dk[2][4], dv[2][4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dk[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const float c = p.scale * LOG2E;
-    const int it0 = p.causal ? k0 / 64 : 0;
-    // a key block that lies entirely in the masked tail receives no gradient: skip its whole query loop (zeros are written)
-    const int nt = (p.kmax && k0 >= p.kmax[b]) ? 0 : (p.Sq + 63) / 64;
+    unsigned qoff[4], ooff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { qoff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane); ooff[dt] = qoff[dt] + 8192; }
     auto stage = [&](int it, int sidx) {
-        char* st = smem + sidx * STG;
+        char* st = smem + sidx * TILE2;
         stage64(Q, p.q_ss, it * 64, p.Sq, st, wave, lane);
         stage64(DO, p.o_ss, it * 64, p.Sq, st + 8192, wave, lane);
-        if (t < 64) {
-            const int q = it * 64 + t;
-            const long li = ((long)b * p.H + h) * p.Sq + q;
-            float* f = reinterpret_cast<float*>(st + 16384);
-            f[t] = q < p.Sq ? p.lse[li] * LOG2E : INFINITY;
-            f[64 + t] = q < p.Sq ? p.delta[li] : 0.f;
-        }
     };
     if (it0 < nt) stage(it0, 0);
-    __syncthreads();
+    if (it0 + 1 < nt) { stage(it0 + 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    int sidx = 0;
     for (int it = it0; it < nt; ++it) {
-        const int par = (it - it0) & 1;
-        const char* st = smem + par * STG;
-        if (it + 1 < nt) stage(it + 1, par ^ 1);
+        const char* st = smem + sidx * TILE2;
+        const int nidx = sidx == 0 ? 2 : sidx - 1;
+        if (it + 2 < nt) stage(it + 2, nidx);
         const char* ldsQ = st; const char* ldsO = st + 8192;
-        const float* ldsL = reinterpret_cast<const float*>(st + 16384);
         const int q0 = it * 64;
         const bool diag = p.causal && (k0 + wave * 32 + 31 > q0);          // wave-uniform: this q tile can be below some of the wave's keys
         bf16x8 pf[2][2], df[2][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {            // q tiles (2 half, 2 half + 1) -> one k-step of the dV/dK products
-            f32x4 s[2][2], dp[2][2];
+            f32x4 sv[2][2], dp[2][2];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int qt = half * 2 + qq;
                 const bf16x8 qa = frag_row(ldsQ, qt * 16 + lr, 0, g), qb = frag_row(ldsQ, qt * 16 + lr, 1, g);
                 const bf16x8 oa = frag_row(ldsO, qt * 16 + lr, 0, g), ob = frag_row(ldsO, qt * 16 + lr, 1, g);
-                const f32x4 lse = *reinterpret_cast<const f32x4*>(ldsL + qt * 16 + g * 4);
-                const f32x4 dl = *reinterpret_cast<const f32x4*>(ldsL + 64 + qt * 16 + g * 4);
+                const f32x4 nl = *reinterpret_cast<const f32x4*>(ldsNL + q0 + qt * 16 + g * 4);
+                const f32x4 nd = *reinterpret_cast<const f32x4*>(ldsND + q0 + qt * 16 + g * 4);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
-                    f32x4 sv = MFMA16(qa, kf[kt][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    sv = MFMA16(qb, kf[kt][1], sv);
-                    f32x4 dv_ = MFMA16(oa, vf[kt][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    dv_ = MFMA16(ob, vf[kt][1], dv_);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = q0 + qt * 16 + g * 4 + r;
-                        const bool vis = kvis[kt] && (!diag || mykey[kt] <= q);
-                        const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(sv[r], c, -lse[r])) : 0.f;
-                        sv[r] = pr;
-                        dv_[r] = pr * (dv_[r] - dl[r]) * p.scale;
-                    }
-                    s[kt][qq] = sv; dp[kt][qq] = dv_;
+                    sv[kt][qq] = MFMA16(qb, kf[kt][1], MFMA16(qa, kf[kt][0], nl));
+                    dp[kt][qq] = MFMA16(ob, vf[kt][1], MFMA16(oa, vf[kt][0], nd));
                 }
             }
+            if (diag) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) { pf[kt][half] = pack_pair(s[kt][0], s[kt][1]); df[kt][half] = pack_pair(dp[kt][0], dp[kt][1]); }
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int q = q0 + (half * 2 + qq) * 16 + g * 4 + r;
+                            const float pr = mykey[kt] <= q ? __builtin_amdgcn_exp2f(sv[kt][qq][r]) : 0.f;
+                            sv[kt][qq][r] = pr; dp[kt][qq][r] *= pr;
+                        }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = __builtin_amdgcn_exp2f(sv[kt][qq][r]);
+                            sv[kt][qq][r] = pr; dp[kt][qq][r] *= pr;
+                        }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { pf[kt][half] = pack_pair(sv[kt][0], sv[kt][1]); df[kt][half] = pack_pair(dp[kt][0], dp[kt][1]); }
         }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int si = 0; si < 2; ++si) {                                   // k-step si of the dV / dK products = q rows 32 si .. 32 si + 31
+            s16x4 to[4][2], tq[4][2];
 #pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-                const bf16x8 ot = frag_tr(ldsO, dt * 16, sidx, lane), qtf = frag_tr(ldsQ, dt * 16, sidx, lane);
+            for (int dt = 0; dt < 4; ++dt) {
+                const unsigned ao = ooff[dt] + (unsigned)(sidx * TILE2), aq = qoff[dt] + (unsigned)(sidx * TILE2);
+                if (si == 0) { ds_tr<0>(to[dt][0], ao); ds_tr<2048>(to[dt][1], ao); ds_tr<0>(tq[dt][0], aq); ds_tr<2048>(tq[dt][1], aq); }
+                else { ds_tr<4096>(to[dt][0], ao); ds_tr<6144>(to[dt][1], ao); ds_tr<4096>(tq[dt][0], aq); ds_tr<6144>(tq[dt][1], aq); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(to[0][0]), "+v"(to[0][1]), "+v"(to[1][0]), "+v"(to[1][1]), "+v"(to[2][0]), "+v"(to[2][1]), "+v"(to[3][0]), "+v"(to[3][1]),
+                                                  "+v"(tq[0][0]), "+v"(tq[0][1]), "+v"(tq[1][0]), "+v"(tq[1][1]), "+v"(tq[2][0]), "+v"(tq[2][1]), "+v"(tq[3][0]), "+v"(tq[3][1]));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 ot = tr_join(to[dt][0], to[dt][1]), qtf = tr_join(tq[dt][0], tq[dt][1]);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
-                    dv[kt][dt] = MFMA16(pf[kt][sidx], ot, dv[kt][dt]);
-                    dk[kt][dt] = MFMA16(df[kt][sidx], qtf, dk[kt][dt]);
+                    dv[kt][dt] = MFMA16(pf[kt][si], ot, dv[kt][dt]);
+                    dk[kt][dt] = MFMA16(df[kt][si], qtf, dk[kt][dt]);
                 }
             }
         }
-        __syncthreads();
+        if (it + 2 < nt) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        sidx = sidx == 2 ? 0 : sidx + 1;
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -310,15 +443,22 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         for (int r = 0; r < 4; ++r) {
             const int key = k0 + wave * 32 + kt * 16 + g * 4 + r;
             if (key < p.Sk) {
+                const bool kvis = !p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f;    // a masked key receives no gradient
                 bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HD;
                 bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HD;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) { DK[dt * 16 + lr] = (bf16_t)dk[kt][dt][r]; DV[dt * 16 + lr] = (bf16_t)dv[kt][dt][r]; }
+                for (int dt = 0; dt < 4; ++dt) {
+                    DK[dt * 16 + lr] = (bf16_t)(kvis ? dk[kt][dt][r] * p.scale : 0.f);
+                    DV[dt * 16 + lr] = (bf16_t)(kvis ? dv[kt][dt][r] : 0.f);
+                }
             }
         }
 }
 
 // ================================================================== backward dQ: block = 128 queries
+// Same arithmetic with the roles swapped: Q (prescaled by c) and dO of the wave's 32 queries stay in registers, -lse * log2(e)
+// and -delta are per-lane constants splatted into the initial accumulators, K / V tiles stream through the DMA ring, and a
+// tile that holds a masked key adds the 0 / -inf key bias before the exp2 (no select).
 __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
@@ -330,47 +470,64 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;
     const bf16_t* DO = p.dout + b * p.o_sb + h * HD;
-    int myq[2]; float lse[2], dl[2];
+    const float c = p.scale * LOG2E;
+    const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
+    const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
+    const int nt = (kend + 63) / 64;
+    float* ldsBias = reinterpret_cast<float*>(smem + NSTG * TILE2);
+    unsigned* ldsFlag = reinterpret_cast<unsigned*>(ldsBias + ((p.Sk + 63) / 64) * 64);
+    for (int tile = wave; tile < nt; tile += 4) {
+        const int key = tile * 64 + lane;
+        const bool vis = key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
+        ldsBias[key] = vis ? 0.f : -INFINITY;
+        const bool allvis = __builtin_amdgcn_ballot_w64(vis) == ~0ull;
+        if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
+    }
+    int myq[2];
     bf16x8 qf[2][2], of[2][2];
+    float nl[2], nd[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         myq[qt] = q0 + wave * 32 + qt * 16 + lr;
         const long li = ((long)b * p.H + h) * p.Sq + myq[qt];
-        lse[qt] = myq[qt] < p.Sq ? p.lse[li] * LOG2E : INFINITY;
-        dl[qt] = myq[qt] < p.Sq ? p.delta[li] : 0.f;
+        const float ls = myq[qt] < p.Sq ? p.lse[li] : INFINITY;
+        nl[qt] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
+        nd[qt] = myq[qt] < p.Sq ? -p.delta[li] : 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qf[qt][ks] = frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8);
+            qf[qt][ks] = scale_frag(frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8), c);
             of[qt][ks] = frag_global(DO, p.o_ss, myq[qt], p.Sq, ks * 32 + g * 8);
         }
     }
+    asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(of[0][0]), "+v"(of[0][1]), "+v"(of[1][0]), "+v"(of[1][1]),
+                      "+v"(nl[0]), "+v"(nl[1]), "+v"(nd[0]), "+v"(nd[1]));
     f32x4 dq[2][4];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dq[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float c = p.scale * LOG2E;
-    const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
-    const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
-    const int nt = (kend + 63) / 64;
+    unsigned koff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) koff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane);
     auto stage = [&](int it, int sidx) {
-        char* st = smem + sidx * STG;
+        char* st = smem + sidx * TILE2;
         stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane);
         stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane);
-        if (t < 64) {
-            const int key = it * 64 + t;
-            reinterpret_cast<float*>(st + 16384)[t] = (key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f)) ? 1.f : 0.f;
-        }
     };
     if (nt > 0) stage(0, 0);
-    __syncthreads();
+    if (nt > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    int sidx = 0;
     for (int it = 0; it < nt; ++it) {
-        const char* st = smem + (it & 1) * STG;
-        if (it + 1 < nt) stage(it + 1, (it + 1) & 1);
+        const char* st = smem + sidx * TILE2;
+        const int nidx = sidx == 0 ? 2 : sidx - 1;
+        if (it + 2 < nt) stage(it + 2, nidx);
         const char* ldsK = st; const char* ldsV = st + 8192;
-        const float* ldsB = reinterpret_cast<const float*>(st + 16384);
+        const float* ldsB = ldsBias + it * 64;
         const int k0 = it * 64;
         const bool diag = p.causal && (k0 + 63 > q0 + wave * 32);
+        const bool masked = __builtin_amdgcn_readfirstlane(ldsFlag[it]) != 0u;
         bf16x8 df[2][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -380,36 +537,39 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
                 const int kt = half * 2 + kk;
                 const bf16x8 ka = frag_row(ldsK, kt * 16 + lr, 0, g), kb = frag_row(ldsK, kt * 16 + lr, 1, g);
                 const bf16x8 va = frag_row(ldsV, kt * 16 + lr, 0, g), vb = frag_row(ldsV, kt * 16 + lr, 1, g);
-                const f32x4 vis4 = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
-                    f32x4 sv = MFMA16(ka, qf[qt][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    sv = MFMA16(kb, qf[qt][1], sv);
-                    f32x4 dpv = MFMA16(va, of[qt][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    dpv = MFMA16(vb, of[qt][1], dpv);
+                    f32x4 sv = MFMA16(kb, qf[qt][1], MFMA16(ka, qf[qt][0], (f32x4{nl[qt], nl[qt], nl[qt], nl[qt]})));
+                    f32x4 dpv = MFMA16(vb, of[qt][1], MFMA16(va, of[qt][0], (f32x4{nd[qt], nd[qt], nd[qt], nd[qt]})));
+                    if (masked) sv += *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
+                    if (diag) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = k0 + kt * 16 + g * 4 + r;
-                        const bool vis = vis4[r] != 0.f && (!diag || key <= myq[qt]);
-                        const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(sv[r], c, -lse[qt])) : 0.f;
-                        dpv[r] = pr * (dpv[r] - dl[qt]) * p.scale;
+                        for (int r = 0; r < 4; ++r) if (k0 + kt * 16 + g * 4 + r > myq[qt]) sv[r] = -INFINITY;
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dpv[r] *= __builtin_amdgcn_exp2f(sv[r]);
                     ds_[qt][kk] = dpv;
                 }
             }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) df[qt][half] = pack_pair(ds_[qt][0], ds_[qt][1]);
         }
+        s16x4 tk[4][2][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ds_tr_block(tk[dt], koff[dt] + (unsigned)(sidx * TILE2));
+        tr_wait4(tk);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 k0f = frag_tr(ldsK, dt * 16, 0, lane), k1f = frag_tr(ldsK, dt * 16, 1, lane);
+            const bf16x8 k0f = tr_join(tk[dt][0][0], tk[dt][0][1]), k1f = tr_join(tk[dt][1][0], tk[dt][1][1]);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 dq[qt][dt] = MFMA16(k0f, df[qt][0], dq[qt][dt]);
                 dq[qt][dt] = MFMA16(k1f, df[qt][1], dq[qt][dt]);
             }
         }
-        __syncthreads();
+        if (it + 2 < nt) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        sidx = sidx == 2 ? 0 : sidx + 1;
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
@@ -417,7 +577,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
             bf16_t* DQ = p.dq + b * p.dq_sb + (long)myq[qt] * p.dq_ss + h * HD;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                bf16x4 r = {(bf16_t)dq[qt][dt][0], (bf16_t)dq[qt][dt][1], (bf16_t)dq[qt][dt][2], (bf16_t)dq[qt][dt][3]};
+                bf16x4 r = {(bf16_t)(dq[qt][dt][0] * p.scale), (bf16_t)(dq[qt][dt][1] * p.scale), (bf16_t)(dq[qt][dt][2] * p.scale), (bf16_t)(dq[qt][dt][3] * p.scale)};
                 *reinterpret_cast<bf16x4*>(DQ + dt * 16 + g * 4) = r;
             }
         }
@@ -432,7 +592,10 @@ int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* 
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal;
-    hipLaunchKernelGGL(fa64_fwd_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), 2 * STG, stream, a);
+    const size_t lds_fwd = (size_t)NSTG * TILE2 + (size_t)((Sk + 63) / 64) * (64 * 4 + 4);
+    PB_REQUIRE(lds_fwd <= 160 * 1024, "pb_flash_fwd: Sk=%d needs %zu bytes of LDS", Sk, lds_fwd);
+    if (lds_fwd > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);
+    hipLaunchKernelGGL(fa64_fwd_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), lds_fwd, stream, a);
     PB_LAUNCH_CHECK();
     return 0;
 }
@@ -447,9 +610,14 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
     a.scale = scale; a.causal = causal;
-    hipLaunchKernelGGL(fa64_bwd_dkv_kernel, dim3(((Sk + 127) / 128) * H * B), dim3(FT), 2 * STG, stream, a);
+    const size_t lds_dkv = (size_t)NSTG * TILE2 + (size_t)((Sq + 63) / 64) * 64 * 8;
+    const size_t lds_dq = (size_t)NSTG * TILE2 + (size_t)((Sk + 63) / 64) * (64 * 4 + 4);
+    PB_REQUIRE(lds_dkv <= 160 * 1024 && lds_dq <= 160 * 1024, "pb_flash_bwd: Sq=%d Sk=%d need %zu / %zu bytes of LDS", Sq, Sk, lds_dkv, lds_dq);
+    if (lds_dkv > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+    if (lds_dq > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+    hipLaunchKernelGGL(fa64_bwd_dkv_kernel, dim3(((Sk + 127) / 128) * H * B), dim3(FT), lds_dkv, stream, a);
     PB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fa64_bwd_dq_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), 2 * STG, stream, a);
+    hipLaunchKernelGGL(fa64_bwd_dq_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), lds_dq, stream, a);
     PB_LAUNCH_CHECK();
     return 0;
 }
