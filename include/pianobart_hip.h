@@ -31,8 +31,8 @@ const char* pb_last_error(void);
  * Batched over nb1*nb2 problems with element strides s?1 / s?2. */
 #define PB_GEMM_ACCUM 1          /* C = C + result                                   */
 #define PB_GEMM_C_F32 2          /* C is float regardless of dtype                   */
-#define PB_GEMM_GELU 4           /* aux_out = pre-activation; C = gelu_erf(result)    */
-#define PB_GEMM_MUL_GELU_GRAD 8  /* C = result * gelu'(aux_in)                        */
+#define PB_GEMM_GELU 4           /* C = gelu_erf(result); aux_out = gelu_erf'(result): the forward pays 3 extra FMAs per element so that */
+#define PB_GEMM_MUL_GELU_GRAD 8  /* C = result * aux_in      ... the backward of the activation (dU = dG * gelu'(U)) is one multiply        */
 #define PB_GEMM_FORCE_V1 16      /* use the generic register-staged kernel (tests)    */
 #define PB_GEMM_TILE128 32       /* bf16 fast path: force the 128x128 tile             */
 #define PB_GEMM_TILE256 64       /* bf16 fast path: prefer the 256x256 tile (default when M >= 512, N >= 256) */

@@ -87,6 +87,7 @@ __device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& ex) 
     cdf = 0.5f * (1.0f + (x < 0.f ? -erfa : erfa));
 }
 __device__ __forceinline__ float gelu_fast(float x) { float c, e; gelu_parts_fast(x, c, e); return x * c; }
+__device__ __forceinline__ void gelu_both_fast(float x, float& y, float& dy) { float c, e; gelu_parts_fast(x, c, e); y = x * c; dy = c + x * 0.3989422804014327f * e; }
 __device__ __forceinline__ float gelu_grad_fast(float x) { float c, e; gelu_parts_fast(x, c, e); return c + x * 0.3989422804014327f * e; }
 
 // ---- counter-based RNG for dropout: Philox4x32-7 -----------------------------------

@@ -35,15 +35,34 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-// stage rows r0..r0+63 (clamped to nrows-1) of a [*, 64] bf16 matrix with row stride ld: 8 KiB = 8 DMA pieces, 2 per wave
-__device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, long ld, int r0, int nrows, char* lds, int wave, int lane) {
+// stage rows r0..r0+63 (clamped to nrows-1) of a [*, 64] bf16 matrix with row stride ld: 8 KiB = 8 DMA pieces, 2 per wave.
+// The per-lane part of the source address (row within the tile, swizzled chunk) is computed once per kernel (StageOff); a
+// whole tile then costs one 64-bit add per piece on top of a wave-uniform tile base -- the row * ld multiplies of the naive
+// form were 16 % of the forward's vector cycles. Only a ragged last tile takes the clamped path.
+struct StageOff { unsigned off[2]; };
+__device__ __forceinline__ StageOff stage_off(long ld, int wave, int lane) {
+    StageOff o;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int inst = wave * 2 + n;
-        const int row = inst * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ fsw(row);
-        const int gr = min(r0 + row, nrows - 1);
-        glds16(base + (long)gr * ld + chunk * 8, lds + inst * 1024);
+        const int row = (wave * 2 + n) * 8 + (lane >> 3);
+        o.off[n] = (unsigned)(row * ld + (((lane & 7) ^ fsw(row)) << 3));
+    }
+    return o;
+}
+__device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, long ld, int r0, int nrows, char* lds, int wave, int lane, const StageOff& so) {
+    if (r0 + 64 <= nrows) {
+        const bf16_t* tb = base + (long)r0 * ld;                          // wave-uniform
+#pragma unroll
+        for (int n = 0; n < 2; ++n) glds16(tb + so.off[n], lds + (wave * 2 + n) * 1024);
+    } else {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int inst = wave * 2 + n;
+            const int row = inst * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ fsw(row);
+            const int gr = min(r0 + row, nrows - 1);
+            glds16(base + (long)gr * ld + chunk * 8, lds + inst * 1024);
+        }
     }
 }
 // natural fragment: 8 consecutive columns (32 ks + 8 g ..) of image row `row`
@@ -182,10 +201,11 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     unsigned voff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_u32(smem) + 8192 + tr_lane_off64(dt * 16, lane);
+    const StageOff so_k = stage_off(p.k_ss, wave, lane), so_v = stage_off(p.v_ss, wave, lane);
     auto stage = [&](int it, int sidx) {
         char* st = smem + sidx * TILE2;
-        stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane);
-        stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane);
+        stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane, so_k);
+        stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane, so_v);
     };
     if (nt > 0) stage(0, 0);
     if (nt > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -353,10 +373,11 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
     unsigned qoff[4], ooff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { qoff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane); ooff[dt] = qoff[dt] + 8192; }
+    const StageOff so_q = stage_off(p.q_ss, wave, lane), so_o = stage_off(p.o_ss, wave, lane);
     auto stage = [&](int it, int sidx) {
         char* st = smem + sidx * TILE2;
-        stage64(Q, p.q_ss, it * 64, p.Sq, st, wave, lane);
-        stage64(DO, p.o_ss, it * 64, p.Sq, st + 8192, wave, lane);
+        stage64(Q, p.q_ss, it * 64, p.Sq, st, wave, lane, so_q);
+        stage64(DO, p.o_ss, it * 64, p.Sq, st + 8192, wave, lane, so_o);
     };
     if (it0 < nt) stage(it0, 0);
     if (it0 + 1 < nt) { stage(it0 + 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -509,10 +530,11 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
     unsigned koff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) koff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane);
+    const StageOff so_k = stage_off(p.k_ss, wave, lane), so_v = stage_off(p.v_ss, wave, lane);
     auto stage = [&](int it, int sidx) {
         char* st = smem + sidx * TILE2;
-        stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane);
-        stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane);
+        stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane, so_k);
+        stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane, so_v);
     };
     if (nt > 0) stage(0, 0);
     if (nt > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -269,10 +269,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
                 if (row >= p.M) continue;
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (do_gelu) {
-                    auxout[(long)row * p.ldaux + col] = from_f<T>(v);
+                    auxout[(long)row * p.ldaux + col] = from_f<T>(gelu_grad_f(v));
                     v = gelu_f(v);
                 }
-                if (mul_gg) v *= gelu_grad_f(to_f(auxin[(long)row * p.ldaux + col]));
+                if (mul_gg) v *= to_f(auxin[(long)row * p.ldaux + col]);
                 const long ci = (long)row * p.ldc + col;
                 if (c32) {
                     if (accum) v += C32[ci];

@@ -175,16 +175,20 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
             if (row < p.M && col < p.N) {
                 v0 = v0 * p.alpha + bv[jp][0];
                 v1 = v1 * p.alpha + bv[jp][1];
-                if (do_gelu) {
-                    store8(p.aux_out + (long)row * p.ldaux + col, v0, v1);
+                if (do_gelu) {                                           // C = gelu(v), aux_out = gelu'(v): both from one exp + one rcp
+                    f32x4 d0, d1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] = gelu_fast(v0[e]); v1[e] = gelu_fast(v1[e]); }
+                    for (int e = 0; e < 4; ++e) {
+                        float y, dy;
+                        gelu_both_fast(v0[e], y, dy); v0[e] = y; d0[e] = dy;
+                        gelu_both_fast(v1[e], y, dy); v1[e] = y; d1[e] = dy;
+                    }
+                    store8(p.aux_out + (long)row * p.ldaux + col, d0, d1);
                 }
-                if (mul_gg) {
+                if (mul_gg) {                                            // aux_in holds gelu'(pre-activation) from the forward
                     f32x4 u0, u1;
                     load8(p.aux_in + (long)row * p.ldaux + col, u0, u1);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] *= gelu_grad_fast(u0[e]); v1[e] *= gelu_grad_fast(u1[e]); }
+                    v0 *= u0; v1 *= u1;
                 }
                 const long ci = (long)row * p.ldc + col;
                 if (c32) {

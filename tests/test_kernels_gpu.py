@@ -60,23 +60,22 @@ def test_gemm_epilogues(ops, dt):
     W = (torch.randn(N, K, device='cuda', generator=g) / math.sqrt(K)).to(dt)
     bias = torch.randn(N, device='cuda', generator=g)
     code = ops.dtype_code(dt)
-    pre = A.double() @ W.double().t() + bias.double()
-    # bias + GELU (pre-activation saved)
+    pre = (A.double() @ W.double().t() + bias.double()).requires_grad_(True)
+    torch.nn.functional.gelu(pre).sum().backward()
+    # bias + GELU (the activation's derivative is saved for the backward)
     C = torch.empty(M, N, device='cuda', dtype=dt); U = torch.empty_like(C)
     ops.gemm(A, W, C, M=M, N=N, K=K, dtype=code, bias=bias, gelu_aux_out=U)
-    assert _rel(U, pre) < TOL[dt] and _rel(C, torch.nn.functional.gelu(pre)) < TOL[dt]
+    assert _rel(U, pre.grad) < TOL[dt] and _rel(C, torch.nn.functional.gelu(pre.detach())) < TOL[dt]
     # alpha + accumulate into f32 C
     C32 = torch.randn(M, N, device='cuda', generator=g)
     ref = C32.double() + 0.5 * (A.double() @ W.double().t())
     ops.gemm(A, W, C32, M=M, N=N, K=K, dtype=code, alpha=0.5, accum=True, c_f32=True)
     assert _rel(C32, ref) < TOL[dt]
-    # multiply by gelu'(aux)
+    # multiply by the saved derivative
     u = torch.randn(M, N, device='cuda', generator=g).to(dt)
-    ud = u.double().requires_grad_(True)
-    torch.nn.functional.gelu(ud).sum().backward()
     C = torch.empty(M, N, device='cuda', dtype=dt)
     ops.gemm(A, W, C, M=M, N=N, K=K, dtype=code, gelu_grad_aux_in=u)
-    assert _rel(C, (A.double() @ W.double().t()) * ud.grad) < TOL[dt]
+    assert _rel(C, (A.double() @ W.double().t()) * u.double()) < TOL[dt]
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
@@ -335,8 +334,9 @@ def test_gemm2_fast_path_matches_generic(ops, a_kc, b_kc, M, N, K, splitk, tile2
     bias = torch.randn(N, device='cuda', generator=g)
     Cb = torch.empty(M, N, device='cuda', dtype=dt); U = torch.empty_like(Cb)
     ops.gemm(Am, Bm, Cb, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, bias=bias, alpha=0.125, gelu_aux_out=U, tile256=tile256)
-    pre = 0.125 * ref + bias.double()
-    assert _rel(U, pre) < 1e-2 and _rel(Cb, torch.nn.functional.gelu(pre)) < 1e-2
+    pre = (0.125 * ref + bias.double()).requires_grad_(True)
+    torch.nn.functional.gelu(pre).sum().backward()
+    assert _rel(U, pre.grad) < 1e-2 and _rel(Cb, torch.nn.functional.gelu(pre.detach())) < 1e-2
     acc0 = torch.randn(M, N, device='cuda', generator=g).to(dt)
     acc = acc0.clone()
     ops.gemm(Am, Bm, acc, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, alpha=0.01, accum=True, tile256=tile256)
