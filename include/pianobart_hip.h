@@ -159,6 +159,29 @@ int pb_corrupt(const int16_t* ids, int16_t* out, float* loss_mask, const int32_t
                int32_t S, float mask_percent, uint64_t seed, const int16_t* pad_row, const int16_t* mask_row,
                const int32_t* n_tokens, void* stream);
 
+/* ---- K14: fine-tune heads, exact f32 (model.py:128-143 SelfAttention, :165-218 SequenceClassification, :220-232 Excitation,
+ * :236-272 TokenClassification; loss finetune.py:121-129). Their matrix products are pb_gemm (f32) calls.
+ * pb_eltwise_fwd: y = dropout(act(x)), op 1 tanh / 2 relu / 3 sigmoid / 4 identity / 5 x * x2; n elements;
+ *   dropout by the step's Philox stream (seed, site), p_drop = 0 disables it.
+ * pb_eltwise_bwd: dx = dy * mask * act'(.) with the derivative taken from the PRE-dropout output `y` (op 5: y = x, also dx2).
+ * pb_softmax_dim1_*: F.softmax(x, dim=1) of x (B, S, R) and its backward (model.py:140).
+ * pb_ce_rows: loss[row] = CrossEntropy(logits[row, :C], target[row]) (reduction='none'), argmax[row] (first maximum, may be
+ *   NULL) and, if dlogits != NULL, dlogits = (softmax - onehot) * coef[0] * weight[row] (weight / coef may be NULL = 1). */
+int pb_eltwise_fwd(int32_t op, const float* x, const float* x2, float* y, int64_t n, uint64_t seed, uint32_t site, float p_drop, void* stream);
+int pb_eltwise_bwd(int32_t op, const float* y, const float* x2, const float* dy, float* dx, float* dx2, int64_t n, uint64_t seed,
+                   uint32_t site, float p_drop, void* stream);
+int pb_softmax_dim1_fwd(const float* x, float* y, int32_t B, int32_t S, int32_t R, void* stream);
+int pb_softmax_dim1_bwd(const float* y, const float* dy, float* dx, int32_t B, int32_t S, int32_t R, void* stream);
+int pb_ce_rows(const float* logits, const int32_t* target, const float* weight, const float* coef, float* loss, float* dlogits,
+               int32_t* argmax, int64_t rows, int32_t C, void* stream);
+/* Decoder label-embedding swap of the velocity task (PianoBart.change_decoder_embedding, PianoBart.py:88-91; model.py:242-245):
+ * pb_gather_rows: out[t] = table[ids[t]] + bias for a small projected label table (nrows x d, f32); pb_gather_rows_bwd: dtable[r] =
+ * sum of dout[t] over ids[t] == r (sequential per element: deterministic). pb_dropout: y = x * mask / (1 - p) in storage dtype
+ * (BART drops after layernorm_embedding); the same call on the gradient is its backward. */
+int pb_gather_rows(const float* table, const int32_t* ids, const float* bias, float* out, int64_t T, int32_t d, int32_t nrows, void* stream);
+int pb_gather_rows_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t T, int32_t d, int32_t nrows, void* stream);
+int pb_dropout(const void* x, void* y, int64_t n, int32_t dtype, uint64_t seed, uint32_t site, float p_drop, void* stream);
+
 /* ---- K13: batch-1 KV-cached decode (model.py:28-66) --------------------------------------------------------------
  * pb_gemv: y[n] = act(sum_k W[n][k] x[k] + bias[n]), W (N,K) row-major in dtype, x (K) dtype, y dtype or f32, gelu = exact erf GELU.
  * pb_attn_decode: one query (H*hd) against cached K/V rows (element (j,h,c) at ptr[j*ss + h*hd + c]), keys 0..Sk-1, optional

@@ -301,10 +301,78 @@ if __name__ == '__main__':
     fns = dict(vocab=g_vocab, g1=g1_forward, g4=g4_grads, g6=g6_gen_mask, g7=g7_sampling, g8=g8_generate,
                g9=g9_state_dict, g10=g10_cfg2_spot)
     for w in which:
-        if w == 'g11':
+        if w in ('g11', 'g12'):
             continue
         print('==', w)
         fns[w]()
+
+
+def g12_finetune_heads():
+    """G12: fine-tune heads: SequenceClassification (composer-like, 8 classes) and TokenClassification in both forms
+    (4 classes: ordinary decoder input; 8 classes: the velocity task's decoder label-embedding swap), dropout off: logits, loss,
+    gradient norm and a few named gradients from the REAL reference; the oracle restatement is asserted against it first."""
+    S, d, L, f, h = 64, 128, 2, 256, 4
+    hf_cfg, o_cfg = cfg_pair(S, d, L, f, h, dropout=0.0)
+    enc, dec, loss_mask, emask, dmask, target = synth_batch(2, S, seed=21)
+    out = {}
+    for tag, mk_o, mk_r in (
+            ('seq', lambda pb: O.SequenceClassification(pb, 8, d), lambda pb: ref_model.SequenceClassification(pb, 8, d)),
+            ('tok4', lambda pb: O.TokenClassification(pb, 4, d), lambda pb: ref_model.TokenClassification(pb, 4, d)),
+            ('tok8', lambda pb: O.TokenClassification(pb, 8, d), lambda pb: ref_model.TokenClassification(pb, 8, d))):
+        o = mk_o(O.PianoBart(o_cfg, E2W, W2E)); r = mk_r(ref_pb.PianoBart(hf_cfg, E2W, W2E))
+        O_randomize(o, 31)
+        assert list(o.state_dict().keys()) == list(r.state_dict().keys()), (tag, 'state_dict keys differ')
+        r.load_state_dict(o.state_dict(), strict=True)
+        for mdl in (o, r):
+            mdl.train()
+            for m in mdl.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+        g = torch.Generator().manual_seed(7)
+        if tag == 'seq':
+            y = torch.randint(0, 8, (2,), generator=g)
+            run = lambda mdl: mdl(input_ids_encoder=enc, encoder_attention_mask=emask)
+            lossf = lambda yh: O.finetune_loss(yh, y, None, True)
+        elif tag == 'tok4':
+            y = torch.randint(0, 4, (2, S), generator=g)
+            run = lambda mdl: mdl(input_ids_encoder=enc, input_ids_decoder=enc, encoder_attention_mask=emask, decoder_attention_mask=emask)
+            lossf = lambda yh: O.finetune_loss(yh, y, emask, False)
+        else:
+            y = torch.randint(0, 7, (2, S), generator=g)
+            y_shift = torch.zeros_like(y) + 7
+            y_shift[:, 1:] = y[:, :-1]
+            attn_shift = torch.zeros_like(emask); attn_shift[:, 1:] = emask[:, :-1]; attn_shift[:, 0] = emask[:, 0]
+            run = lambda mdl: mdl(input_ids_encoder=enc, input_ids_decoder=y_shift, encoder_attention_mask=emask, decoder_attention_mask=attn_shift)
+            lossf = lambda yh: O.finetune_loss(yh, y, emask, False)
+            out['tok8_y_shift'] = y_shift; out['tok8_attn_shift'] = attn_shift
+        res = {}
+        for name, mdl in (('o', o), ('r', r)):
+            mdl.zero_grad()
+            yh = run(mdl)
+            loss = lossf(yh)
+            loss.backward()
+            res[name] = (yh.detach(), loss.detach(), {k: p.grad.detach().clone() for k, p in mdl.named_parameters() if p.grad is not None})
+        assert rel(res['o'][0], res['r'][0]) < 2e-5, (tag, rel(res['o'][0], res['r'][0]))
+        assert abs(float(res['o'][1]) - float(res['r'][1])) < 1e-5 * abs(float(res['r'][1]))
+        gr = res['r'][2]
+        gmax = max(float(v.abs().max()) for v in gr.values())
+        for k in gr:       # k_proj.bias gradients are mathematically zero (softmax shift invariance): noise only
+            assert rel(res['o'][2][k], gr[k]) < 5e-4 or float(gr[k].abs().max()) < 1e-5 * gmax, (tag, k, rel(res['o'][2][k], gr[k]))
+        gnorm = torch.sqrt(sum((v.double() ** 2).sum() for v in gr.values())).float()
+        names = [k for k in gr if k.startswith('classifier') or k.startswith('attention') or 'decoder_emb' in k or 'decoder_linear' in k]
+        names += ['pianobart.bart.decoder.layers.0.self_attn.q_proj.weight', 'pianobart.word_emb.3.lut.weight']
+        out[tag + '_logits'] = res['r'][0]; out[tag + '_loss'] = res['r'][1]; out[tag + '_gnorm'] = gnorm; out[tag + '_y'] = y
+        out[tag + '_sd'] = np.array(sd_checksum(o.state_dict()))
+        out[tag + '_grad_names'] = np.array(names)
+        for i, k in enumerate(names):
+            out['%s_grad_%d' % (tag, i)] = gr[k]
+        print('G12', tag, 'logits rel', rel(res['o'][0], res['r'][0]), 'loss', float(res['r'][1]), 'gnorm', float(gnorm))
+    out['enc'] = enc.to(torch.int16); out['emask'] = emask
+    save('g12_finetune_heads.npz', **out)
+
+
+if __name__ == '__main__' and 'g12' in sys.argv[1:]:
+    g12_finetune_heads()
 
 
 def g11_pretrain_artifacts():

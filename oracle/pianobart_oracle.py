@@ -364,6 +364,69 @@ class PianoBartLM(nn.Module):
 
 
 # ------------------------------------------------------------------ pre-train step
+# ---- fine-tune heads ------------------------------------------------------------------------------------
+class SelfAttention(nn.Module):
+    """model.py:128-143."""
+
+    def __init__(self, input_dim, da, r):
+        super().__init__()
+        self.ws1 = nn.Linear(input_dim, da, bias=False)
+        self.ws2 = nn.Linear(da, r, bias=False)
+
+    def forward(self, h):
+        return torch.softmax(self.ws2(torch.tanh(self.ws1(h))), dim=1).permute(0, 2, 1)
+
+
+class SequenceClassification(nn.Module):
+    """model.py:165-218 (the live code path: decoder input = encoder input, decoder mask = encoder mask)."""
+
+    def __init__(self, pianobart, class_num, hs, da=128, r=4):
+        super().__init__()
+        self.pianobart = pianobart
+        self.attention = SelfAttention(hs, da, r)
+        self.classifier = nn.Sequential(nn.Dropout(0.1), nn.Linear(hs * r, 256), nn.ReLU(), nn.Linear(256, class_num))
+
+    def forward(self, input_ids_encoder, encoder_attention_mask=None):
+        x = self.pianobart(input_ids_encoder=input_ids_encoder, input_ids_decoder=input_ids_encoder,
+                           encoder_attention_mask=encoder_attention_mask, decoder_attention_mask=encoder_attention_mask).last_hidden_state
+        m = torch.bmm(self.attention(x), x)
+        return self.classifier(m.view(m.size()[0], -1))
+
+
+class Excitation(nn.Module):
+    """model.py:220-232."""
+
+    def __init__(self, channel_dim, reduction=16):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(channel_dim, channel_dim // reduction), nn.ReLU(), nn.Linear(channel_dim // reduction, channel_dim), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.fc(x)
+
+
+class TokenClassification(nn.Module):
+    """model.py:236-272."""
+
+    def __init__(self, pianobart, class_num, hs, d_model=64):
+        super().__init__()
+        self.pianobart = pianobart
+        if class_num >= 5:
+            self.pianobart.change_decoder_embedding(Embeddings(n_token=class_num, d_model=d_model), nn.Linear(d_model, pianobart.bartConfig.d_model))
+        self.classifier = nn.Sequential(nn.Dropout(0.1), nn.Linear(hs, 256), nn.ReLU(), nn.Linear(256, class_num))
+
+    def forward(self, input_ids_encoder, input_ids_decoder, encoder_attention_mask=None, decoder_attention_mask=None):
+        x = self.pianobart(input_ids_encoder, input_ids_decoder, encoder_attention_mask, decoder_attention_mask).last_hidden_state
+        return self.classifier(x)
+
+
+def finetune_loss(predict, target, loss_mask, seq):
+    """FinetuneTrainer.compute_loss, finetune.py:121-129; predict (..., C)."""
+    loss = torch.nn.functional.cross_entropy(predict.reshape(-1, predict.shape[-1]), target.reshape(-1), reduction='none').reshape(target.shape)
+    if not seq:
+        return torch.sum(loss * loss_mask) / torch.sum(loss_mask)
+    return torch.sum(loss) / loss.shape[0]
+
+
 def loss_weights(e2w):
     """pretrain.py:185-189: weights are len(e2w[etype]) in *dict order*, applied to heads
     in classes order (SURVEY a-8)."""

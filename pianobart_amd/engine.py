@@ -283,7 +283,7 @@ class Engine:
                  c_f32=True, nb1=8, sA=(R * 256, 0), sB=(256, 0), sC=(R * self.d, 0))
 
     # ------------------------------------------------------------------ forward
-    def forward_hidden(self, enc16, dec16, emask, dmask, train, seed, reuse_encoder=False):
+    def forward_hidden(self, enc16, dec16, emask, dmask, train, seed, reuse_encoder=False, dec_embeds=None):
         """enc16/dec16: (B,S,8) int16 device; masks (B,S) f32 or None. Returns (dec_hidden, enc_hidden) in storage dtype."""
         B, S = enc16.shape[:2]
         if S > self.Smax:
@@ -319,11 +319,21 @@ class Engine:
             ops.add_ln_fwd(L['y1'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('enc', l, 1), p)
             x = L['y2']
         enc_out = x if not reuse_encoder else (ws['enc'][-1]['y2'] if self.NE else x)
-        if dec16 is None:
+        if dec16 is None and dec_embeds is None:
             return None, enc_out
         y = ws['x_dec']
-        ops.embed_ln_fwd(dec16, self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], wf['dec.lne.b'], y, ws['md'], ws['rd'], S,
-                         LN_EPS, seed, self._site('dec_emb'), p, padded=True)
+        if dec_embeds is None:
+            ops.embed_ln_fwd(dec16, self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], wf['dec.lne.b'], y, ws['md'], ws['rd'], S,
+                             LN_EPS, seed, self._site('dec_emb'), p, padded=True)
+        else:
+            # decoder_inputs_embeds supplied by the caller (velocity task's label embedding, PianoBart.py:65-66): BART adds the
+            # learned positions (offset 2), applies layernorm_embedding, then dropout (modeling_bart.py, BartDecoder.forward)
+            ws['alt_pos'] = wf['dec.pos'][2:2 + S].to(self.xdt).unsqueeze(0).expand(B, S, d).reshape(T, d).contiguous()
+            ws['alt_e'] = dec_embeds
+            pre = y if p == 0.0 else ws.setdefault('x_dec_pre', torch.empty_like(y))
+            ops.add_ln_fwd(ws['alt_pos'], dec_embeds, wf['dec.lne.w'], wf['dec.lne.b'], pre, ws['md'], ws['rd'], LN_EPS, 0, 0, 0.0)
+            if p > 0.0:
+                ops.dropout(pre, y, seed, self._site('dec_emb'), p)
         for l in range(self.ND):
             L, pf = ws['dec'][l], 'dec.%d.' % l
             self._linear(y, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
@@ -339,7 +349,8 @@ class Engine:
             self._linear(L['g'], pf + 'w2', pf + 'b2', L['a2'], T, d, self.fd)
             ops.add_ln_fwd(L['yc'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('dec', l, 2), p)
             y = L['y2']
-        self._saved = dict(enc16=enc16, dec16=dec16, emask=emask, dmask=dmask, p=p, seed=seed, enc_out=enc_out, dec_out=y, B=B, S=S)
+        self._saved = dict(enc16=enc16, dec16=dec16, emask=emask, dmask=dmask, p=p, seed=seed, enc_out=enc_out, dec_out=y, B=B, S=S,
+                           alt=dec_embeds is not None)
         return y, enc_out
 
     def heads_forward(self, dec_hidden):
@@ -443,11 +454,23 @@ class Engine:
                 self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
                 cur = g2
                 self._ready(pf + 'wqkv', pf + 'w2')
-            ops.embed_ln_bwd(cur, sv['dec16'], self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], ws['md'], ws['rd'], self.dptab,
-                             g['dec.pos'], g['lin.b'], g['dec.lne.w'], g['dec.lne.b'], self.partials, S, seed, self._site('dec_emb'), p,
-                             dz_out=ws['dz'][T:] if onehot_route else None, padded=True)
-            if onehot_route:
-                ops.batch_sum(ws['dz'][T:], g['dec.pos'][2:2 + S], B, S * d)
+            if sv.get('alt'):
+                gpre = cur
+                if p > 0.0:
+                    gpre = gy if cur is not gy else galt
+                    ops.dropout(cur, gpre, seed, self._site('dec_emb'), p)
+                dz = ws.setdefault('alt_dz', torch.empty(T, d, dtype=self.xdt, device=self.device))
+                scratch = ws.setdefault('alt_db', torch.zeros(d, dtype=torch.float32, device=self.device))
+                ops.add_ln_bwd(gpre, ws['alt_pos'], ws['alt_e'], wf['dec.lne.w'], ws['md'], ws['rd'], dz, None, g['dec.lne.w'], g['dec.lne.b'],
+                               scratch, self.partials, False, 0, 0, 0.0)
+                ops.batch_sum(dz, g['dec.pos'][2:2 + S], B, S * d)
+                self._alt_grad = dz                                       # gradient wrt the supplied decoder_inputs_embeds
+            else:
+                ops.embed_ln_bwd(cur, sv['dec16'], self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], ws['md'], ws['rd'], self.dptab,
+                                 g['dec.pos'], g['lin.b'], g['dec.lne.w'], g['dec.lne.b'], self.partials, S, seed, self._site('dec_emb'), p,
+                                 dz_out=ws['dz'][T:] if onehot_route else None, padded=True)
+                if onehot_route:
+                    ops.batch_sum(ws['dz'][T:], g['dec.pos'][2:2 + S], B, S * d)
             cur = genc
             if gy_enc_extra is not None:
                 cur = genc.add_(gy_enc_extra)
@@ -473,8 +496,9 @@ class Engine:
             # dP = Onehot^T dz over the encoder AND decoder tokens in one split-K MFMA GEMM (K = 2T): no atomics
             ops.batch_sum(ws['dz'][:T], g['enc.pos'][2:2 + S], B, S * d)
             ops.onehot_build(sv['enc16'], ws['onehot'][:T], padded=True)
-            K2 = 2 * T if gy_dec is not None else T
-            if gy_dec is not None:
+            dec_tab = gy_dec is not None and not sv.get('alt')          # a caller-supplied decoder embedding has no Octuple rows to scatter into
+            K2 = 2 * T if dec_tab else T
+            if dec_tab:
                 ops.onehot_build(sv['dec16'], ws['onehot'][T:], padded=True)
             need = 16 * ops.TAB_TOTAL * d
             if self._slabs is None or self._slabs.numel() < need:
@@ -540,13 +564,13 @@ class Engine:
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
         return _LMFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, *self.params)
 
-    def module_forward_hidden(self, enc_ids, dec_ids, emask, dmask, training):
+    def module_forward_hidden(self, enc_ids, dec_ids, emask, dmask, training, dec_embeds=None):
         if enc_ids.device.type != 'cuda':
             raise PBError('pianobart_amd needs HIP device tensors (got %s); there is no CPU path' % enc_ids.device)
         self.bind(enc_ids.device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
         n_backbone = len(self.params) - (16 if self.mlm is not None else 0)
-        out = _HiddenFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, *self.params[:n_backbone])
+        out = _HiddenFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, dec_embeds, *self.params[:n_backbone])
         return out
 
     # ------------------------------------------------------------------ fused pre-train step (bench / Pretrainer)
@@ -782,18 +806,20 @@ class _HiddenFn(torch.autograd.Function):
     """PianoBart.forward (hidden states, f32 views for API compatibility)."""
 
     @staticmethod
-    def forward(ctx, eng, enc_ids, dec_ids, emask, dmask, training, need_grad, *params):
+    def forward(ctx, eng, enc_ids, dec_ids, emask, dmask, training, need_grad, dec_embeds, *params):
         enc16, dec16, em, dm = eng._prep_inputs(enc_ids, dec_ids, emask, dmask)
         B, S = enc16.shape[:2]
         seed = eng._next_seed() if training else 0
-        dec_h, enc_h = eng.forward_hidden(enc16, dec16, em, dm, training, seed)
-        if dec16 is None:
+        de = None if dec_embeds is None else dec_embeds.detach().reshape(B * S, eng.d).to(eng.xdt).contiguous()
+        dec_h, enc_h = eng.forward_hidden(enc16, dec16, em, dm, training, seed, dec_embeds=de)
+        ctx.alt_shape = None if dec_embeds is None else dec_embeds.shape
+        if dec16 is None and de is None:
             eng._saved = dict(enc16=enc16, dec16=None, emask=em, dmask=None, p=eng.p_drop if training else 0.0, seed=seed,
                               enc_out=enc_h, dec_out=None, B=B, S=S)
         eng._fwd_token += 1
-        ctx.eng, ctx.token, ctx.has_dec, ctx.nparams = eng, eng._fwd_token, dec16 is not None, len(params)
+        ctx.eng, ctx.token, ctx.has_dec, ctx.nparams = eng, eng._fwd_token, (dec16 is not None or de is not None), len(params)
         enc_o = enc_h.float().view(B, S, eng.d).clone() if enc_h.dtype == torch.float32 else enc_h.float().view(B, S, eng.d)
-        if dec16 is None:
+        if not ctx.has_dec:
             return torch.zeros(0, device=enc_o.device), enc_o
         dec_o = dec_h.float().view(B, S, eng.d).clone() if dec_h.dtype == torch.float32 else dec_h.float().view(B, S, eng.d)
         return dec_o, enc_o
@@ -816,4 +842,5 @@ class _HiddenFn(torch.autograd.Function):
             eng.backward(None, conv(d_enc))
         grads = eng.grad_views_of(eng.Gcur)[:ctx.nparams]
         eng._select_grads(False)
-        return (None,) * 7 + tuple(grads)
+        d_embeds = eng._alt_grad.float().view(ctx.alt_shape) if ctx.alt_shape is not None else None
+        return (None,) * 7 + (d_embeds,) + tuple(grads)

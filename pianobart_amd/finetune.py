@@ -1,0 +1,280 @@
+"""Fine-tune driver for the classification tasks: counterpart of the reference's finetune.py (`get_args_finetune`
+:14-72, `FinetuneTrainer` :75-256, `load_data_finetune` :259-330) and main.finetune() (main.py:103-215) on top of the HIP backbone.
+
+Same flags, same batch semantics (decoder input = encoder input for the melody task and for sequence tasks, model.py:203 /
+finetune.py:197-198), same loss (masked mean of per-token CE, or mean over the batch for sequence tasks), same accuracy
+bookkeeping, checkpoint dict keys and log line. Differences: one process per GPU instead of nn.DataParallel; the backbone is
+stepped by the engine's fused HF-AdamW on its flat buffers and the head parameters by the same kernel on a second flat buffer
+(the reference builds ONE transformers.AdamW over model.parameters(); it does not clip in fine-tune, finetune.py:227).
+The velocity task's decoder label-embedding swap goes through PianoBart.change_decoder_embedding as in the reference."""
+import argparse
+import os
+import shutil
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import heads, ops
+from ._lib import PBError
+from .model import SequenceClassification, TokenClassification
+
+
+def get_args_finetune(argv=None):
+    parser = argparse.ArgumentParser(description='')
+    parser.add_argument('--task', choices=['melody', 'velocity', 'composer', 'emotion'], required=True)
+    parser.add_argument('--dataset', type=str, choices=('asap', 'Pianist8', 'POP909', 'EMOPIA', 'GiantMIDI1k'), required=True)
+    parser.add_argument('--dataroot', type=str, default=None)
+    parser.add_argument('--dict_file', type=str, default='./Data/Octuple.pkl')
+    parser.add_argument('--name', type=str, default='pianobart')
+    parser.add_argument('--ckpt', default='result/pretrain/pianobart/model_best.ckpt')
+    parser.add_argument('--num_workers', type=int, default=5)
+    parser.add_argument('--class_num', type=int, default=None)
+    parser.add_argument('--batch_size', type=int, default=8)
+    parser.add_argument('--max_seq_len', type=int, default=1024, help='all sequences are padded to `max_seq_len`')
+    parser.add_argument('--hs', type=int, default=1024)
+    parser.add_argument('--layers', type=int, default=8)
+    parser.add_argument('--ffn_dims', type=int, default=2048)
+    parser.add_argument('--heads', type=int, default=8)
+    parser.add_argument('--epochs', type=int, default=50, help='number of training epochs')
+    parser.add_argument('--lr', type=float, default=2e-5, help='initial learning rate')
+    parser.add_argument('--nopretrain', action='store_true')
+    parser.add_argument('--cpu', action='store_true')
+    parser.add_argument('--cuda_devices', type=int, nargs='+', default=[2, 5, 6], help='CUDA device ids')
+    parser.add_argument('--weight', type=float, default=None, help='weight of regularization')
+    parser.add_argument('--error_correction', action='store_true')
+    parser.add_argument('--precision', choices=['bf16', 'fp32'], default='bf16', help='backbone arithmetic (not in the reference)')
+    args = parser.parse_args(argv)
+    if args.class_num is None:
+        args.class_num = {'melody': 4, 'velocity': 7, 'composer': 8, 'emotion': 4}[args.task]
+    return args
+
+
+class FinetuneDataset(Dataset):
+    """dataset.py:19-32."""
+
+    def __init__(self, X, y):
+        self.data, self.label = X, y
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, index):
+        return torch.tensor(self.data[index]), torch.tensor(self.label[index])
+
+
+def load_data_finetune(dataset, task, data_root=None):
+    """finetune.py:259-330 (the classification branch; `gen` lives in finetune_generation.py)."""
+    if data_root is None:
+        data_root = 'Data/finetune/others'
+    if dataset == 'emotion':
+        dataset = 'emopia'
+    if dataset not in ['POP909', 'pop909', 'composer', 'EMOPIA', 'asap', 'Pianist8', 'maestro', 'GiantMIDI1k']:
+        print(f'Dataset {dataset} not supported')
+        exit(1)
+    ld = lambda name: np.load(os.path.join(data_root, name), allow_pickle=True)
+    X_train, X_val, X_test = ld(f'{dataset}_train.npy'), ld(f'{dataset}_valid.npy'), ld(f'{dataset}_test.npy')
+    print('X_train: {}, X_valid: {}, X_test: {}'.format(X_train.shape, X_val.shape, X_test.shape))
+    y_train, y_val, y_test = ld(f'{dataset}_train_ans.npy'), ld(f'{dataset}_valid_ans.npy'), ld(f'{dataset}_test_ans.npy')
+    print('y_train: {}, y_valid: {}, y_test: {}'.format(y_train.shape, y_val.shape, y_test.shape))
+    return X_train, X_val, X_test, y_train, y_val, y_test
+
+
+class HeadAdamW:
+    """HF AdamW (eps added before the bias correction, decay after the update: SURVEY 8a-11) over the head parameters, which are
+    re-homed as views of one flat f32 buffer so that a step is one pb_adamw_step launch."""
+
+    def __init__(self, params, lr, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        n = sum((p.numel() + 3) // 4 * 4 for p in self.params)
+        self.P, self.G = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.views, o = [], 0
+        for p in self.params:
+            v = self.P[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            self.views.append((o, p.numel()))
+            o += (p.numel() + 3) // 4 * 4
+        self.lr, self.wd, self.betas, self.eps, self.t = lr, weight_decay, betas, eps, 0
+
+    def step(self):
+        self.t += 1
+        for p, (o, n) in zip(self.params, self.views):
+            if p.grad is None:
+                self.G[o:o + n].zero_()
+            else:
+                self.G[o:o + n].copy_(p.grad.reshape(-1))
+        ops.adamw_step(self.P, self.G, self.m, self.v, None, None, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+
+class FinetuneTrainer:
+    def __init__(self, pianobart, train_dataloader, valid_dataloader, test_dataloader, lr, class_num, hs, testset_shape, cpu,
+                 cuda_devices=None, model=None, SeqClass=False, error=False, weight=None):
+        if cpu or not torch.cuda.is_available():
+            raise PBError('pianobart_amd has no CPU execution path')
+        if cuda_devices is not None and len(cuda_devices) > 1:
+            raise PBError('nn.DataParallel is replaced by one process per GPU (torch.distributed.run)')
+        if weight is not None:
+            raise PBError('--weight (L2 penalty through autograd on every parameter, finetune.py:219-221) is not built')
+        self.device = torch.device('cuda', cuda_devices[0] if cuda_devices else 0)
+        print('   device:', self.device)
+        self.pianobart, self.SeqClass, self.class_num = pianobart, SeqClass, class_num
+        if model is not None:
+            print('load a fine-tuned model')
+            self.model = model.to(self.device)
+        else:
+            print('init a fine-tune model, sequence-level task?', SeqClass)
+            self.model = (SequenceClassification(pianobart, class_num, hs) if SeqClass else TokenClassification(pianobart, class_num + 1, hs)).to(self.device)
+        print('Use GPU', self.device)
+        self.engine = pianobart._get_engine()
+        self.engine.bind(self.device)
+        self.train_data, self.valid_data, self.test_data = train_dataloader, valid_dataloader, test_dataloader
+        in_engine = {id(p) for p in self.engine.params}              # everything else (heads, swapped decoder label embedding) is stepped here
+        self.head_optim = HeadAdamW([p for p in self.model.parameters() if id(p) not in in_engine], lr=lr, weight_decay=0.01)
+        self.lr = lr
+        self.testset_shape = testset_shape if not error else testset_shape[:-1]
+        self.error = error
+
+    def compute_loss(self, predict, target, loss_mask, seq):
+        """finetune.py:121-129; predict (..., C) (the reference permutes to (B, C, S) for nn.CrossEntropyLoss)."""
+        loss = heads.cross_entropy_rows(predict, target)
+        if not seq:
+            return torch.sum(loss * loss_mask) / torch.sum(loss_mask)
+        return torch.sum(loss) / loss.shape[0]
+
+    def train(self):
+        self.model.train()
+        return self.iteration(self.train_data, 0, self.SeqClass)
+
+    def valid(self):
+        self.model.eval()
+        return self.iteration(self.valid_data, 1, self.SeqClass)
+
+    def test(self):
+        self.model.eval()
+        return self.iteration(self.test_data, 2, self.SeqClass)
+
+    def iteration(self, training_data, mode, seq):
+        total_acc, total_cnt, total_loss = 0.0, 0, 0.0
+        self.model.train(mode == 0)
+        all_output, cnt = (torch.empty(self.testset_shape) if mode == 2 else None), 0
+        with torch.set_grad_enabled(mode == 0):
+            for x, y in training_data:
+                batch = x.shape[0]
+                x, y = x.to(self.device).long(), y.to(self.device).long()
+                if self.error:
+                    y = torch.squeeze(y, dim=-1)
+                attn = (x[:, :, 0] != self.pianobart.bar_pad_word).float()
+                if seq:
+                    y_hat = self.model(input_ids_encoder=x, encoder_attention_mask=attn)
+                else:
+                    if self.class_num >= 5:                              # velocity: labels shifted right, class_num = the pad label
+                        y_shift = torch.zeros_like(y) + self.class_num
+                        y_shift[:, 1:] = y[:, :-1]
+                        attn_shift = torch.zeros_like(attn)
+                        attn_shift[:, 1:] = attn[:, :-1]
+                        attn_shift[:, 0] = attn[:, 0]
+                    else:
+                        y_shift, attn_shift = x, attn
+                    y_hat = self.model(input_ids_encoder=x, input_ids_decoder=y_shift, encoder_attention_mask=attn, decoder_attention_mask=attn_shift)
+                output = torch.from_numpy(np.argmax(y_hat.detach().cpu().numpy(), axis=-1)).to(self.device)
+                if mode == 2:
+                    all_output[cnt:cnt + batch] = output.cpu()
+                    cnt += batch
+                if not seq:
+                    total_acc += float(torch.sum((y == output).float() * attn))
+                    total_cnt += float(torch.sum(attn))
+                else:
+                    total_acc += float(torch.sum((y == output).float()))
+                    total_cnt += y.shape[0]
+                loss = self.compute_loss(y_hat, y, attn, seq)
+                total_loss += float(loss)
+                if mode == 0:
+                    self.model.zero_grad()
+                    self.head_optim.zero_grad()
+                    loss.backward()
+                    self.engine.optimizer_step(lr=self.lr, max_norm=float('inf'))          # no clipping in fine-tune (finetune.py:227)
+                    self.head_optim.step()
+        res = (round(total_loss / len(training_data), 4), round(total_acc / total_cnt, 4))
+        return res + (all_output,) if mode == 2 else res
+
+    def save_checkpoint(self, epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename):
+        state = {'epoch': epoch + 1, 'state_dict': self.model.state_dict(), 'valid_acc': valid_acc, 'valid_loss': valid_loss,
+                 'train_loss': train_loss, 'train_acc': train_acc,
+                 'optimizer': {'backbone_step': self.engine.step_count, 'head_step': self.head_optim.t}}
+        torch.save(state, filename)
+        if is_best:
+            shutil.copyfile(filename, filename.split('.')[0] + '_best.ckpt')
+
+
+def finetune(argv=None):
+    """main.py:103-215."""
+    import pickle
+    import random
+    from torch.utils.data import DataLoader
+    from .model import BartConfig, PianoBart
+    seed = 2023
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    args = get_args_finetune(argv)
+    print('Loading Dictionary')
+    with open(args.dict_file, 'rb') as f:
+        e2w, w2e = pickle.load(f)
+    print('\\nLoading Dataset')
+    seq_class = args.task in ('composer', 'emotion')
+    X_train, X_val, X_test, y_train, y_val, y_test = load_data_finetune(args.dataset, args.task, args.dataroot)
+    mk = lambda X, y, sh: DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=sh)
+    train_loader, valid_loader, test_loader = mk(X_train, y_train, True), mk(X_val, y_val, False), mk(X_test, y_test, False)
+    print('   len of train_loader', len(train_loader))
+    print('   len of valid_loader', len(valid_loader))
+    print('   len of valid_loader', len(test_loader))
+    print('\\nBuilding BART model')
+    configuration = BartConfig(max_position_embeddings=args.max_seq_len, d_model=args.hs, encoder_layers=args.layers, encoder_ffn_dim=args.ffn_dims,
+                               encoder_attention_heads=args.heads, decoder_layers=args.layers, decoder_ffn_dim=args.ffn_dims,
+                               decoder_attention_heads=args.heads)
+    pianobart = PianoBart(bartConfig=configuration, e2w=e2w, w2e=w2e, precision=args.precision)
+    best_mdl = ''
+    if not args.nopretrain:
+        best_mdl = args.ckpt
+        print('   Loading pre-trained model from', best_mdl.split('/')[-1])
+        pianobart.load_state_dict(torch.load(best_mdl, map_location='cpu')['state_dict'])
+    print('\\nCreating Finetune Trainer')
+    trainer = FinetuneTrainer(pianobart, train_loader, valid_loader, test_loader, args.lr, args.class_num, args.hs, y_test.shape, args.cpu,
+                              args.cuda_devices[:1], None, seq_class, args.error_correction, args.weight)
+    print('\\nTraining Start')
+    save_dir = os.path.join('result/finetune/', args.task + '_' + args.name)
+    os.makedirs(save_dir, exist_ok=True)
+    filename = os.path.join(save_dir, 'model.ckpt')
+    print('   save model at {}'.format(filename))
+    best_acc, best_epoch, bad_cnt = 0, 0, 0
+    with open(os.path.join(save_dir, 'log'), 'a') as outfile:
+        outfile.write('Loading pre-trained model from ' + best_mdl.split('/')[-1] + '\\n')
+        for epoch in range(args.epochs):
+            train_loss, train_acc = trainer.train()
+            valid_loss, valid_acc = trainer.valid()
+            test_loss, test_acc, _ = trainer.test()
+            is_best = valid_acc >= best_acc
+            best_acc = max(valid_acc, best_acc)
+            if is_best:
+                bad_cnt, best_epoch = 0, epoch
+            else:
+                bad_cnt += 1
+            print('epoch: {}/{} | Train Loss: {} | Train acc: {} | Valid Loss: {} | Valid acc: {} | Test loss: {} | Test acc: {}'.format(
+                epoch + 1, args.epochs, train_loss, train_acc, valid_loss, valid_acc, test_loss, test_acc))
+            trainer.save_checkpoint(epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename)
+            outfile.write('Epoch {}: train_loss={}, valid_loss={}, test_loss={}, train_acc={}, valid_acc={}, test_acc={}\\n'.format(
+                epoch + 1, train_loss, valid_loss, test_loss, train_acc, valid_acc, test_acc))
+            if bad_cnt > 3:
+                print('valid acc not improving for 3 epochs')
+                break
+
+
+if __name__ == '__main__':
+    finetune()

@@ -181,9 +181,16 @@ class PianoBart(nn.Module):
 
     def forward(self, input_ids_encoder, input_ids_decoder=None, encoder_attention_mask=None,
                 decoder_attention_mask=None, output_hidden_states=True, generate=False):
-        if self.decoder_emb is not None:
-            raise PBError('change_decoder_embedding() path (TokenClassification) is outside the hot-path scope (SURVEY 8f-3)')
         eng = self._get_engine()
+        if self.decoder_emb is not None and input_ids_decoder is not None:
+            # PianoBart.py:65-66,71: decoder_linear(decoder_emb(labels)) with Embeddings = lut(x) * sqrt(d_model) -- computed as a
+            # row gather from the projected label table sqrt(d_model) * lut @ W^T (n_labels x d), differentiable in lut, W and b
+            from . import heads
+            table = heads.linear(self.decoder_emb.lut.weight, self.decoder_linear.weight, None, alpha=math.sqrt(self.decoder_emb.d_model))
+            e = heads.gather_rows(table, input_ids_decoder, self.decoder_linear.bias)
+            dec_h, enc_h = eng.module_forward_hidden(input_ids_encoder, None, encoder_attention_mask, decoder_attention_mask, self.training,
+                                                     dec_embeds=e)
+            return SimpleNamespace(last_hidden_state=dec_h, encoder_last_hidden_state=enc_h)
         dec_h, enc_h = eng.module_forward_hidden(input_ids_encoder, input_ids_decoder, encoder_attention_mask,
                                                  decoder_attention_mask, self.training)
         if input_ids_decoder is None:
@@ -287,3 +294,84 @@ class PianoBartLM(nn.Module):
     def sample(self, x, index):
         t, p = self.SAMPLE_T, self.SAMPLE_P
         return torch.tensor([sampling(x[j][:, index, :], p[j], t[j]) for j in range(8)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fine-tune heads. Same constructor arguments, attribute names and state_dict keys as the reference
+# (model.py:128-272); the nn.Linear / nn.Sequential members are parameter holders, the arithmetic runs through the HIP ops of
+# heads.py (exact f32 on top of the backbone's hidden states).
+class SelfAttention(nn.Module):
+    """model.py:128-143: r-aspect attention pooling weights, softmax over the sequence axis."""
+
+    def __init__(self, input_dim, da, r):
+        super().__init__()
+        self.ws1 = nn.Linear(input_dim, da, bias=False)
+        self.ws2 = nn.Linear(da, r, bias=False)
+
+    def scores(self, h):
+        """softmax(ws2(tanh(ws1(h))), dim=1): (B, S, r), i.e. attn_mat before the reference's permute(0, 2, 1)."""
+        from . import heads
+        return heads.softmax_dim1(heads.linear(heads.act(heads.linear(h, self.ws1.weight), 'tanh'), self.ws2.weight))
+
+    def forward(self, h):
+        return self.scores(h).permute(0, 2, 1)
+
+
+class SequenceClassification(nn.Module):
+    """model.py:165-218: the backbone is run with decoder input = encoder input (model.py:203), attention-pooled into r = 4
+    aspects, flattened and classified by Dropout(0.1) -> Linear(hs r, 256) -> ReLU -> Linear(256, class_num)."""
+
+    def __init__(self, pianobart, class_num, hs, da=128, r=4):
+        super().__init__()
+        self.pianobart = pianobart
+        self.attention = SelfAttention(hs, da, r)
+        self.classifier = nn.Sequential(nn.Dropout(0.1), nn.Linear(hs * r, 256), nn.ReLU(), nn.Linear(256, class_num))
+
+    def forward(self, input_ids_encoder, encoder_attention_mask=None):
+        from . import heads
+        x = self.pianobart(input_ids_encoder=input_ids_encoder, input_ids_decoder=input_ids_encoder,
+                           encoder_attention_mask=encoder_attention_mask, decoder_attention_mask=encoder_attention_mask).last_hidden_state
+        m = heads.pool(self.attention.scores(x), x)                     # torch.bmm(attn_mat, x): (B, r, hs)
+        flat = m.reshape(m.shape[0], -1)
+        c = self.classifier
+        y = heads.dropout(flat, c[0].p, self.training)
+        y = heads.act(heads.linear(y, c[1].weight, c[1].bias), 'relu')
+        return heads.linear(y, c[3].weight, c[3].bias)
+
+
+class Excitation(nn.Module):
+    """model.py:220-232 (squeeze-excitation gate; commented out of both classifiers in the reference, kept for API parity)."""
+
+    def __init__(self, channel_dim, reduction=16):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(channel_dim, channel_dim // reduction), nn.ReLU(), nn.Linear(channel_dim // reduction, channel_dim), nn.Sigmoid())
+
+    def forward(self, x):
+        from . import heads
+        y = heads.act(heads.linear(x, self.fc[0].weight, self.fc[0].bias), 'relu')
+        y = heads.act(heads.linear(y, self.fc[2].weight, self.fc[2].bias), 'sigmoid')
+        return heads.mul(x, y)
+
+
+class TokenClassification(nn.Module):
+    """model.py:236-272: per-token Dropout(0.1) -> Linear(hs, 256) -> ReLU -> Linear(256, class_num) on the decoder's hidden states.
+    class_num >= 5 (the velocity task) swaps the decoder's input embedding for a class-label embedding of width 64 and its own
+    Linear(64, d) (PianoBart.change_decoder_embedding, model.py:242-245); input_ids_decoder is then (B, S) labels."""
+
+    def __init__(self, pianobart, class_num, hs, d_model=64):
+        super().__init__()
+        self.pianobart = pianobart
+        if class_num >= 5:
+            new_embedding = Embeddings(n_token=class_num, d_model=d_model)
+            new_linear = nn.Linear(d_model, pianobart.bartConfig.d_model)
+            self.pianobart.change_decoder_embedding(new_embedding, new_linear)
+        self.classifier = nn.Sequential(nn.Dropout(0.1), nn.Linear(hs, 256), nn.ReLU(), nn.Linear(256, class_num))
+
+    def forward(self, input_ids_encoder, input_ids_decoder, encoder_attention_mask=None, decoder_attention_mask=None):
+        from . import heads
+        x = self.pianobart(input_ids_encoder, input_ids_decoder, encoder_attention_mask, decoder_attention_mask).last_hidden_state
+        c = self.classifier
+        y = heads.dropout(x, c[0].p, self.training)
+        y = heads.act(heads.linear(y, c[1].weight, c[1].bias), 'relu')
+        return heads.linear(y, c[3].weight, c[3].bias)
+

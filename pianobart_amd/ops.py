@@ -214,3 +214,39 @@ def corrupt(ids16, out16, loss_mask, choice, choice_out, mask_percent, seed, pad
 def key_extent(key_mask, kmax):
     B, Sk = key_mask.shape
     LIB.call('pb_key_extent', _p(key_mask), _p(kmax), B, Sk, _stream())
+
+
+# ---- K14: fine-tune heads (f32) ------------------------------------------------------------------------------------
+def eltwise_fwd(op, x, x2, y, seed, site, p):
+    LIB.call('pb_eltwise_fwd', op, _p(x), _p(x2), _p(y), x.numel(), seed, site, p, _stream())
+
+
+def eltwise_bwd(op, y, x2, dy, dx, dx2, seed, site, p):
+    LIB.call('pb_eltwise_bwd', op, _p(y), _p(x2), _p(dy), _p(dx), _p(dx2), dy.numel(), seed, site, p, _stream())
+
+
+def softmax_dim1_fwd(x, y):
+    B, S, R = x.shape
+    LIB.call('pb_softmax_dim1_fwd', _p(x), _p(y), B, S, R, _stream())
+
+
+def softmax_dim1_bwd(y, dy, dx):
+    B, S, R = y.shape
+    LIB.call('pb_softmax_dim1_bwd', _p(y), _p(dy), _p(dx), B, S, R, _stream())
+
+
+def ce_rows(logits, target32, weight, coef, loss, dlogits, argmax):
+    rows, C = logits.shape
+    LIB.call('pb_ce_rows', _p(logits), _p(target32), _p(weight), _p(coef), _p(loss), _p(dlogits), _p(argmax), rows, C, _stream())
+
+
+def gather_rows(table, ids32, bias, out):
+    LIB.call('pb_gather_rows', _p(table), _p(ids32), _p(bias), _p(out), ids32.numel(), table.shape[1], table.shape[0], _stream())
+
+
+def gather_rows_bwd(dout, ids32, dtable):
+    LIB.call('pb_gather_rows_bwd', _p(dout), _p(ids32), _p(dtable), ids32.numel(), dtable.shape[1], dtable.shape[0], _stream())
+
+
+def dropout(x, y, seed, site, p):
+    LIB.call('pb_dropout', _p(x), _p(y), x.numel(), dtype_code(x.dtype), seed, site, p, _stream())

@@ -1,0 +1,116 @@
+"""fine-tune heads (SequenceClassification, TokenClassification incl. the velocity task's decoder label-embedding swap)
+against G12, the logits / loss / gradients of the REAL reference (oracle/make_goldens.py g12). CPU: the oracle restatement is pinned to
+G12. GPU: the product path (HIP ops through autograd) is compared with G12 in both precisions, and FinetuneTrainer runs end to end."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load_vocab, randomize_params, sd_checksum, synth_octuple_batch
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+E2W, W2E = load_vocab()
+S, D, L, F, H = 64, 128, 2, 256, 4
+KW = dict(max_position_embeddings=S, d_model=D, encoder_layers=L, decoder_layers=L, encoder_ffn_dim=F, decoder_ffn_dim=F,
+          encoder_attention_heads=H, decoder_attention_heads=H, dropout=0.0)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _build(mod, cfgcls, pbcls, tag, **pbkw):
+    pb = pbcls(cfgcls(**KW), E2W, W2E, **pbkw)
+    m = {'seq': lambda: mod.SequenceClassification(pb, 8, D), 'tok4': lambda: mod.TokenClassification(pb, 4, D),
+         'tok8': lambda: mod.TokenClassification(pb, 8, D)}[tag]()
+    randomize_params(m, 31)
+    for x in m.modules():
+        if isinstance(x, torch.nn.Dropout):
+            x.p = 0.0
+    return m.train()
+
+
+def _run(m, z, tag, dev, lossf):
+    enc = torch.from_numpy(z['enc']).long().to(dev); emask = torch.from_numpy(z['emask']).to(dev)
+    y = torch.from_numpy(z[tag + '_y']).to(dev)
+    if tag == 'seq':
+        yh = m(input_ids_encoder=enc, encoder_attention_mask=emask)
+        return yh, lossf(yh, y, None, True)
+    if tag == 'tok4':
+        yh = m(input_ids_encoder=enc, input_ids_decoder=enc, encoder_attention_mask=emask, decoder_attention_mask=emask)
+    else:
+        yh = m(input_ids_encoder=enc, input_ids_decoder=torch.from_numpy(z['tok8_y_shift']).to(dev), encoder_attention_mask=emask,
+               decoder_attention_mask=torch.from_numpy(z['tok8_attn_shift']).to(dev))
+    return yh, lossf(yh, y, emask, False)
+
+
+def _check(m, z, tag, yh, loss, tol_logits, tol_grad):
+    assert _rel(yh.detach(), torch.from_numpy(z[tag + '_logits'])) < tol_logits
+    assert abs(float(loss) - float(z[tag + '_loss'])) < max(tol_logits, 1e-5) * abs(float(z[tag + '_loss'])) * 10
+    m.zero_grad()
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    for i, k in enumerate(z[tag + '_grad_names']):
+        r = _rel(grads[str(k)], torch.from_numpy(z['%s_grad_%d' % (tag, i)]))
+        assert r < tol_grad, (tag, str(k), r)
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    assert abs(gn - float(z[tag + '_gnorm'])) < tol_grad * float(z[tag + '_gnorm'])
+
+
+@pytest.mark.parametrize('tag', ['seq', 'tok4', 'tok8'])
+def test_oracle_heads_match_reference_golden(tag):
+    from oracle import pianobart_oracle as O
+    z = np.load(os.path.join(GOLD, 'g12_finetune_heads.npz'))
+    m = _build(O, O.BartConfig, O.PianoBart, tag)
+    assert sd_checksum(m.state_dict()) == str(z[tag + '_sd'])         # same weights as the reference run
+    yh, loss = _run(m, z, tag, 'cpu', O.finetune_loss)
+    _check(m, z, tag, yh, loss, 2e-5, 5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,tol_logits,tol_grad', [('fp32', 1e-4, 2e-3), ('bf16', 6e-2, 2e-1)])
+@pytest.mark.parametrize('tag', ['seq', 'tok4', 'tok8'])
+def test_heads_match_reference_golden(tag, precision, tol_logits, tol_grad):
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a HIP device')
+    from pianobart_amd import model as M
+    from pianobart_amd.finetune import FinetuneTrainer
+    z = np.load(os.path.join(GOLD, 'g12_finetune_heads.npz'))
+    m = _build(M, M.BartConfig, M.PianoBart, tag, precision=precision)
+    assert sd_checksum(m.state_dict()) == str(z[tag + '_sd'])         # state_dict keys / shapes / values identical to the reference's
+    m = m.cuda()
+    lossf = lambda yh, y, mask, seq: FinetuneTrainer.compute_loss(None, yh, y, mask, seq)
+    yh, loss = _run(m, z, tag, 'cuda', lossf)
+    _check(m, z, tag, yh, loss, tol_logits, tol_grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('task', ['composer', 'velocity'])
+def test_finetune_trainer_end_to_end(task):
+    """FinetuneTrainer train / valid / test on a synthetic set: runs, learns (the loss of a memorisable 8-sample set drops),
+    returns the reference's tuple shapes, and steps backbone AND head parameters."""
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a HIP device')
+    from torch.utils.data import DataLoader
+    from pianobart_amd import model as M
+    from pianobart_amd.finetune import FinetuneDataset, FinetuneTrainer
+    torch.manual_seed(0)
+    X = synth_octuple_batch(8, S, seed=3)[0].numpy()
+    seq = task == 'composer'
+    rng = np.random.default_rng(0)
+    y = rng.integers(0, 8, size=(8,)) if seq else rng.integers(0, 7, size=(8, S))
+    mk = lambda: DataLoader(FinetuneDataset(X, y), batch_size=4)
+    pb = M.PianoBart(M.BartConfig(**dict(KW, dropout=0.1)), E2W, W2E, precision='fp32')
+    tr = FinetuneTrainer(pb, mk(), mk(), mk(), lr=1e-3, class_num=8 if seq else 7, hs=D, testset_shape=y.shape, cpu=False, cuda_devices=[0], SeqClass=seq)
+    head_before = [p.detach().clone() for p in tr.head_optim.params]
+    bb_before = pb.bart.encoder.layers[0].fc1.weight.detach().clone()
+    l0, a0 = tr.train()
+    for _ in range(5):
+        l1, a1 = tr.train()
+    vl, va = tr.valid()
+    tl, ta, out = tr.test()
+    assert np.isfinite([l0, l1, vl, tl]).all() and l1 < l0
+    assert tuple(out.shape) == tuple(y.shape) and 0.0 <= ta <= 1.0
+    assert all(not torch.equal(a, b.detach()) for a, b in zip(head_before, tr.head_optim.params))
+    assert not torch.equal(bb_before, pb.bart.encoder.layers[0].fc1.weight.detach())
