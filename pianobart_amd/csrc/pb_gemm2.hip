@@ -112,14 +112,14 @@ __device__ __forceinline__ void load8(const bf16_t* p, f32x4& a, f32x4& b) {
 
 // 1-D grid over (split, tile) -> (m0, n0, split).
 template <int BM, int BN>
-__device__ __forceinline__ void block_tile(const Gemm2Args& p, int& m0, int& n0, int& zs) {
+__device__ __forceinline__ void block_tile(const Gemm2Args& p, int L, int& m0, int& n0, int& zs) {
     const int ntiles = p.tiles_m * p.tiles_n;
     // 1-D grid over (split, tile). XCD x (= id % 8) takes a CONTIGUOUS chunk of the (split-major, tile-minor) list, so with
     // split-K the workgroups of one XCD work on (nearly) one K slice: its A/B rows are fetched into that L2 once and
     // shared by all its tiles (wgrad measured ~2x its algorithmic bytes from beyond L2 with the tile-only remap).
     int bid;
     {
-        const int total = ntiles * p.nsplit, L = blockIdx.x;
+        const int total = ntiles * p.nsplit;
         const int q = total >> 3, r = total & 7, x = L & 7, idx = L >> 3;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
         zs = lin / ntiles; bid = lin - zs * ntiles;
@@ -142,7 +142,8 @@ __device__ __forceinline__ void block_tile(const Gemm2Args& p, int& m0, int& n0,
 // instruction, with bias / GELU / GELU-grad / accumulate applied in f32 in between. No LDS and no barrier: the f32 LDS
 // panel this replaces cost about a third of the store tail of a 256 x 256 tile, and its 8-byte stores another 6 %.
 template <int TM>
-__device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[TM][4], int mw /*wave's first row*/, int nw /*first column*/, long coff, int lane) {
+__device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[TM][4], int mw /*wave's first row*/, int nw /*first column*/, long coff, int lane,
+                                              const float* lds_bias = nullptr /*bias[nw ..] staged in LDS by the caller*/) {
     const int lr = lane & 15, lg = lane >> 4;
     const bool accum = p.flags & PB_GEMM_ACCUM, c32 = p.flags & PB_GEMM_C_F32;
     const bool do_gelu = p.flags & PB_GEMM_GELU, mul_gg = p.flags & PB_GEMM_MUL_GELU_GRAD;
@@ -155,8 +156,13 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
     for (int jp = 0; jp < 2; ++jp) {
         const int c = nw + jp * 32 + cb;
         const bool has = p.bias && c < p.N;
-        bv[jp][0] = has ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bv[jp][1] = has ? *reinterpret_cast<const f32x4*>(p.bias + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lds_bias) {
+            bv[jp][0] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[jp][1] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            bv[jp][0] = has ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[jp][1] = has ? *reinterpret_cast<const f32x4*>(p.bias + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int m0, n0, zs;
-    block_tile<BM, BN>(p, m0, n0, zs);
+    block_tile<BM, BN>(p, blockIdx.x, m0, n0, zs);
     const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
@@ -341,14 +347,18 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    // Persistent over the (split, tile) work list: workgroup b takes items b, b + grid, ... (grid = a multiple of 8, so an item's
+    // XCD chunk in block_tile stays the workgroup's XCD). The first DMA pieces of the NEXT item are issued right after the last
+    // barrier of the current one, i.e. before its epilogue: the ~2 us from first DMA to first MFMA hide under the store tail.
+    const int total = p.tiles_m * p.tiles_n * p.nsplit;
+    int L = blockIdx.x;
     int m0, n0, zs;
-    block_tile<256, 256>(p, m0, n0, zs);
+    block_tile<256, 256>(p, L, m0, n0, zs);
     const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
-    const long coff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
-    const int kbeg = zs * p.Kc, kend = min(p.K, kbeg + p.Kc);
-    const int nk = max(0, kend - kbeg) / BK;
+    int kbeg = zs * p.Kc;
+    int nk = max(0, min(p.K, kbeg + p.Kc) - kbeg) / BK;
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -410,51 +420,93 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 
-    if (nk > 0) {
-        G3_ISSUE_A(0, 0); G3_ISSUE_B(0, 0); G3_ISSUE_B(0, 1); G3_ISSUE_A(0, 1);
+    // the tile's 256 bias values ride along as one more DMA piece (wave 0, issued FIRST so that the counted waits, which spare
+    // only the youngest operations, never see it): an ordinary bias load in the epilogue would draw the compiler's vmcnt(0) and
+    // drain the next item's prologue. Two alternating 1 KiB slots above the stage ring: item i's epilogue reads while item i+1's
+    // piece lands.
+#define G3_PROLOGUE()                                                                                             \
+    do {                                                                                                          \
+        bslot ^= 1;                                                                                               \
+        if (p.bias && wave == 0) glds16(reinterpret_cast<const bf16_t*>(p.bias + min(n0 + lane * 4, p.N - 4)), smem + 2 * SLOT + bslot * 1024); \
+        if (nk > 0) { G3_ISSUE_A(0, 0); G3_ISSUE_B(0, 0); G3_ISSUE_B(0, 1); G3_ISSUE_A(0, 1); }                   \
+        if (nk > 1) { G3_ISSUE_A(1, 0); G3_ISSUE_B(1, 1); }                                                       \
+    } while (0)
+    int bslot = 0;
+    G3_PROLOGUE();
+    int pend = 0;                                                    // store instructions this wave left in flight behind the prologue
+    while (true) {
+        // K-tile 0 of this item must have landed. vmcnt counts loads, stores and DMA pieces in ONE in-order queue, and behind
+        // K-tile 0's pieces sit the 4 pieces of K-tile 1 and the `pend` stores of the previous item's epilogue (exactly 16 / 32
+        // per wave when that tile was interior and store-only; 0 = "unknown", which waits for the stores too): leave them flying.
         if (nk > 1) {
-            G3_ISSUE_A(1, 0); G3_ISSUE_B(1, 1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (pend == 32) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
+            else if (pend == 16) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
+            else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pend == 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
+            else if (pend == 16) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         }
-    }
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int sl = kt & 1;
-        // phase 0: quadrant (0,0)
-        G3_READ_B(sl, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        G3_READ_A(sl, 0);
-        if (kt + 1 < nk) G3_ISSUE_A(kt + 1, 1);
-        G3_MMA(0, 0, true, true);
-        // phase 1: quadrant (0,1)
-        G3_READ_B(sl, 1);
-        if (kt + 1 < nk) G3_ISSUE_B(kt + 1, 0);
-        G3_MMA(0, 1, false, true);
-        // phase 2: quadrant (1,1)
-        G3_READ_A(sl, 1);
-        if (kt + 2 < nk) G3_ISSUE_A(kt + 2, 0);
-        G3_MMA(1, 1, true, false);
-        // phase 3: quadrant (1,0)
-        G3_READ_B(sl, 0);
-        if (kt + 2 < nk) {
-            G3_ISSUE_B(kt + 2, 1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int sl = kt & 1;
+            // phase 0: quadrant (0,0)
+            G3_READ_B(sl, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            G3_READ_A(sl, 0);
+            if (kt + 1 < nk) G3_ISSUE_A(kt + 1, 1);
+            G3_MMA(0, 0, true, true);
+            // phase 1: quadrant (0,1)
+            G3_READ_B(sl, 1);
+            if (kt + 1 < nk) G3_ISSUE_B(kt + 1, 0);
+            G3_MMA(0, 1, false, true);
+            // phase 2: quadrant (1,1)
+            G3_READ_A(sl, 1);
+            if (kt + 2 < nk) G3_ISSUE_A(kt + 2, 0);
+            G3_MMA(1, 1, true, false);
+            // phase 3: quadrant (1,0)
+            G3_READ_B(sl, 0);
+            if (kt + 2 < nk) {
+                G3_ISSUE_B(kt + 2, 1);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            G3_MMA(1, 0, false, true);
         }
-        G3_MMA(1, 0, false, true);
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        // all LDS reads of this item are complete: both slots are free for the next item's first pieces
+        const int em0 = m0, en0 = n0;
+        const float* ebias = reinterpret_cast<const float*>(smem + 2 * SLOT + bslot * 1024) + wc * 64;
+        const long ecoff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
+        L += gridDim.x;
+        const bool more = L < total;
+        if (more) {
+            block_tile<256, 256>(p, L, m0, n0, zs);
+            kbeg = zs * p.Kc;
+            nk = max(0, min(p.K, kbeg + p.Kc) - kbeg) / BK;
+            G3_PROLOGUE();
+        }
+        if (!(p.flags & 128)) epilogue_regs<8>(p, acc, em0 + wr * 128, en0 + wc * 64, ecoff, lane, ebias);   // bit 7: profiling build without the epilogue
+        if (!more) break;
+        {   // an interior tile without read-modify-write issues exactly 8 x 2 (x 2 for f32 C or the GELU pair) stores per wave
+            const bool interior = em0 + 256 <= p.M && en0 + 256 <= p.N;
+            const bool plain = !(p.flags & (PB_GEMM_ACCUM | PB_GEMM_MUL_GELU_GRAD | 128));
+            pend = (interior && plain) ? (((p.flags & PB_GEMM_C_F32) || (p.flags & PB_GEMM_GELU)) ? 32 : 16) : 0;
+            if ((p.flags & PB_GEMM_C_F32) && (p.flags & PB_GEMM_GELU)) pend = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef G3_PROLOGUE
 #undef G3_ISSUE_A
 #undef G3_ISSUE_B
 #undef G3_READ_A
 #undef G3_READ_B
 #undef G3_MMA
-    if (p.flags & 128) return;                                      // bit 7: profiling build without the epilogue
-    epilogue_regs<8>(p, acc, m0 + wr * 128, n0 + wc * 64, coff, lane);
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, long n, float* __restrict__ out) {
@@ -467,6 +519,18 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 }  // namespace
+
+// CU count of the current device, rounded down to a multiple of 8 (one persistent workgroup per CU; a grid that is a multiple
+// of 8 keeps every work item of a workgroup on the workgroup's own XCD chunk).
+static int pb_num_cus() {
+    static int cached = 0;
+    if (!cached) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cached = n / 8 * 8;
+    }
+    return cached;
+}
 
 // Called by pb_gemm (pb_gemm.hip) when the problem qualifies. Returns 1 if it declined, 0 on success, <0 on error.
 int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
@@ -529,8 +593,9 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
         auto kfn = gemm3_kernel<AK, BK_>;                                                                                  \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);      \
-        hipLaunchKernelGGL(kfn, grid, dim3(512), 131072, stream, a);                                                      \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
+        dim3 pgrid(std::min<unsigned>(grid.x, (d->flags & 4096) ? grid.x : (unsigned)pb_num_cus()), grid.y, 1);            \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(512), 131072 + 2048, stream, a);                                                     \
     } while (0)
         if (a_kc && b_kc) PB_G3_LAUNCH(true, true);
         else if (a_kc && !b_kc) PB_G3_LAUNCH(true, false);

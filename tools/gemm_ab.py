@@ -41,5 +41,5 @@ for name, M, N, K, a_kc, b_kc, sk in shapes:
             e1.record(); torch.cuda.synchronize()
             ms[i] += e0.elapsed_time(e1) / 25
     tf = [2.0 * M * N * K / m / 1e9 for m in ms]
-    print('%-8s M=%6d N=%5d K=%6d sk=%2d/%2d/%2d  256-1bar %6.3f ms %5.0f TF | 256-pp %6.3f ms %5.0f TF | default %6.3f ms %5.0f TF | 128-1bar %6.3f ms %5.0f TF  same=%s maxdiff=%.3g'
+    print('%-8s M=%6d N=%5d K=%6d sk=%2d/%2d/%2d  256-1bar %6.3f ms %5.0f TF | 256-pp-np %6.3f ms %5.0f TF | default %6.3f ms %5.0f TF | 128-1bar %6.3f ms %5.0f TF  same=%s maxdiff=%.3g'
           % (name, M, N, K, sk, sk2, sk3, ms[0], tf[0], ms[1], tf[1], ms[2], tf[2], ms[3], tf[3], same, err), flush=True)
