@@ -197,7 +197,12 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    float m[2] = {-INFINITY, -INFINITY};
+    // row sums ride on the MFMA pipe: l^T += 1 P^T with an all-ones A operand gives sum_k p[q][k] (of the bf16 p the PV product
+    // sees) in every register of the accumulator -- 4 MFMAs per tile instead of 32 v_add + 2 cross-row reductions per lane
+    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const bf16_t one = (bf16_t)1.0f;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
     unsigned voff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_u32(smem) + 8192 + tr_lane_off64(dt * 16, lane);
@@ -265,23 +270,18 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
                 const float mnew = fmaxf(m[qt], mx);
                 const float muse = mnew == -INFINITY ? 0.f : mnew;
                 const float alpha = __builtin_amdgcn_exp2f(m[qt] - muse);
-                float rs = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = MASKED ? __builtin_amdgcn_exp2f(s[qt][kt][r] - muse) : __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], c, -muse));
-                        s[qt][kt][r] = e; rs += e;
-                    }
-                rs = grp_sum(rs);
-                l[qt] = l[qt] * alpha + rs;
+                    for (int r = 0; r < 4; ++r)
+                        s[qt][kt][r] = MASKED ? __builtin_amdgcn_exp2f(s[qt][kt][r] - muse) : __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], c, -muse));
+                lacc[qt] *= alpha;
                 m[qt] = mnew;
-                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {      // no row of this wave moved its maximum: nothing to rescale
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) oacc[qt][i] *= alpha;
-                }
+                for (int i = 0; i < 4; ++i) oacc[qt][i] *= alpha;    // (skipping this when no row moved its maximum costs more in copies than it saves)
                 pf[qt][0] = pack_pair(s[qt][0], s[qt][1]);
                 pf[qt][1] = pack_pair(s[qt][2], s[qt][3]);
+                lacc[qt] = MFMA16(ones, pf[qt][1], MFMA16(ones, pf[qt][0], lacc[qt]));
             }
         };
         if (masked) softmax_tile(BoolTag<true>{}); else softmax_tile(BoolTag<false>{});
@@ -302,14 +302,15 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         if (myq[qt] < p.Sq) {
-            const float inv = l[qt] > 0.f ? 1.0f / l[qt] : 0.f;
+            const float lq = lacc[qt][0];
+            const float inv = lq > 0.f ? 1.0f / lq : 0.f;
             bf16_t* O = p.out + b * p.o_sb + (long)myq[qt] * p.o_ss + h * HD;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x4 r = {(bf16_t)(oacc[qt][dt][0] * inv), (bf16_t)(oacc[qt][dt][1] * inv), (bf16_t)(oacc[qt][dt][2] * inv), (bf16_t)(oacc[qt][dt][3] * inv)};
                 *reinterpret_cast<bf16x4*>(O + dt * 16 + g * 4) = r;
             }
-            if (g == 0) p.lse[((long)b * p.H + h) * p.Sq + myq[qt]] = l[qt] > 0.f ? (m[qt] + log2f(l[qt])) / LOG2E : INFINITY;
+            if (g == 0) p.lse[((long)b * p.H + h) * p.Sq + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;
         }
     }
 }
