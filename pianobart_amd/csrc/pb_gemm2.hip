@@ -589,7 +589,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 4, 2, 4, 4);
         else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 4, 2, 4, 4);
         else PB_G2_LAUNCH(false, false, 4, 2, 4, 4);
-    } else if (big && !(d->flags & 2048)) {                          // bit 11: A/B against the one-barrier 256x256 kernel
+    } else if (big && !(d->flags & 2048)) {                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
         auto kfn = gemm3_kernel<AK, BK_>;                                                                                  \

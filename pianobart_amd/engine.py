@@ -374,11 +374,17 @@ class Engine:
                     self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
                 slabs = self._slabs
         ops.gemm(dy, x, self.g[gname], M=M, N=N, K=T, dtype=self.code, a_kc=False, b_kc=False, lda=ldy or M, ldb=ldx or N, ldc=N,
-                 c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off, splitk=nsplit, slabs=slabs, tile256=big)
+                 c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off, splitk=nsplit, slabs=slabs, tile256=big, dbg=self._bwd_dbg())
 
     def _dgrad(self, dy, wname, out, T, N, K, accum, ldy=None, **kw):
         """out(T,N) (+)= dy(T,K) @ W(K,N)   (NN GEMM, W stored [K][N])."""
-        ops.gemm(dy, self.w[wname], out, M=T, N=N, K=K, dtype=self.code, b_kc=False, lda=ldy or K, ldb=N, ldc=N, accum=accum, **kw)
+        ops.gemm(dy, self.w[wname], out, M=T, N=N, K=K, dtype=self.code, b_kc=False, lda=ldy or K, ldb=N, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
+
+    def _bwd_dbg(self):
+        """Backward GEMMs that can run beside in-flight gradient all-reduces (data parallel: grad_hook set) are launched as ordinary
+        grids (bit 12): a persistent one-workgroup-per-CU grid whose CUs are partly held by RCCL's kernels would run its stragglers as
+        a second full round, twice the time, where an ordinary grid merely loses those CUs' share."""
+        return 4096 if self.grad_hook is not None else 0
 
     def _ffn_ln_bwd(self, L, pf, ff, gy, y_in, seed, site, p):
         """Backward of y2 = LN2(y_in + drop(fc2(gelu(fc1(y_in))))). gy: grad wrt y2. Returns grad wrt y_in in ws['gA']."""
@@ -503,7 +509,7 @@ class Engine:
             need = 16 * ops.TAB_TOTAL * d
             if self._slabs is None or self._slabs.numel() < need:
                 self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
-            ops.gemm(ws['onehot'], ws['dz'], self.dptab, M=ops.TAB_TOTAL, N=d, K=K2, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.TAB_TOTAL, ldb=d,
+            ops.gemm(ws['onehot'], ws['dz'], self.dptab, M=ops.TAB_TOTAL, N=d, K=K2, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.TAB_TOTAL, ldb=d, dbg=self._bwd_dbg(),
                      ldc=d, c_f32=True, splitk=16, slabs=self._slabs, tile256=True)
         # projected-table gradient -> embedding tables and the shared merge Linear (exact f32)
         E, W, R = self.wf['emb'], self.wf['lin.w'], ops.TAB_ROWS
