@@ -404,10 +404,10 @@ int check_common(const char* who, int hd, long a, long b2, long c2, long d2) {
 
 }  // namespace
 
-int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int* kmax, int B, int H, int Sq, int Sk,
+int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int* kmax, int B, int H, int Sq, int Sk, int hd,
                    long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream);
 int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, const float* key_mask,
-                   const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
+                   const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, int hd, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
                    int causal, hipStream_t stream);
 
@@ -444,8 +444,8 @@ extern "C" int pb_flash_fwd(const void* q, const void* k, const void* v, void* o
     if (check_common("pb_flash_fwd", hd, q_ss, k_ss, v_ss, o_ss)) return -2;
     PB_REQUIRE(q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0, "pb_flash_fwd: batch strides must be multiples of 8");
     if (B <= 0 || H <= 0 || Sq <= 0) return 0;
-    if (hd == 64 && !(causal & 2))      // bit 1 of `causal` forces the generic kernel (tests)
-        return pb_flash64_fwd(q, k, v, o, lse, key_mask, kmax, B, H, Sq, Sk, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, scale, causal & 1, (hipStream_t)stream_);
+    if ((hd == 64 || hd == 128) && !(causal & 2))      // bit 1 of `causal` forces the generic kernel (tests)
+        return pb_flash64_fwd(q, k, v, o, lse, key_mask, kmax, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, scale, causal & 1, (hipStream_t)stream_);
     FaArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
@@ -474,8 +474,8 @@ extern "C" int pb_flash_bwd(const void* q, const void* k, const void* v, const v
     const long nrow = (long)B * H * Sq;
     FA_DISPATCH(hd, hipLaunchKernelGGL((fa_delta_kernel<HD>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, a.o, a.dout, delta, B, H, Sq, o_sb, o_ss));
     PB_LAUNCH_CHECK();
-    if (hd == 64 && !(causal & 2))
-        return pb_flash64_bwd(q, k, v, dout, lse, delta, key_mask, kmax, dq, dk, dv, B, H, Sq, Sk, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss,
+    if ((hd == 64 || hd == 128) && !(causal & 2))
+        return pb_flash64_bwd(q, k, v, dout, lse, delta, key_mask, kmax, dq, dk, dv, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss,
                               dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, scale, causal & 1, stream);
     dim3 gk((Sk + TK - 1) / TK, H, B), gq((Sq + TQ - 1) / TQ, H, B);
     if (hd == 128) {   // 4 x 16 KiB tiles exceed the default 64 KiB dynamic-LDS limit

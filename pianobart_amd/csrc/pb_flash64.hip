@@ -152,29 +152,43 @@ __device__ __forceinline__ void tr_wait8(s16x4 (&t)[4][2][2], s16x4 (&u)[4][2][2
 #undef TRW4
 __device__ __forceinline__ unsigned lds_u32(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 
-constexpr int NSTG = 3, TILE2 = 16384;     // 3-deep ring of {two 8 KiB images}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+// The three kernels are templates on NB = head_dim / 64: a [64 rows][head_dim] operand tile is kept as NB images of
+// [64][64] in the layout above (one swizzle, one set of fragment routines), the QK^T / dP chains run over the NB images'
+// k-steps and the outputs carry 4 NB column blocks. head_dim 64: 3-deep DMA ring, 2 row tiles per wave everywhere; head_dim
+// 128 (the reference's CLI default, 1024 / 8 heads): 2-deep ring (64 KiB of tiles per workgroup) and one key tile per wave in dKV.
+template <int NB> struct FaCfg {
+    static constexpr int NS = NB == 1 ? 3 : 2;            // ring depth
+    static constexpr int STB = 2 * NB * 8192;             // bytes of one ring stage: NB images of each of the two operands
+    static constexpr int PCS = 4 * NB;                    // DMA pieces per wave per stage
+    static constexpr int KT = NB == 1 ? 2 : 1;            // key tiles (16 keys) per wave in the dK/dV kernel
+};
 
 // ================================================================== forward: block = 128 queries
-// LDS: 3 x {K tile, V tile} | key bias (0 / -inf) of every key this block visits | one "has a masked key" word per tile.
-// Pipeline: the DMA of tile it+2 is issued at the top of tile it and waited for, with a counted vmcnt(4), at the bottom of
-// tile it+1 in front of a raw s_barrier -- two tiles of flight time, nothing in the loop drains it (no ordinary global load,
-// no __syncthreads(), no ds_read_tr builtin). V's transposed fragments are requested before the softmax and collected after.
+// LDS: ring of {K tile, V tile} | key bias (0 / -inf) of every key this block visits | one "has a masked key" word per tile.
+// Pipeline: the DMA of tile it+NS-1 is issued at the top of tile it and waited for, with a counted vmcnt, at the bottom of
+// tile it+NS-2 in front of a raw s_barrier; nothing in the loop drains it (no ordinary global load, no __syncthreads(), no
+// ds_read_tr builtin). V's transposed fragments are requested before the softmax and collected after.
+template <int NB>
 __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
+    using C = FaCfg<NB>;
+    constexpr int HDT = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
     block_map((p.Sq + 127) / 128, p.H, p.B, rb, h, b);
     const int q0 = rb * 128;
-    const bf16_t* Q = p.q + b * p.q_sb + h * HD;
-    const bf16_t* K = p.k + b * p.k_sb + h * HD;
-    const bf16_t* V = p.v + b * p.v_sb + h * HD;
+    const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
+    const bf16_t* K = p.k + b * p.k_sb + h * HDT;
+    const bf16_t* V = p.v + b * p.v_sb + h * HDT;
     const float c = p.scale * LOG2E;
     // keys at and beyond kmax[b] (1 + last visible key of this batch row: the PAD tail) are masked for every query: skip their tiles
     const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
     const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
     const int nt = (kend + 63) / 64;
-    float* ldsBias = reinterpret_cast<float*>(smem + NSTG * TILE2);
+    float* ldsBias = reinterpret_cast<float*>(smem + C::NS * C::STB);
     unsigned* ldsFlag = reinterpret_cast<unsigned*>(ldsBias + ((p.Sk + 63) / 64) * 64);
     for (int tile = wave; tile < nt; tile += 4) {                        // one wave = one tile of keys
         const int key = tile * 64 + lane;
@@ -184,19 +198,20 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
         if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
     }
     int myq[2];
-    bf16x8 qf[2][2];
+    bf16x8 qf[2][2 * NB];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         myq[qt] = q0 + wave * 32 + qt * 16 + lr;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8);
+        for (int ks = 0; ks < 2 * NB; ++ks) qf[qt][ks] = frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8);
     }
-    asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]));   // ordinary loads are done before the first DMA
-    f32x4 oacc[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2 * NB; ++ks) asm volatile("" : "+v"(qf[0][ks]), "+v"(qf[1][ks]));   // ordinary loads are done before the first DMA
+    f32x4 oacc[2][4 * NB];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4 * NB; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m[2] = {-INFINITY, -INFINITY};
     // row sums ride on the MFMA pipe: l^T += 1 P^T with an all-ones A operand gives sum_k p[q][k] (of the bf16 p the PV product
     // sees) in every register of the accumulator -- 4 MFMAs per tile instead of 32 v_add + 2 cross-row reductions per lane
@@ -205,23 +220,25 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     const bf16x8 ones = {one, one, one, one, one, one, one, one};
     unsigned voff[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_u32(smem) + 8192 + tr_lane_off64(dt * 16, lane);
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_u32(smem) + NB * 8192 + tr_lane_off64(dt * 16, lane);
     const StageOff so_k = stage_off(p.k_ss, wave, lane), so_v = stage_off(p.v_ss, wave, lane);
     auto stage = [&](int it, int sidx) {
-        char* st = smem + sidx * TILE2;
-        stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane, so_k);
-        stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane, so_v);
+        char* st = smem + sidx * C::STB;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            stage64(K + nb * 64, p.k_ss, it * 64, p.Sk, st + nb * 8192, wave, lane, so_k);
+            stage64(V + nb * 64, p.v_ss, it * 64, p.Sk, st + (NB + nb) * 8192, wave, lane, so_v);
+        }
     };
     if (nt > 0) stage(0, 0);
-    if (nt > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (C::NS == 3 && nt > 1) { stage(1, 1); wait_vm<C::PCS>(); } else { wait_vm<0>(); }
     __builtin_amdgcn_s_waitcnt(0xc07f);                                    // this wave's bias / flag stores
     __builtin_amdgcn_s_barrier();
     int sidx = 0;
     for (int it = 0; it < nt; ++it) {
-        const char* st = smem + sidx * TILE2;
-        const int nidx = sidx == 0 ? 2 : sidx - 1;                         // (it + 2) % 3
-        if (it + 2 < nt) stage(it + 2, nidx);
-        const char* ldsK = st;
+        const char* st = smem + sidx * C::STB;
+        const int nidx = sidx == 0 ? C::NS - 1 : sidx - 1;                 // (it + NS - 1) % NS
+        if (it + C::NS - 1 < nt) stage(it + C::NS - 1, nidx);
         const float* ldsB = ldsBias + it * 64;
         const int k0 = it * 64;
         const bool diag = p.causal && (k0 + 63 > q0 + wave * 32);        // wave-uniform: only tiles that touch the diagonal compare
@@ -229,16 +246,18 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
         f32x4 s[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            const bf16x8 ka = frag_row(ldsK, kt * 16 + lr, 0, g), kb = frag_row(ldsK, kt * 16 + lr, 1, g);
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                s[qt][kt] = MFMA16(ka, qf[qt][0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                s[qt][kt] = MFMA16(kb, qf[qt][1], s[qt][kt]);
+            for (int qt = 0; qt < 2; ++qt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 ka = frag_row(st + nb * 8192, kt * 16 + lr, 0, g), kb = frag_row(st + nb * 8192, kt * 16 + lr, 1, g);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) s[qt][kt] = MFMA16(kb, qf[qt][2 * nb + 1], MFMA16(ka, qf[qt][2 * nb], s[qt][kt]));
             }
         }
-        s16x4 tv[4][2][2];                                                // requested before the softmax, collected after it
+        s16x4 tv[4][2][2];                                                // V image 0: requested before the softmax, collected after it
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * TILE2));
+        for (int dt = 0; dt < 4; ++dt) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * C::STB));
         bf16x8 pf[2][2];
         // Online softmax of the tile: the common tile -- no masked key, not on the causal diagonal -- takes a path without
         // bias add, compare and select: max on the raw scores, then exp2(fma(s, c, -max)).
@@ -278,35 +297,39 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
                 lacc[qt] *= alpha;
                 m[qt] = mnew;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) oacc[qt][i] *= alpha;    // (skipping this when no row moved its maximum costs more in copies than it saves)
+                for (int i = 0; i < 4 * NB; ++i) oacc[qt][i] *= alpha;    // (skipping this when no row moved its maximum costs more in copies than it saves)
                 pf[qt][0] = pack_pair(s[qt][0], s[qt][1]);
                 pf[qt][1] = pack_pair(s[qt][2], s[qt][3]);
                 lacc[qt] = MFMA16(ones, pf[qt][1], MFMA16(ones, pf[qt][0], lacc[qt]));
             }
         };
         if (masked) softmax_tile(BoolTag<true>{}); else softmax_tile(BoolTag<false>{});
-        tr_wait4(tv);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 v0 = tr_join(tv[dt][0][0], tv[dt][0][1]), v1 = tr_join(tv[dt][1][0], tv[dt][1][1]);
+        for (int nb = 0; nb < NB; ++nb) {
+            if (nb > 0) {                                                 // next V image into the same registers (the compiler keeps the anti-dependence)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                oacc[qt][dt] = MFMA16(v0, pf[qt][0], oacc[qt][dt]);
-                oacc[qt][dt] = MFMA16(v1, pf[qt][1], oacc[qt][dt]);
+                for (int dt = 0; dt < 4; ++dt) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * C::STB + nb * 8192));
+            }
+            tr_wait4(tv);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 v0 = tr_join(tv[dt][0][0], tv[dt][0][1]), v1 = tr_join(tv[dt][1][0], tv[dt][1][1]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) oacc[qt][nb * 4 + dt] = MFMA16(v1, pf[qt][1], MFMA16(v0, pf[qt][0], oacc[qt][nb * 4 + dt]));
             }
         }
-        if (it + 2 < nt) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (C::NS == 3 && it + 2 < nt) { wait_vm<C::PCS>(); } else { wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
-        sidx = sidx == 2 ? 0 : sidx + 1;
+        sidx = sidx == C::NS - 1 ? 0 : sidx + 1;
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         if (myq[qt] < p.Sq) {
             const float lq = lacc[qt][0];
             const float inv = lq > 0.f ? 1.0f / lq : 0.f;
-            bf16_t* O = p.out + b * p.o_sb + (long)myq[qt] * p.o_ss + h * HD;
+            bf16_t* O = p.out + b * p.o_sb + (long)myq[qt] * p.o_ss + h * HDT;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4 * NB; ++dt) {
                 bf16x4 r = {(bf16_t)(oacc[qt][dt][0] * inv), (bf16_t)(oacc[qt][dt][1] * inv), (bf16_t)(oacc[qt][dt][2] * inv), (bf16_t)(oacc[qt][dt][3] * inv)};
                 *reinterpret_cast<bf16x4*>(O + dt * 16 + g * 4) = r;
             }
@@ -323,30 +346,33 @@ __device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float c) {
     return r;
 }
 
-// ================================================================== backward dK, dV: block = 128 keys
+// ================================================================== backward dK, dV: block = 64 KT keys
 // Per score the backward needs p = exp(s - lse) and ds = p (dp - delta). With K prescaled by c = scale * log2(e) and the
 // row constants -lse * log2(e) and -delta loaded as the INITIAL ACCUMULATORS of the S and dP MFMA chains, that is one
 // v_exp_f32 and one multiply: no fma, no subtract, no per-score mask (a masked key only dirties its own dK / dV rows, which
 // are zeroed in the epilogue; a fully masked or out-of-range query row has -lse = -inf, so p = 0), and the softmax scale is
-// applied once to dK. Only tiles on the causal diagonal compare. Pipeline as in the forward: 3-deep DMA ring of {Q, dO}
+// applied once to dK. Only tiles on the causal diagonal compare. Pipeline as in the forward: DMA ring of {Q, dO}
 // tiles behind a counted vmcnt, raw barriers, transposed fragments by asm; -lse, -delta of the whole row sit in LDS.
+template <int NB>
 __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
+    using C = FaCfg<NB>;
+    constexpr int HDT = 64 * NB, KT = C::KT, BK_ = 64 * KT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
-    block_map((p.Sk + 127) / 128, p.H, p.B, rb, h, b);
-    const int k0 = rb * 128;
-    const bf16_t* Q = p.q + b * p.q_sb + h * HD;
-    const bf16_t* K = p.k + b * p.k_sb + h * HD;
-    const bf16_t* V = p.v + b * p.v_sb + h * HD;
-    const bf16_t* DO = p.dout + b * p.o_sb + h * HD;
+    block_map((p.Sk + BK_ - 1) / BK_, p.H, p.B, rb, h, b);
+    const int k0 = rb * BK_;
+    const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
+    const bf16_t* K = p.k + b * p.k_sb + h * HDT;
+    const bf16_t* V = p.v + b * p.v_sb + h * HDT;
+    const bf16_t* DO = p.dout + b * p.o_sb + h * HDT;
     const float c = p.scale * LOG2E;
     const int it0 = p.causal ? k0 / 64 : 0;
     // a key block that lies entirely in the masked tail receives no gradient: skip its whole query loop (zeros are written)
     const int nt = (p.kmax && k0 >= p.kmax[b]) ? 0 : (p.Sq + 63) / 64;
     const int sqp = ((p.Sq + 63) / 64) * 64;
-    float* ldsNL = reinterpret_cast<float*>(smem + NSTG * TILE2);         // -lse * log2(e) per query (-inf: row contributes nothing)
+    float* ldsNL = reinterpret_cast<float*>(smem + C::NS * C::STB);       // -lse * log2(e) per query (-inf: row contributes nothing)
     float* ldsND = ldsNL + sqp;                                          // -delta per query
     for (int q = it0 * 64 + t; q < nt * 64; q += FT) {
         const long li = ((long)b * p.H + h) * p.Sq + q;
@@ -354,64 +380,75 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         ldsNL[q] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
         ldsND[q] = q < p.Sq ? -p.delta[li] : 0.f;
     }
-    int mykey[2];
-    bf16x8 kf[2][2], vf[2][2];
+    int mykey[KT];
+    bf16x8 kf[KT][2 * NB], vf[KT][2 * NB];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        mykey[kt] = k0 + wave * 32 + kt * 16 + lr;
+    for (int kt = 0; kt < KT; ++kt) {
+        mykey[kt] = k0 + wave * (16 * KT) + kt * 16 + lr;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 2 * NB; ++ks) {
             kf[kt][ks] = scale_frag(frag_global(K, p.k_ss, mykey[kt], p.Sk, ks * 32 + g * 8), c);
             vf[kt][ks] = frag_global(V, p.v_ss, mykey[kt], p.Sk, ks * 32 + g * 8);
         }
     }
-    asm volatile("" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));
-    f32x4 dk[2][4], dv[2][4];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { dk[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int ks = 0; ks < 2 * NB; ++ks) asm volatile("" : "+v"(kf[kt][ks]), "+v"(vf[kt][ks]));
+    f32x4 dk[KT][4 * NB], dv[KT][4 * NB];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i) { dk[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     unsigned qoff[4], ooff[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { qoff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane); ooff[dt] = qoff[dt] + 8192; }
+    for (int dt = 0; dt < 4; ++dt) { qoff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane); ooff[dt] = qoff[dt] + NB * 8192; }
     const StageOff so_q = stage_off(p.q_ss, wave, lane), so_o = stage_off(p.o_ss, wave, lane);
     auto stage = [&](int it, int sidx) {
-        char* st = smem + sidx * TILE2;
-        stage64(Q, p.q_ss, it * 64, p.Sq, st, wave, lane, so_q);
-        stage64(DO, p.o_ss, it * 64, p.Sq, st + 8192, wave, lane, so_o);
+        char* st = smem + sidx * C::STB;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            stage64(Q + nb * 64, p.q_ss, it * 64, p.Sq, st + nb * 8192, wave, lane, so_q);
+            stage64(DO + nb * 64, p.o_ss, it * 64, p.Sq, st + (NB + nb) * 8192, wave, lane, so_o);
+        }
     };
     if (it0 < nt) stage(it0, 0);
-    if (it0 + 1 < nt) { stage(it0 + 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (C::NS == 3 && it0 + 1 < nt) { stage(it0 + 1, 1); wait_vm<C::PCS>(); } else { wait_vm<0>(); }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
     int sidx = 0;
     for (int it = it0; it < nt; ++it) {
-        const char* st = smem + sidx * TILE2;
-        const int nidx = sidx == 0 ? 2 : sidx - 1;
-        if (it + 2 < nt) stage(it + 2, nidx);
-        const char* ldsQ = st; const char* ldsO = st + 8192;
+        const char* st = smem + sidx * C::STB;
+        const int nidx = sidx == 0 ? C::NS - 1 : sidx - 1;
+        if (it + C::NS - 1 < nt) stage(it + C::NS - 1, nidx);
         const int q0 = it * 64;
-        const bool diag = p.causal && (k0 + wave * 32 + 31 > q0);          // wave-uniform: this q tile can be below some of the wave's keys
-        bf16x8 pf[2][2], df[2][2];
+        const bool diag = p.causal && (k0 + wave * (16 * KT) + 16 * KT - 1 > q0);   // wave-uniform: this q tile can be below some of the wave's keys
+        bf16x8 pf[KT][2], df[KT][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {            // q tiles (2 half, 2 half + 1) -> one k-step of the dV/dK products
-            f32x4 sv[2][2], dp[2][2];
+            f32x4 sv[KT][2], dp[KT][2];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int qt = half * 2 + qq;
-                const bf16x8 qa = frag_row(ldsQ, qt * 16 + lr, 0, g), qb = frag_row(ldsQ, qt * 16 + lr, 1, g);
-                const bf16x8 oa = frag_row(ldsO, qt * 16 + lr, 0, g), ob = frag_row(ldsO, qt * 16 + lr, 1, g);
                 const f32x4 nl = *reinterpret_cast<const f32x4*>(ldsNL + q0 + qt * 16 + g * 4);
                 const f32x4 nd = *reinterpret_cast<const f32x4*>(ldsND + q0 + qt * 16 + g * 4);
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    sv[kt][qq] = MFMA16(qb, kf[kt][1], MFMA16(qa, kf[kt][0], nl));
-                    dp[kt][qq] = MFMA16(ob, vf[kt][1], MFMA16(oa, vf[kt][0], nd));
+                for (int kt = 0; kt < KT; ++kt) { sv[kt][qq] = nl; dp[kt][qq] = nd; }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const char* ldsQ = st + nb * 8192; const char* ldsO = st + (NB + nb) * 8192;
+                    const bf16x8 qa = frag_row(ldsQ, qt * 16 + lr, 0, g), qb = frag_row(ldsQ, qt * 16 + lr, 1, g);
+                    const bf16x8 oa = frag_row(ldsO, qt * 16 + lr, 0, g), ob = frag_row(ldsO, qt * 16 + lr, 1, g);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        sv[kt][qq] = MFMA16(qb, kf[kt][2 * nb + 1], MFMA16(qa, kf[kt][2 * nb], sv[kt][qq]));
+                        dp[kt][qq] = MFMA16(ob, vf[kt][2 * nb + 1], MFMA16(oa, vf[kt][2 * nb], dp[kt][qq]));
+                    }
                 }
             }
             if (diag) {
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
@@ -422,7 +459,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
                         }
             } else {
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
@@ -432,14 +469,16 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
                         }
             }
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) { pf[kt][half] = pack_pair(sv[kt][0], sv[kt][1]); df[kt][half] = pack_pair(dp[kt][0], dp[kt][1]); }
+            for (int kt = 0; kt < KT; ++kt) { pf[kt][half] = pack_pair(sv[kt][0], sv[kt][1]); df[kt][half] = pack_pair(dp[kt][0], dp[kt][1]); }
         }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int si = 0; si < 2; ++si) {                                   // k-step si of the dV / dK products = q rows 32 si .. 32 si + 31
             s16x4 to[4][2], tq[4][2];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const unsigned ao = ooff[dt] + (unsigned)(sidx * TILE2), aq = qoff[dt] + (unsigned)(sidx * TILE2);
+                const unsigned ao = ooff[dt] + (unsigned)(sidx * C::STB + nb * 8192), aq = qoff[dt] + (unsigned)(sidx * C::STB + nb * 8192);
                 if (si == 0) { ds_tr<0>(to[dt][0], ao); ds_tr<2048>(to[dt][1], ao); ds_tr<0>(tq[dt][0], aq); ds_tr<2048>(tq[dt][1], aq); }
                 else { ds_tr<4096>(to[dt][0], ao); ds_tr<6144>(to[dt][1], ao); ds_tr<4096>(tq[dt][0], aq); ds_tr<6144>(tq[dt][1], aq); }
             }
@@ -449,27 +488,27 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
             for (int dt = 0; dt < 4; ++dt) {
                 const bf16x8 ot = tr_join(to[dt][0], to[dt][1]), qtf = tr_join(tq[dt][0], tq[dt][1]);
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    dv[kt][dt] = MFMA16(pf[kt][si], ot, dv[kt][dt]);
-                    dk[kt][dt] = MFMA16(df[kt][si], qtf, dk[kt][dt]);
+                for (int kt = 0; kt < KT; ++kt) {
+                    dv[kt][nb * 4 + dt] = MFMA16(pf[kt][si], ot, dv[kt][nb * 4 + dt]);
+                    dk[kt][nb * 4 + dt] = MFMA16(df[kt][si], qtf, dk[kt][nb * 4 + dt]);
                 }
             }
         }
-        if (it + 2 < nt) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (C::NS == 3 && it + 2 < nt) { wait_vm<C::PCS>(); } else { wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
-        sidx = sidx == 2 ? 0 : sidx + 1;
+        sidx = sidx == C::NS - 1 ? 0 : sidx + 1;
     }
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int key = k0 + wave * 32 + kt * 16 + g * 4 + r;
+            const int key = k0 + wave * (16 * KT) + kt * 16 + g * 4 + r;
             if (key < p.Sk) {
                 const bool kvis = !p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f;    // a masked key receives no gradient
-                bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HD;
-                bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HD;
+                bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HDT;
+                bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < 4 * NB; ++dt) {
                     DK[dt * 16 + lr] = (bf16_t)(kvis ? dk[kt][dt][r] * p.scale : 0.f);
                     DV[dt * 16 + lr] = (bf16_t)(kvis ? dv[kt][dt][r] : 0.f);
                 }
@@ -481,22 +520,25 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
 // Same arithmetic with the roles swapped: Q (prescaled by c) and dO of the wave's 32 queries stay in registers, -lse * log2(e)
 // and -delta are per-lane constants splatted into the initial accumulators, K / V tiles stream through the DMA ring, and a
 // tile that holds a masked key adds the 0 / -inf key bias before the exp2 (no select).
+template <int NB>
 __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
+    using C = FaCfg<NB>;
+    constexpr int HDT = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
     block_map((p.Sq + 127) / 128, p.H, p.B, rb, h, b);
     const int q0 = rb * 128;
-    const bf16_t* Q = p.q + b * p.q_sb + h * HD;
-    const bf16_t* K = p.k + b * p.k_sb + h * HD;
-    const bf16_t* V = p.v + b * p.v_sb + h * HD;
-    const bf16_t* DO = p.dout + b * p.o_sb + h * HD;
+    const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
+    const bf16_t* K = p.k + b * p.k_sb + h * HDT;
+    const bf16_t* V = p.v + b * p.v_sb + h * HDT;
+    const bf16_t* DO = p.dout + b * p.o_sb + h * HDT;
     const float c = p.scale * LOG2E;
     const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
     const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
     const int nt = (kend + 63) / 64;
-    float* ldsBias = reinterpret_cast<float*>(smem + NSTG * TILE2);
+    float* ldsBias = reinterpret_cast<float*>(smem + C::NS * C::STB);
     unsigned* ldsFlag = reinterpret_cast<unsigned*>(ldsBias + ((p.Sk + 63) / 64) * 64);
     for (int tile = wave; tile < nt; tile += 4) {
         const int key = tile * 64 + lane;
@@ -506,7 +548,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
     }
     int myq[2];
-    bf16x8 qf[2][2], of[2][2];
+    bf16x8 qf[2][2 * NB], of[2][2 * NB];
     float nl[2], nd[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -516,37 +558,43 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         nl[qt] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
         nd[qt] = myq[qt] < p.Sq ? -p.delta[li] : 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 2 * NB; ++ks) {
             qf[qt][ks] = scale_frag(frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8), c);
             of[qt][ks] = frag_global(DO, p.o_ss, myq[qt], p.Sq, ks * 32 + g * 8);
         }
     }
-    asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(of[0][0]), "+v"(of[0][1]), "+v"(of[1][0]), "+v"(of[1][1]),
-                      "+v"(nl[0]), "+v"(nl[1]), "+v"(nd[0]), "+v"(nd[1]));
-    f32x4 dq[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int ks = 0; ks < 2 * NB; ++ks) asm volatile("" : "+v"(qf[qt][ks]), "+v"(of[qt][ks]));
+        asm volatile("" : "+v"(nl[qt]), "+v"(nd[qt]));
+    }
+    f32x4 dq[2][4 * NB];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dq[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4 * NB; ++i) dq[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned koff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) koff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane);
     const StageOff so_k = stage_off(p.k_ss, wave, lane), so_v = stage_off(p.v_ss, wave, lane);
     auto stage = [&](int it, int sidx) {
-        char* st = smem + sidx * TILE2;
-        stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane, so_k);
-        stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane, so_v);
+        char* st = smem + sidx * C::STB;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            stage64(K + nb * 64, p.k_ss, it * 64, p.Sk, st + nb * 8192, wave, lane, so_k);
+            stage64(V + nb * 64, p.v_ss, it * 64, p.Sk, st + (NB + nb) * 8192, wave, lane, so_v);
+        }
     };
     if (nt > 0) stage(0, 0);
-    if (nt > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (C::NS == 3 && nt > 1) { stage(1, 1); wait_vm<C::PCS>(); } else { wait_vm<0>(); }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
     int sidx = 0;
     for (int it = 0; it < nt; ++it) {
-        const char* st = smem + sidx * TILE2;
-        const int nidx = sidx == 0 ? 2 : sidx - 1;
-        if (it + 2 < nt) stage(it + 2, nidx);
-        const char* ldsK = st; const char* ldsV = st + 8192;
+        const char* st = smem + sidx * C::STB;
+        const int nidx = sidx == 0 ? C::NS - 1 : sidx - 1;
+        if (it + C::NS - 1 < nt) stage(it + C::NS - 1, nidx);
         const float* ldsB = ldsBias + it * 64;
         const int k0 = it * 64;
         const bool diag = p.causal && (k0 + 63 > q0 + wave * 32);
@@ -558,48 +606,58 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int kt = half * 2 + kk;
-                const bf16x8 ka = frag_row(ldsK, kt * 16 + lr, 0, g), kb = frag_row(ldsK, kt * 16 + lr, 1, g);
-                const bf16x8 va = frag_row(ldsV, kt * 16 + lr, 0, g), vb = frag_row(ldsV, kt * 16 + lr, 1, g);
+                f32x4 sv[2], dpv[2];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) { sv[qt] = f32x4{nl[qt], nl[qt], nl[qt], nl[qt]}; dpv[qt] = f32x4{nd[qt], nd[qt], nd[qt], nd[qt]}; }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const char* ldsK = st + nb * 8192; const char* ldsV = st + (NB + nb) * 8192;
+                    const bf16x8 ka = frag_row(ldsK, kt * 16 + lr, 0, g), kb = frag_row(ldsK, kt * 16 + lr, 1, g);
+                    const bf16x8 va = frag_row(ldsV, kt * 16 + lr, 0, g), vb = frag_row(ldsV, kt * 16 + lr, 1, g);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        sv[qt] = MFMA16(kb, qf[qt][2 * nb + 1], MFMA16(ka, qf[qt][2 * nb], sv[qt]));
+                        dpv[qt] = MFMA16(vb, of[qt][2 * nb + 1], MFMA16(va, of[qt][2 * nb], dpv[qt]));
+                    }
+                }
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
-                    f32x4 sv = MFMA16(kb, qf[qt][1], MFMA16(ka, qf[qt][0], (f32x4{nl[qt], nl[qt], nl[qt], nl[qt]})));
-                    f32x4 dpv = MFMA16(vb, of[qt][1], MFMA16(va, of[qt][0], (f32x4{nd[qt], nd[qt], nd[qt], nd[qt]})));
-                    if (masked) sv += *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
+                    if (masked) sv[qt] += *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
                     if (diag) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (k0 + kt * 16 + g * 4 + r > myq[qt]) sv[r] = -INFINITY;
+                        for (int r = 0; r < 4; ++r) if (k0 + kt * 16 + g * 4 + r > myq[qt]) sv[qt][r] = -INFINITY;
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dpv[r] *= __builtin_amdgcn_exp2f(sv[r]);
-                    ds_[qt][kk] = dpv;
+                    for (int r = 0; r < 4; ++r) dpv[qt][r] *= __builtin_amdgcn_exp2f(sv[qt][r]);
+                    ds_[qt][kk] = dpv[qt];
                 }
             }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) df[qt][half] = pack_pair(ds_[qt][0], ds_[qt][1]);
         }
-        s16x4 tk[4][2][2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ds_tr_block(tk[dt], koff[dt] + (unsigned)(sidx * TILE2));
-        tr_wait4(tk);
+        for (int nb = 0; nb < NB; ++nb) {
+            s16x4 tk[4][2][2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 k0f = tr_join(tk[dt][0][0], tk[dt][0][1]), k1f = tr_join(tk[dt][1][0], tk[dt][1][1]);
+            for (int dt = 0; dt < 4; ++dt) ds_tr_block(tk[dt], koff[dt] + (unsigned)(sidx * C::STB + nb * 8192));
+            tr_wait4(tk);
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                dq[qt][dt] = MFMA16(k0f, df[qt][0], dq[qt][dt]);
-                dq[qt][dt] = MFMA16(k1f, df[qt][1], dq[qt][dt]);
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 k0f = tr_join(tk[dt][0][0], tk[dt][0][1]), k1f = tr_join(tk[dt][1][0], tk[dt][1][1]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) dq[qt][nb * 4 + dt] = MFMA16(k1f, df[qt][1], MFMA16(k0f, df[qt][0], dq[qt][nb * 4 + dt]));
             }
         }
-        if (it + 2 < nt) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (C::NS == 3 && it + 2 < nt) { wait_vm<C::PCS>(); } else { wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
-        sidx = sidx == 2 ? 0 : sidx + 1;
+        sidx = sidx == C::NS - 1 ? 0 : sidx + 1;
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
         if (myq[qt] < p.Sq) {
-            bf16_t* DQ = p.dq + b * p.dq_sb + (long)myq[qt] * p.dq_ss + h * HD;
+            bf16_t* DQ = p.dq + b * p.dq_sb + (long)myq[qt] * p.dq_ss + h * HDT;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4 * NB; ++dt) {
                 bf16x4 r = {(bf16_t)(dq[qt][dt][0] * p.scale), (bf16_t)(dq[qt][dt][1] * p.scale), (bf16_t)(dq[qt][dt][2] * p.scale), (bf16_t)(dq[qt][dt][3] * p.scale)};
                 *reinterpret_cast<bf16x4*>(DQ + dt * 16 + g * 4) = r;
             }
@@ -608,23 +666,45 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 
 }  // namespace
 
-// entry points used by pb_flash.hip's dispatch (same argument meaning as pb_flash_fwd / pb_flash_bwd, hd == 64)
-int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int* kmax, int B, int H, int Sq, int Sk,
+// entry points used by pb_flash.hip's dispatch (same argument meaning as pb_flash_fwd / pb_flash_bwd; hd = 64 or 128)
+template <int NB>
+static int fa64_fwd_launch(const Fa64Args& a, hipStream_t stream) {
+    using C = FaCfg<NB>;
+    const size_t lds = (size_t)C::NS * C::STB + (size_t)((a.Sk + 63) / 64) * (64 * 4 + 4);
+    PB_REQUIRE(lds <= 160 * 1024, "pb_flash_fwd: Sk=%d needs %zu bytes of LDS", a.Sk, lds);
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_fwd_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fa64_fwd_kernel<NB>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds, stream, a);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int* kmax, int B, int H, int Sq, int Sk, int hd,
                    long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream) {
     Fa64Args a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal;
-    const size_t lds_fwd = (size_t)NSTG * TILE2 + (size_t)((Sk + 63) / 64) * (64 * 4 + 4);
-    PB_REQUIRE(lds_fwd <= 160 * 1024, "pb_flash_fwd: Sk=%d needs %zu bytes of LDS", Sk, lds_fwd);
-    if (lds_fwd > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd);
-    hipLaunchKernelGGL(fa64_fwd_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), lds_fwd, stream, a);
+    return hd == 128 ? fa64_fwd_launch<2>(a, stream) : fa64_fwd_launch<1>(a, stream);
+}
+
+template <int NB>
+static int fa64_bwd_launch(const Fa64Args& a, hipStream_t stream) {
+    using C = FaCfg<NB>;
+    const size_t lds_dkv = (size_t)C::NS * C::STB + (size_t)((a.Sq + 63) / 64) * 64 * 8;
+    const size_t lds_dq = (size_t)C::NS * C::STB + (size_t)((a.Sk + 63) / 64) * (64 * 4 + 4);
+    PB_REQUIRE(lds_dkv <= 160 * 1024 && lds_dq <= 160 * 1024, "pb_flash_bwd: Sq=%d Sk=%d need %zu / %zu bytes of LDS", a.Sq, a.Sk, lds_dkv, lds_dq);
+    if (lds_dkv > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dkv_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+    if (lds_dq > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dq_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+    constexpr int BK_ = 64 * C::KT;
+    hipLaunchKernelGGL(fa64_bwd_dkv_kernel<NB>, dim3(((a.Sk + BK_ - 1) / BK_) * a.H * a.B), dim3(FT), lds_dkv, stream, a);
+    PB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fa64_bwd_dq_kernel<NB>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds_dq, stream, a);
     PB_LAUNCH_CHECK();
     return 0;
 }
 
 int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, const float* key_mask,
-                   const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
+                   const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, int hd, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
                    int causal, hipStream_t stream) {
     Fa64Args a = {};
@@ -633,14 +713,5 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
     a.scale = scale; a.causal = causal;
-    const size_t lds_dkv = (size_t)NSTG * TILE2 + (size_t)((Sq + 63) / 64) * 64 * 8;
-    const size_t lds_dq = (size_t)NSTG * TILE2 + (size_t)((Sk + 63) / 64) * (64 * 4 + 4);
-    PB_REQUIRE(lds_dkv <= 160 * 1024 && lds_dq <= 160 * 1024, "pb_flash_bwd: Sq=%d Sk=%d need %zu / %zu bytes of LDS", Sq, Sk, lds_dkv, lds_dq);
-    if (lds_dkv > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
-    if (lds_dq > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-    hipLaunchKernelGGL(fa64_bwd_dkv_kernel, dim3(((Sk + 127) / 128) * H * B), dim3(FT), lds_dkv, stream, a);
-    PB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fa64_bwd_dq_kernel, dim3(((Sq + 127) / 128) * H * B), dim3(FT), lds_dq, stream, a);
-    PB_LAUNCH_CHECK();
-    return 0;
+    return hd == 128 ? fa64_bwd_launch<2>(a, stream) : fa64_bwd_launch<1>(a, stream);
 }
