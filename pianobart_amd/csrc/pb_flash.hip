@@ -397,7 +397,7 @@ __global__ __launch_bounds__(FA_THREADS) void fa_bwd_dq_kernel(const FaArgs p) {
 }
 
 int check_common(const char* who, int hd, long a, long b2, long c2, long d2) {
-    PB_REQUIRE(hd == 32 || hd == 64 || hd == 128, "%s: head_dim %d not supported by the flash kernel (32/64/128)", who, hd);
+    PB_REQUIRE(hd == 32 || hd == 64 || hd == 96 || hd == 128, "%s: head_dim %d not supported by the flash kernels (32/64/96/128)", who, hd);
     PB_REQUIRE(a % 8 == 0 && b2 % 8 == 0 && c2 % 8 == 0 && d2 % 8 == 0, "%s: strides must be multiples of 8 elements", who);
     return 0;
 }
@@ -444,7 +444,8 @@ extern "C" int pb_flash_fwd(const void* q, const void* k, const void* v, void* o
     if (check_common("pb_flash_fwd", hd, q_ss, k_ss, v_ss, o_ss)) return -2;
     PB_REQUIRE(q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0, "pb_flash_fwd: batch strides must be multiples of 8");
     if (B <= 0 || H <= 0 || Sq <= 0) return 0;
-    if ((hd == 64 || hd == 128) && !(causal & 2))      // bit 1 of `causal` forces the generic kernel (tests)
+    PB_REQUIRE(hd != 96 || !(causal & 2), "pb_flash_fwd: head_dim 96 exists in the pipelined kernel family only");
+    if ((hd == 64 || hd == 96 || hd == 128) && !(causal & 2))      // bit 1 of `causal` forces the generic kernel (tests)
         return pb_flash64_fwd(q, k, v, o, lse, key_mask, kmax, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, scale, causal & 1, (hipStream_t)stream_);
     FaArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask;
@@ -472,9 +473,11 @@ extern "C" int pb_flash_bwd(const void* q, const void* k, const void* v, const v
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
     a.scale = scale; a.causal = causal & 1;
     const long nrow = (long)B * H * Sq;
-    FA_DISPATCH(hd, hipLaunchKernelGGL((fa_delta_kernel<HD>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, a.o, a.dout, delta, B, H, Sq, o_sb, o_ss));
+    PB_REQUIRE(hd != 96 || !(causal & 2), "pb_flash_bwd: head_dim 96 exists in the pipelined kernel family only");
+    if (hd == 96) hipLaunchKernelGGL((fa_delta_kernel<96>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, a.o, a.dout, delta, B, H, Sq, o_sb, o_ss);
+    else FA_DISPATCH(hd, hipLaunchKernelGGL((fa_delta_kernel<HD>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, a.o, a.dout, delta, B, H, Sq, o_sb, o_ss));
     PB_LAUNCH_CHECK();
-    if ((hd == 64 || hd == 128) && !(causal & 2))
+    if ((hd == 64 || hd == 96 || hd == 128) && !(causal & 2))
         return pb_flash64_bwd(q, k, v, dout, lse, delta, key_mask, kmax, dq, dk, dv, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss,
                               dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, scale, causal & 1, stream);
     dim3 gk((Sk + TK - 1) / TK, H, B), gq((Sq + TQ - 1) / TQ, H, B);

@@ -24,6 +24,7 @@ struct Fa64Args {
     int B, H, Sq, Sk;
     long q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
     float scale; int causal;
+    const bf16_t* zeros;              // >= 16 bytes of zeros (source of the column chunks beyond head_dim in a partly filled image)
 };
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
@@ -39,21 +40,25 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
 // The per-lane part of the source address (row within the tile, swizzled chunk) is computed once per kernel (StageOff); a
 // whole tile then costs one 64-bit add per piece on top of a wave-uniform tile base -- the row * ld multiplies of the naive
 // form were 16 % of the forward's vector cycles. Only a ragged last tile takes the clamped path.
-struct StageOff { unsigned off[2]; };
+struct StageOff { unsigned off[2]; unsigned chunk[2]; };
 __device__ __forceinline__ StageOff stage_off(long ld, int wave, int lane) {
     StageOff o;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int row = (wave * 2 + n) * 8 + (lane >> 3);
-        o.off[n] = (unsigned)(row * ld + (((lane & 7) ^ fsw(row)) << 3));
+        o.chunk[n] = (unsigned)((lane & 7) ^ fsw(row));               // the 8-column source chunk this lane fetches
+        o.off[n] = (unsigned)(row * ld + (o.chunk[n] << 3));
     }
     return o;
 }
-__device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, long ld, int r0, int nrows, char* lds, int wave, int lane, const StageOff& so) {
+// cmax = number of valid 8-column chunks of this image (8, or 4 for the second image of head_dim 96): the lanes of the other
+// chunks fetch zeros, so that the padded columns contribute nothing to any product.
+__device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, long ld, int r0, int nrows, char* lds, int wave, int lane, const StageOff& so,
+                                        int cmax = 8, const bf16_t* zeros = nullptr) {
     if (r0 + 64 <= nrows) {
         const bf16_t* tb = base + (long)r0 * ld;                          // wave-uniform
 #pragma unroll
-        for (int n = 0; n < 2; ++n) glds16(tb + so.off[n], lds + (wave * 2 + n) * 1024);
+        for (int n = 0; n < 2; ++n) glds16((cmax == 8 || (int)so.chunk[n] < cmax) ? tb + so.off[n] : zeros, lds + (wave * 2 + n) * 1024);
     } else {
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -61,7 +66,7 @@ __device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, long ld
             const int row = inst * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ fsw(row);
             const int gr = min(r0 + row, nrows - 1);
-            glds16(base + (long)gr * ld + chunk * 8, lds + inst * 1024);
+            glds16((cmax == 8 || chunk < cmax) ? base + (long)gr * ld + chunk * 8 : zeros, lds + inst * 1024);
         }
     }
 }
@@ -154,10 +159,11 @@ __device__ __forceinline__ unsigned lds_u32(const void* p) { return (unsigned)(u
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
-// The three kernels are templates on NB = head_dim / 64: a [64 rows][head_dim] operand tile is kept as NB images of
-// [64][64] in the layout above (one swizzle, one set of fragment routines), the QK^T / dP chains run over the NB images'
-// k-steps and the outputs carry 4 NB column blocks. head_dim 64: 3-deep DMA ring, 2 row tiles per wave everywhere; head_dim
-// 128 (the reference's CLI default, 1024 / 8 heads): 2-deep ring (64 KiB of tiles per workgroup) and one key tile per wave in dKV.
+// The three kernels are templates on head_dim HD in {64, 96, 128}: a [64 rows][HD] operand tile is kept as NB = ceil(HD / 64)
+// images of [64][64] in the layout above (one swizzle, one set of fragment routines; the second image of head_dim 96 is half
+// zeros), the QK^T / dP chains run over the HD / 32 k-steps and the outputs carry HD / 16 column blocks. head_dim 64: 3-deep
+// DMA ring, 2 row tiles per wave everywhere; head_dim 96 / 128 (128 = the reference's CLI default, 1024 / 8 heads; 96 = 768 / 8
+// heads): 2-deep ring (64 KiB of tiles per workgroup) and one key tile per wave in dKV.
 template <int NB> struct FaCfg {
     static constexpr int NS = NB == 1 ? 3 : 2;            // ring depth
     static constexpr int STB = 2 * NB * 8192;             // bytes of one ring stage: NB images of each of the two operands
@@ -170,10 +176,10 @@ template <int NB> struct FaCfg {
 // Pipeline: the DMA of tile it+NS-1 is issued at the top of tile it and waited for, with a counted vmcnt, at the bottom of
 // tile it+NS-2 in front of a raw s_barrier; nothing in the loop drains it (no ordinary global load, no __syncthreads(), no
 // ds_read_tr builtin). V's transposed fragments are requested before the softmax and collected after.
-template <int NB>
+template <int HD>
 __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
+    constexpr int NB = (HD + 63) / 64, KS = HD / 32, DT = HD / 16, HDT = HD;
     using C = FaCfg<NB>;
-    constexpr int HDT = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -198,20 +204,20 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
         if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
     }
     int myq[2];
-    bf16x8 qf[2][2 * NB];
+    bf16x8 qf[2][KS];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         myq[qt] = q0 + wave * 32 + qt * 16 + lr;
 #pragma unroll
-        for (int ks = 0; ks < 2 * NB; ++ks) qf[qt][ks] = frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8);
+        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8);
     }
 #pragma unroll
-    for (int ks = 0; ks < 2 * NB; ++ks) asm volatile("" : "+v"(qf[0][ks]), "+v"(qf[1][ks]));   // ordinary loads are done before the first DMA
-    f32x4 oacc[2][4 * NB];
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[0][ks]), "+v"(qf[1][ks]));   // ordinary loads are done before the first DMA
+    f32x4 oacc[2][DT];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int i = 0; i < 4 * NB; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < DT; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m[2] = {-INFINITY, -INFINITY};
     // row sums ride on the MFMA pipe: l^T += 1 P^T with an all-ones A operand gives sum_k p[q][k] (of the bf16 p the PV product
     // sees) in every register of the accumulator -- 4 MFMAs per tile instead of 32 v_add + 2 cross-row reductions per lane
@@ -226,8 +232,8 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
         char* st = smem + sidx * C::STB;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            stage64(K + nb * 64, p.k_ss, it * 64, p.Sk, st + nb * 8192, wave, lane, so_k);
-            stage64(V + nb * 64, p.v_ss, it * 64, p.Sk, st + (NB + nb) * 8192, wave, lane, so_v);
+            stage64(K + nb * 64, p.k_ss, it * 64, p.Sk, st + nb * 8192, wave, lane, so_k, min(8, (HD - nb * 64) / 8), p.zeros);
+            stage64(V + nb * 64, p.v_ss, it * 64, p.Sk, st + (NB + nb) * 8192, wave, lane, so_v, min(8, (HD - nb * 64) / 8), p.zeros);
         }
     };
     if (nt > 0) stage(0, 0);
@@ -250,14 +256,18 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
             for (int qt = 0; qt < 2; ++qt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 ka = frag_row(st + nb * 8192, kt * 16 + lr, 0, g), kb = frag_row(st + nb * 8192, kt * 16 + lr, 1, g);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) s[qt][kt] = MFMA16(kb, qf[qt][2 * nb + 1], MFMA16(ka, qf[qt][2 * nb], s[qt][kt]));
+                for (int k2 = 0; k2 < 2; ++k2)
+                    if (2 * nb + k2 < KS) {
+                        const bf16x8 kk = frag_row(st + nb * 8192, kt * 16 + lr, k2, g);
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt) s[qt][kt] = MFMA16(kk, qf[qt][2 * nb + k2], s[qt][kt]);
+                    }
             }
         }
         s16x4 tv[4][2][2];                                                // V image 0: requested before the softmax, collected after it
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * C::STB));
+        for (int dt = 0; dt < 4; ++dt) if (dt < DT) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * C::STB));
         bf16x8 pf[2][2];
         // Online softmax of the tile: the common tile -- no masked key, not on the causal diagonal -- takes a path without
         // bias add, compare and select: max on the raw scores, then exp2(fma(s, c, -max)).
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
                 lacc[qt] *= alpha;
                 m[qt] = mnew;
 #pragma unroll
-                for (int i = 0; i < 4 * NB; ++i) oacc[qt][i] *= alpha;    // (skipping this when no row moved its maximum costs more in copies than it saves)
+                for (int i = 0; i < DT; ++i) oacc[qt][i] *= alpha;    // (skipping this when no row moved its maximum costs more in copies than it saves)
                 pf[qt][0] = pack_pair(s[qt][0], s[qt][1]);
                 pf[qt][1] = pack_pair(s[qt][2], s[qt][3]);
                 lacc[qt] = MFMA16(ones, pf[qt][1], MFMA16(ones, pf[qt][0], lacc[qt]));
@@ -308,11 +318,11 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
         for (int nb = 0; nb < NB; ++nb) {
             if (nb > 0) {                                                 // next V image into the same registers (the compiler keeps the anti-dependence)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * C::STB + nb * 8192));
+                for (int dt = 0; dt < 4; ++dt) if (nb * 4 + dt < DT) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * C::STB + nb * 8192));
             }
             tr_wait4(tv);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4; ++dt) if (nb * 4 + dt < DT) {
                 const bf16x8 v0 = tr_join(tv[dt][0][0], tv[dt][0][1]), v1 = tr_join(tv[dt][1][0], tv[dt][1][1]);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) oacc[qt][nb * 4 + dt] = MFMA16(v1, pf[qt][1], MFMA16(v0, pf[qt][0], oacc[qt][nb * 4 + dt]));
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
             const float inv = lq > 0.f ? 1.0f / lq : 0.f;
             bf16_t* O = p.out + b * p.o_sb + (long)myq[qt] * p.o_ss + h * HDT;
 #pragma unroll
-            for (int dt = 0; dt < 4 * NB; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 bf16x4 r = {(bf16_t)(oacc[qt][dt][0] * inv), (bf16_t)(oacc[qt][dt][1] * inv), (bf16_t)(oacc[qt][dt][2] * inv), (bf16_t)(oacc[qt][dt][3] * inv)};
                 *reinterpret_cast<bf16x4*>(O + dt * 16 + g * 4) = r;
             }
@@ -353,10 +363,11 @@ __device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float c) {
 // are zeroed in the epilogue; a fully masked or out-of-range query row has -lse = -inf, so p = 0), and the softmax scale is
 // applied once to dK. Only tiles on the causal diagonal compare. Pipeline as in the forward: DMA ring of {Q, dO}
 // tiles behind a counted vmcnt, raw barriers, transposed fragments by asm; -lse, -delta of the whole row sit in LDS.
-template <int NB>
+template <int HD>
 __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
+    constexpr int NB = (HD + 63) / 64, KS = HD / 32, DT = HD / 16, HDT = HD;
     using C = FaCfg<NB>;
-    constexpr int HDT = 64 * NB, KT = C::KT, BK_ = 64 * KT;
+    constexpr int KT = C::KT, BK_ = 64 * KT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -381,12 +392,12 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         ldsND[q] = q < p.Sq ? -p.delta[li] : 0.f;
     }
     int mykey[KT];
-    bf16x8 kf[KT][2 * NB], vf[KT][2 * NB];
+    bf16x8 kf[KT][KS], vf[KT][KS];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
         mykey[kt] = k0 + wave * (16 * KT) + kt * 16 + lr;
 #pragma unroll
-        for (int ks = 0; ks < 2 * NB; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             kf[kt][ks] = scale_frag(frag_global(K, p.k_ss, mykey[kt], p.Sk, ks * 32 + g * 8), c);
             vf[kt][ks] = frag_global(V, p.v_ss, mykey[kt], p.Sk, ks * 32 + g * 8);
         }
@@ -394,12 +405,12 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int ks = 0; ks < 2 * NB; ++ks) asm volatile("" : "+v"(kf[kt][ks]), "+v"(vf[kt][ks]));
-    f32x4 dk[KT][4 * NB], dv[KT][4 * NB];
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[kt][ks]), "+v"(vf[kt][ks]));
+    f32x4 dk[KT][DT], dv[KT][DT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int i = 0; i < 4 * NB; ++i) { dk[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int i = 0; i < DT; ++i) { dk[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     unsigned qoff[4], ooff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { qoff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane); ooff[dt] = qoff[dt] + NB * 8192; }
@@ -408,8 +419,8 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         char* st = smem + sidx * C::STB;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            stage64(Q + nb * 64, p.q_ss, it * 64, p.Sq, st + nb * 8192, wave, lane, so_q);
-            stage64(DO + nb * 64, p.o_ss, it * 64, p.Sq, st + (NB + nb) * 8192, wave, lane, so_o);
+            stage64(Q + nb * 64, p.q_ss, it * 64, p.Sq, st + nb * 8192, wave, lane, so_q, min(8, (HD - nb * 64) / 8), p.zeros);
+            stage64(DO + nb * 64, p.o_ss, it * 64, p.Sq, st + (NB + nb) * 8192, wave, lane, so_o, min(8, (HD - nb * 64) / 8), p.zeros);
         }
     };
     if (it0 < nt) stage(it0, 0);
@@ -437,13 +448,16 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const char* ldsQ = st + nb * 8192; const char* ldsO = st + (NB + nb) * 8192;
-                    const bf16x8 qa = frag_row(ldsQ, qt * 16 + lr, 0, g), qb = frag_row(ldsQ, qt * 16 + lr, 1, g);
-                    const bf16x8 oa = frag_row(ldsO, qt * 16 + lr, 0, g), ob = frag_row(ldsO, qt * 16 + lr, 1, g);
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) {
-                        sv[kt][qq] = MFMA16(qb, kf[kt][2 * nb + 1], MFMA16(qa, kf[kt][2 * nb], sv[kt][qq]));
-                        dp[kt][qq] = MFMA16(ob, vf[kt][2 * nb + 1], MFMA16(oa, vf[kt][2 * nb], dp[kt][qq]));
-                    }
+                    for (int k2 = 0; k2 < 2; ++k2)
+                        if (2 * nb + k2 < KS) {
+                            const bf16x8 qa = frag_row(ldsQ, qt * 16 + lr, k2, g), oa = frag_row(ldsO, qt * 16 + lr, k2, g);
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt) {
+                                sv[kt][qq] = MFMA16(qa, kf[kt][2 * nb + k2], sv[kt][qq]);
+                                dp[kt][qq] = MFMA16(oa, vf[kt][2 * nb + k2], dp[kt][qq]);
+                            }
+                        }
                 }
             }
             if (diag) {
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         for (int si = 0; si < 2; ++si) {                                   // k-step si of the dV / dK products = q rows 32 si .. 32 si + 31
             s16x4 to[4][2], tq[4][2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4; ++dt) if (nb * 4 + dt < DT) {
                 const unsigned ao = ooff[dt] + (unsigned)(sidx * C::STB + nb * 8192), aq = qoff[dt] + (unsigned)(sidx * C::STB + nb * 8192);
                 if (si == 0) { ds_tr<0>(to[dt][0], ao); ds_tr<2048>(to[dt][1], ao); ds_tr<0>(tq[dt][0], aq); ds_tr<2048>(tq[dt][1], aq); }
                 else { ds_tr<4096>(to[dt][0], ao); ds_tr<6144>(to[dt][1], ao); ds_tr<4096>(tq[dt][0], aq); ds_tr<6144>(tq[dt][1], aq); }
@@ -485,7 +499,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(to[0][0]), "+v"(to[0][1]), "+v"(to[1][0]), "+v"(to[1][1]), "+v"(to[2][0]), "+v"(to[2][1]), "+v"(to[3][0]), "+v"(to[3][1]),
                                                   "+v"(tq[0][0]), "+v"(tq[0][1]), "+v"(tq[1][0]), "+v"(tq[1][1]), "+v"(tq[2][0]), "+v"(tq[2][1]), "+v"(tq[3][0]), "+v"(tq[3][1]));
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4; ++dt) if (nb * 4 + dt < DT) {
                 const bf16x8 ot = tr_join(to[dt][0], to[dt][1]), qtf = tr_join(tq[dt][0], tq[dt][1]);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
                 bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HDT;
                 bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT;
 #pragma unroll
-                for (int dt = 0; dt < 4 * NB; ++dt) {
+                for (int dt = 0; dt < DT; ++dt) {
                     DK[dt * 16 + lr] = (bf16_t)(kvis ? dk[kt][dt][r] * p.scale : 0.f);
                     DV[dt * 16 + lr] = (bf16_t)(kvis ? dv[kt][dt][r] : 0.f);
                 }
@@ -520,10 +534,10 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
 // Same arithmetic with the roles swapped: Q (prescaled by c) and dO of the wave's 32 queries stay in registers, -lse * log2(e)
 // and -delta are per-lane constants splatted into the initial accumulators, K / V tiles stream through the DMA ring, and a
 // tile that holds a masked key adds the 0 / -inf key bias before the exp2 (no select).
-template <int NB>
+template <int HD>
 __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
+    constexpr int NB = (HD + 63) / 64, KS = HD / 32, DT = HD / 16, HDT = HD;
     using C = FaCfg<NB>;
-    constexpr int HDT = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -548,7 +562,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
     }
     int myq[2];
-    bf16x8 qf[2][2 * NB], of[2][2 * NB];
+    bf16x8 qf[2][KS], of[2][KS];
     float nl[2], nd[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -558,7 +572,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         nl[qt] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
         nd[qt] = myq[qt] < p.Sq ? -p.delta[li] : 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2 * NB; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             qf[qt][ks] = scale_frag(frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8), c);
             of[qt][ks] = frag_global(DO, p.o_ss, myq[qt], p.Sq, ks * 32 + g * 8);
         }
@@ -566,14 +580,14 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-        for (int ks = 0; ks < 2 * NB; ++ks) asm volatile("" : "+v"(qf[qt][ks]), "+v"(of[qt][ks]));
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qt][ks]), "+v"(of[qt][ks]));
         asm volatile("" : "+v"(nl[qt]), "+v"(nd[qt]));
     }
-    f32x4 dq[2][4 * NB];
+    f32x4 dq[2][DT];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int i = 0; i < 4 * NB; ++i) dq[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < DT; ++i) dq[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned koff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) koff[dt] = lds_u32(smem) + tr_lane_off64(dt * 16, lane);
@@ -582,8 +596,8 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         char* st = smem + sidx * C::STB;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            stage64(K + nb * 64, p.k_ss, it * 64, p.Sk, st + nb * 8192, wave, lane, so_k);
-            stage64(V + nb * 64, p.v_ss, it * 64, p.Sk, st + (NB + nb) * 8192, wave, lane, so_v);
+            stage64(K + nb * 64, p.k_ss, it * 64, p.Sk, st + nb * 8192, wave, lane, so_k, min(8, (HD - nb * 64) / 8), p.zeros);
+            stage64(V + nb * 64, p.v_ss, it * 64, p.Sk, st + (NB + nb) * 8192, wave, lane, so_v, min(8, (HD - nb * 64) / 8), p.zeros);
         }
     };
     if (nt > 0) stage(0, 0);
@@ -612,13 +626,16 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const char* ldsK = st + nb * 8192; const char* ldsV = st + (NB + nb) * 8192;
-                    const bf16x8 ka = frag_row(ldsK, kt * 16 + lr, 0, g), kb = frag_row(ldsK, kt * 16 + lr, 1, g);
-                    const bf16x8 va = frag_row(ldsV, kt * 16 + lr, 0, g), vb = frag_row(ldsV, kt * 16 + lr, 1, g);
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
-                        sv[qt] = MFMA16(kb, qf[qt][2 * nb + 1], MFMA16(ka, qf[qt][2 * nb], sv[qt]));
-                        dpv[qt] = MFMA16(vb, of[qt][2 * nb + 1], MFMA16(va, of[qt][2 * nb], dpv[qt]));
-                    }
+                    for (int k2 = 0; k2 < 2; ++k2)
+                        if (2 * nb + k2 < KS) {
+                            const bf16x8 ka = frag_row(ldsK, kt * 16 + lr, k2, g), va = frag_row(ldsV, kt * 16 + lr, k2, g);
+#pragma unroll
+                            for (int qt = 0; qt < 2; ++qt) {
+                                sv[qt] = MFMA16(ka, qf[qt][2 * nb + k2], sv[qt]);
+                                dpv[qt] = MFMA16(va, of[qt][2 * nb + k2], dpv[qt]);
+                            }
+                        }
                 }
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
@@ -639,10 +656,10 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         for (int nb = 0; nb < NB; ++nb) {
             s16x4 tk[4][2][2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) ds_tr_block(tk[dt], koff[dt] + (unsigned)(sidx * C::STB + nb * 8192));
+            for (int dt = 0; dt < 4; ++dt) if (nb * 4 + dt < DT) ds_tr_block(tk[dt], koff[dt] + (unsigned)(sidx * C::STB + nb * 8192));
             tr_wait4(tk);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4; ++dt) if (nb * 4 + dt < DT) {
                 const bf16x8 k0f = tr_join(tk[dt][0][0], tk[dt][0][1]), k1f = tr_join(tk[dt][1][0], tk[dt][1][1]);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) dq[qt][nb * 4 + dt] = MFMA16(k1f, df[qt][1], MFMA16(k0f, df[qt][0], dq[qt][nb * 4 + dt]));
@@ -657,7 +674,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         if (myq[qt] < p.Sq) {
             bf16_t* DQ = p.dq + b * p.dq_sb + (long)myq[qt] * p.dq_ss + h * HDT;
 #pragma unroll
-            for (int dt = 0; dt < 4 * NB; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 bf16x4 r = {(bf16_t)(dq[qt][dt][0] * p.scale), (bf16_t)(dq[qt][dt][1] * p.scale), (bf16_t)(dq[qt][dt][2] * p.scale), (bf16_t)(dq[qt][dt][3] * p.scale)};
                 *reinterpret_cast<bf16x4*>(DQ + dt * 16 + g * 4) = r;
             }
@@ -666,14 +683,27 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 
 }  // namespace
 
-// entry points used by pb_flash.hip's dispatch (same argument meaning as pb_flash_fwd / pb_flash_bwd; hd = 64 or 128)
-template <int NB>
+// 256 bytes of device zeros per device, allocated on first use (never freed: lives as long as the process' HIP context)
+static const bf16_t* fa_zero_page() {
+    static void* pages[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = p;
+    }
+    return (const bf16_t*)pages[dev];
+}
+
+// entry points used by pb_flash.hip's dispatch (same argument meaning as pb_flash_fwd / pb_flash_bwd; hd = 64, 96 or 128)
+template <int HD>
 static int fa64_fwd_launch(const Fa64Args& a, hipStream_t stream) {
-    using C = FaCfg<NB>;
+    using C = FaCfg<(HD + 63) / 64>;
     const size_t lds = (size_t)C::NS * C::STB + (size_t)((a.Sk + 63) / 64) * (64 * 4 + 4);
     PB_REQUIRE(lds <= 160 * 1024, "pb_flash_fwd: Sk=%d needs %zu bytes of LDS", a.Sk, lds);
-    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_fwd_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(fa64_fwd_kernel<NB>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds, stream, a);
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_fwd_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fa64_fwd_kernel<HD>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds, stream, a);
     PB_LAUNCH_CHECK();
     return 0;
 }
@@ -684,21 +714,23 @@ int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* 
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal;
-    return hd == 128 ? fa64_fwd_launch<2>(a, stream) : fa64_fwd_launch<1>(a, stream);
+    a.zeros = fa_zero_page();
+    PB_REQUIRE(a.zeros != nullptr, "pb_flash_fwd: cannot allocate the zero page");
+    return hd == 128 ? fa64_fwd_launch<128>(a, stream) : hd == 96 ? fa64_fwd_launch<96>(a, stream) : fa64_fwd_launch<64>(a, stream);
 }
 
-template <int NB>
+template <int HD>
 static int fa64_bwd_launch(const Fa64Args& a, hipStream_t stream) {
-    using C = FaCfg<NB>;
+    using C = FaCfg<(HD + 63) / 64>;
     const size_t lds_dkv = (size_t)C::NS * C::STB + (size_t)((a.Sq + 63) / 64) * 64 * 8;
     const size_t lds_dq = (size_t)C::NS * C::STB + (size_t)((a.Sk + 63) / 64) * (64 * 4 + 4);
     PB_REQUIRE(lds_dkv <= 160 * 1024 && lds_dq <= 160 * 1024, "pb_flash_bwd: Sq=%d Sk=%d need %zu / %zu bytes of LDS", a.Sq, a.Sk, lds_dkv, lds_dq);
-    if (lds_dkv > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dkv_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
-    if (lds_dq > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dq_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+    if (lds_dkv > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dkv_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+    if (lds_dq > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dq_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
     constexpr int BK_ = 64 * C::KT;
-    hipLaunchKernelGGL(fa64_bwd_dkv_kernel<NB>, dim3(((a.Sk + BK_ - 1) / BK_) * a.H * a.B), dim3(FT), lds_dkv, stream, a);
+    hipLaunchKernelGGL(fa64_bwd_dkv_kernel<HD>, dim3(((a.Sk + BK_ - 1) / BK_) * a.H * a.B), dim3(FT), lds_dkv, stream, a);
     PB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fa64_bwd_dq_kernel<NB>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds_dq, stream, a);
+    hipLaunchKernelGGL(fa64_bwd_dq_kernel<HD>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds_dq, stream, a);
     PB_LAUNCH_CHECK();
     return 0;
 }
@@ -713,5 +745,7 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
     a.scale = scale; a.causal = causal;
-    return hd == 128 ? fa64_bwd_launch<2>(a, stream) : fa64_bwd_launch<1>(a, stream);
+    a.zeros = fa_zero_page();
+    PB_REQUIRE(a.zeros != nullptr, "pb_flash_bwd: cannot allocate the zero page");
+    return hd == 128 ? fa64_bwd_launch<128>(a, stream) : hd == 96 ? fa64_bwd_launch<96>(a, stream) : fa64_bwd_launch<64>(a, stream);
 }

@@ -60,7 +60,7 @@ class Engine:
         self.step_count = 0
         self.opt_m = self.opt_v = None
         self._versions = None
-        self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 128))
+        self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 96, 128))
         self._slabs = None
         self._kmax = {}
         self.grad_hook = None          # callable(lo, hi): flat gradient range is final (data-parallel bucketing)
@@ -296,7 +296,7 @@ class Engine:
         self.build_ptab()
         # per-batch-row key extents (1 + last visible key): the attention kernels skip the masked PAD tail tile-wise
         self._kmax = {}
-        if self.use_flash and self.hd == 64:
+        if self.use_flash and self.hd in (64, 96, 128):
             for msk in (emask, dmask):
                 if msk is not None and id(msk) not in self._kmax:
                     km = torch.empty(msk.shape[0], dtype=torch.int32, device=msk.device)

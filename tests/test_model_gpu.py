@@ -275,8 +275,9 @@ def test_generate_kv_cache_equals_full_rerun(precision):
 
 
 @pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 8e-2)])
-def test_head_dim_96_falls_back_to_unfused_attention(precision, tol):
-    """Reference CLI default heads=8 gives head_dim 96 at d=768: not covered by the flash kernels -> GEMM + masked softmax."""
+def test_head_dim_96(precision, tol):
+    """Reference CLI default heads=8 gives head_dim 96 at d=768: fused attention with a half-filled second [64][64] image (bf16);
+    GEMM + masked softmax in the exact-f32 instantiation."""
     _need_gpu()
     from oracle import pianobart_oracle as O
     m = _lm(40, 192, 1, 256, 2, 5, precision, dropout=0.0).train()
