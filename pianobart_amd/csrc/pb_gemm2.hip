@@ -13,8 +13,11 @@
 //     summed by pb_reduce_slabs: deterministic, no atomics;
 //   * the epilogue stays in registers: operand-swapped MFMAs + v_permlane16_swap give every lane 8 consecutive
 //     output columns, stored as 16-byte row segments (epilogue_regs).
-// Tile 128x128x64, 256 threads (2x2 waves of 64x64 = 4x4 MFMA 16x16x32), 2 LDS stages of 32 KiB;
-// per K tile: issue next tile's 8 DMA pieces -> 32 MFMAs on the current tile -> vmcnt(0) + barrier.
+// Two kernels:
+//   gemm3_kernel  256x256x64 tile, 8 waves, persistent, ping-pong schedule with the DMA prefetch in flight across barriers
+//                 (every output at least 512 wide, and the split-K wgrads);
+//   gemm2_kernel  128x128x64 tile, 4 waves (2x2 of 64x64), 2 LDS stages, one barrier per K tile, 2 workgroups per CU
+//                 (narrow outputs, the 768x768 split-K wgrads; also the 256x256 one-barrier form kept for A/B runs).
 // Requirements (else pb_gemm falls back to pb_gemm.hip): K % 64 == 0 per split, 16-byte aligned rows,
 // contiguous dims multiples of 8.
 #include "pb_common.h"
@@ -210,12 +213,9 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
     }
 }
 
-// WM x WN waves, each TM x TN MFMA tiles of 16x16: block tile BM = 16*WM*TM by BN = 16*WN*TN.
-// Measured (tools/gemm_probe.py, MI355X): the 128x128 main loop is bound by the L2 -> LDS load path (~60 GB/s per CU,
-// 64 FLOP per loaded byte -> ~1 PF ceiling), the 256x256 one reaches 1.1-1.2 PF; the output write (HBM write rate,
-// ~3.1 TB/s) is NOT overlapped with the main loop. Tried and measured (tools/gemm_probe.py history): persistent tiles with
-// stores left in flight, register epilogue with swapped MFMA operands, non-temporal stores, and the store traffic spread
-// over the K loop of the same launch (hides only ~1/3 of it) -- none pays; the 8-phase counted-vmcnt pipeline is next.
+// One-barrier kernel. WM x WN waves, each TM x TN MFMA tiles of 16x16: block tile BM = 16*WM*TM by BN = 16*WN*TN.
+// Measured: the 128x128 main loop is bound by the L2 -> LDS load path (64 FLOP per loaded byte, ~1 PF ceiling); with two
+// workgroups per CU one's store tail overlaps the other's main loop, which is why it still serves the narrow outputs.
 template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
     const long coff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
     const int kbeg = zs * p.Kc, kend = min(p.K, kbeg + p.Kc);
-    const int nk = (p.flags & 256) ? 0 : max(0, kend - kbeg) / BK;   // bit 8: profiling build of the epilogue alone
+    const int nk = max(0, kend - kbeg) / BK;
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -550,7 +550,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 256 | 2048 | 4096)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue");
         return -2;
     }
@@ -572,8 +572,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // the small split-K wgrads (768 x 768: 692 vs 620 TF). TN callers pass PB_GEMM_TILE256 together with their split-K factor.
     const bool big = !(d->flags & PB_GEMM_TILE128) && d->M >= 256 && d->N >= 256 &&
                      ((d->flags & PB_GEMM_TILE256) || (nsplit == 1 && d->M >= 2048 && d->N >= 512));
-    const bool tall = !big && (d->flags & 512) && d->M >= 1024;   // measured: no gain over 128x128 (tools/gemm_bench.py), kept for experiments      // 256x128: 8 waves of 64x64, 25% less L2->LDS traffic per FLOP
-    const int BMs = (big || tall) ? 256 : 128, BNs = big ? 256 : 128;
+    const int BMs = big ? 256 : 128, BNs = big ? 256 : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
     a.nsplit = nsplit;
     dim3 grid(a.tiles_m * a.tiles_n * nsplit, nb1 * a.nb2, 1);
@@ -584,12 +583,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, stream, a);                                                \
     } while (0)
-    if (tall) {
-        if (a_kc && b_kc) PB_G2_LAUNCH(true, true, 4, 2, 4, 4);
-        else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 4, 2, 4, 4);
-        else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 4, 2, 4, 4);
-        else PB_G2_LAUNCH(false, false, 4, 2, 4, 4);
-    } else if (big && !(d->flags & 2048)) {                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
+    if (big && !(d->flags & 2048)) {                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
         auto kfn = gemm3_kernel<AK, BK_>;                                                                                  \
