@@ -35,7 +35,11 @@ const char* pb_last_error(void);
 #define PB_GEMM_MUL_GELU_GRAD 8  /* C = result * aux_in      ... the backward of the activation (dU = dG * gelu'(U)) is one multiply        */
 #define PB_GEMM_FORCE_V1 16      /* use the generic register-staged kernel (tests)    */
 #define PB_GEMM_TILE128 32       /* bf16 fast path: force the 128x128 tile             */
-#define PB_GEMM_TILE256 64       /* bf16 fast path: prefer the 256x256 tile (default when M >= 512, N >= 256) */
+#define PB_GEMM_TILE256 64       /* bf16 fast path: prefer the 256x256 tile (default when M >= 2048, N >= 512, no split-K) */
+#define PB_GEMM_NO_EPILOGUE 128  /* profiling: main loop only, nothing is stored                                    */
+#define PB_GEMM_ONE_BARRIER 2048 /* A/B runs: 256x256 tile with the one-barrier kernel instead of the ping-pong one   */
+#define PB_GEMM_PLAIN_GRID 4096  /* 256x256 ping-pong kernel as an ordinary grid (one workgroup per work item) instead of the
+                                    persistent one-per-CU grid: what to ask for when other kernels (RCCL) hold CUs        */
 typedef struct pb_gemm_desc {
     const void* A; const void* B; void* C;
     const float* bias;            /* per-n, may be NULL */
