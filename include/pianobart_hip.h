@@ -51,8 +51,13 @@ typedef struct pb_gemm_desc {
     float alpha; float _pad2;
     int32_t splitk; int32_t _pad3;   /* >1: split K over blockIdx.z into f32 slabs (bf16, f32 C, no epilogue) */
     void* slabs;                      /* workspace of splitk*M*N floats when splitk > 1 */
+    float* colsum_out;                /* optional: colsum_out[n] += sum_m C[m][n] (the bias gradient of the layer that produced C's
+                                         cotangent, e.g. db1 from dU): taken from the epilogue registers of the 256x256 kernel, by a
+                                         pb_colsum pass over C otherwise. Needs colsum_ws; single batch, no split-K */
+    float* colsum_ws;                 /* workspace of pb_gemm_colsum_ws_floats(M, N) floats */
 } pb_gemm_desc;
 int pb_gemm(const pb_gemm_desc* d, void* stream);
+int64_t pb_gemm_colsum_ws_floats(int32_t M, int32_t N);
 
 /* ---- K1/K2: Octuple gather-sum + position + LayerNorm (+dropout) -----------------------------
  * Replaces PianoBart.py:60-71 (8 x Embedding*16 -> cat -> Linear) and modeling_bart.py:520-525 /

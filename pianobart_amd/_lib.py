@@ -26,7 +26,8 @@ class GemmDesc(ctypes.Structure):
                 ('sA1', ctypes.c_int64), ('sA2', ctypes.c_int64), ('sB1', ctypes.c_int64), ('sB2', ctypes.c_int64),
                 ('sC1', ctypes.c_int64), ('sC2', ctypes.c_int64),
                 ('alpha', ctypes.c_float), ('_pad2', ctypes.c_float),
-                ('splitk', ctypes.c_int32), ('_pad3', ctypes.c_int32), ('slabs', ctypes.c_void_p)]
+                ('splitk', ctypes.c_int32), ('_pad3', ctypes.c_int32), ('slabs', ctypes.c_void_p),
+                ('colsum_out', ctypes.c_void_p), ('colsum_ws', ctypes.c_void_p)]
 
 
 class DecodeLayer(ctypes.Structure):

@@ -18,6 +18,7 @@
 // issued before the MFMAs of tile k (register prefetch), one barrier per K tile, 2 LDS buffers.
 #include "pb_common.h"
 #include "pb_api_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -300,6 +301,12 @@ int launch_gemm(const GemmArgs& a, int a_kc, int b_kc, int nbatch, hipStream_t s
 
 }  // namespace
 
+// column sums of the stored C by a separate streaming pass (paths whose epilogue does not produce them)
+static int colsum_of_c(const pb_gemm_desc* d, void* stream_) {
+    const bool c32 = (d->flags & PB_GEMM_C_F32) || d->dtype == PB_F32;
+    return pb_colsum(d->C, d->ldc, d->colsum_out, d->colsum_ws, d->M, d->N, c32 ? PB_F32 : PB_BF16, c32 ? 1 : 0, stream_);
+}
+
 extern "C" int pb_gemm(const pb_gemm_desc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PB_REQUIRE(d != nullptr, "pb_gemm: null descriptor");
@@ -309,9 +316,13 @@ extern "C" int pb_gemm(const pb_gemm_desc* d, void* stream_) {
     PB_REQUIRE(d->A && d->B && d->C, "pb_gemm: null operand");
     PB_REQUIRE(!(d->flags & PB_GEMM_GELU) || d->aux_out, "pb_gemm: GELU epilogue needs aux_out");
     PB_REQUIRE(!(d->flags & PB_GEMM_MUL_GELU_GRAD) || d->aux_in, "pb_gemm: gelu-grad epilogue needs aux_in");
+    const int nbt = (d->nb1 > 0 ? d->nb1 : 1) * (d->nb2 > 0 ? d->nb2 : 1);
+    PB_REQUIRE(!d->colsum_out || (d->colsum_ws && nbt == 1 && d->ldc == d->N), "pb_gemm: colsum_out needs colsum_ws, one batch and a dense C");
     if (!(d->flags & PB_GEMM_FORCE_V1)) {
-        const int r2 = pb_gemm2_try(d, stream_);
-        if (r2 <= 0) return r2;
+        const int r2 = pb_gemm2_try(d, stream_);     // 0: done (column sums included), 2: done but the column sums are still owed, 1: declined
+        if (r2 < 0) return r2;
+        if (r2 == 0) return 0;
+        if (r2 == 2) return colsum_of_c(d, stream_);
     }
     const int esz = d->dtype == PB_BF16 ? 2 : 4, epv = 16 / esz;
     GemmArgs a;
@@ -328,6 +339,13 @@ extern "C" int pb_gemm(const pb_gemm_desc* d, void* stream_) {
     a.b_aligned = aligned(d->B, d->ldb, d->sB1, d->sB2);
     a.tiles_m = (d->M + BM - 1) / BM; a.tiles_n = (d->N + BN - 1) / BN;
     PB_REQUIRE((long)nb1 * a.nb2 <= 65535, "pb_gemm: too many batches");
-    if (d->dtype == PB_BF16) return launch_gemm<bf16_t>(a, d->a_kcontig, d->b_kcontig, nb1 * a.nb2, stream);
-    return launch_gemm<float>(a, d->a_kcontig, d->b_kcontig, nb1 * a.nb2, stream);
+    const int rc = d->dtype == PB_BF16 ? launch_gemm<bf16_t>(a, d->a_kcontig, d->b_kcontig, nb1 * a.nb2, stream)
+                                       : launch_gemm<float>(a, d->a_kcontig, d->b_kcontig, nb1 * a.nb2, stream);
+    if (rc) return rc;
+    return d->colsum_out ? colsum_of_c(d, stream_) : 0;
+}
+
+extern "C" int64_t pb_gemm_colsum_ws_floats(int32_t M, int32_t N) {
+    const int64_t fused = 2LL * ((M + 255) / 256) * N;                  // one partial row per (256-row tile, wave row) of the 256x256 kernel
+    return std::max<int64_t>(fused, pb_colsum_partials_floats(N));
 }

@@ -36,6 +36,7 @@ struct Gemm2Args {
     long lda, ldb, ldc, ldaux;
     int nb2; long sA1, sA2, sB1, sB2, sC1, sC2, sCz;
     float alpha; int flags; int tiles_m, tiles_n, nsplit;
+    float* cs_ws;                         // column-sum partials (2 tiles_m rows of N floats) or NULL
 };
 
 __device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
@@ -146,7 +147,8 @@ __device__ __forceinline__ void block_tile(const Gemm2Args& p, int L, int& m0, i
 // panel this replaces cost about a third of the store tail of a 256 x 256 tile, and its 8-byte stores another 6 %.
 template <int TM>
 __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[TM][4], int mw /*wave's first row*/, int nw /*first column*/, long coff, int lane,
-                                              const float* lds_bias = nullptr /*bias[nw ..] staged in LDS by the caller*/) {
+                                              const float* lds_bias = nullptr /*bias[nw ..] staged in LDS by the caller*/,
+                                              float* cs_row = nullptr /*this wave row's column-sum partials: N floats*/) {
     const int lr = lane & 15, lg = lane >> 4;
     const bool accum = p.flags & PB_GEMM_ACCUM, c32 = p.flags & PB_GEMM_C_F32;
     const bool do_gelu = p.flags & PB_GEMM_GELU, mul_gg = p.flags & PB_GEMM_MUL_GELU_GRAD;
@@ -167,6 +169,7 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
             bv[jp][1] = has ? *reinterpret_cast<const f32x4*>(p.bias + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    f32x4 cs[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = mw + i * 16 + lr;
@@ -207,6 +210,34 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
                 } else {
                     if (accum) { f32x4 c0, c1; load8(CT + ci, c0, c1); v0 += c0; v1 += c1; }
                     store8(CT + ci, v0, v1);
+                }
+                if (cs_row) { cs[jp][0] += v0; cs[jp][1] += v1; }
+            }
+        }
+    }
+    if (cs_row) {
+        // column sums of the wave's TM x 16 rows: the 16 lanes of a DPP row hold 16 different rows of the same 8 columns ->
+        // mirror / half-mirror / quad permutes add them up inside the row; lane lr = 0 of each row stores its 2 x 8 sums
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = cs[jp][hh][e];
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+                    cs[jp][hh][e] = v;
+                }
+        if (lr == 0) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const int col = nw + jp * 32 + cb;
+                if (col < p.N) {
+                    *reinterpret_cast<f32x4*>(cs_row + col) = cs[jp][0];
+                    *reinterpret_cast<f32x4*>(cs_row + col + 4) = cs[jp][1];
                 }
             }
         }
@@ -488,13 +519,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             nk = max(0, min(p.K, kbeg + p.Kc) - kbeg) / BK;
             G3_PROLOGUE();
         }
-        if (!(p.flags & 128)) epilogue_regs<8>(p, acc, em0 + wr * 128, en0 + wc * 64, ecoff, lane, ebias);   // bit 7: profiling build without the epilogue
+        if (!(p.flags & 128)) epilogue_regs<8>(p, acc, em0 + wr * 128, en0 + wc * 64, ecoff, lane, ebias,
+                                                   p.cs_ws ? p.cs_ws + (long)((em0 >> 8) * 2 + wr) * p.N : nullptr);   // bit 7: profiling build without the epilogue
         if (!more) break;
         {   // an interior tile without read-modify-write issues exactly 8 x 2 (x 2 for f32 C or the GELU pair) stores per wave
             const bool interior = em0 + 256 <= p.M && en0 + 256 <= p.N;
             const bool plain = !(p.flags & (PB_GEMM_ACCUM | PB_GEMM_MUL_GELU_GRAD | 128));
             pend = (interior && plain) ? (((p.flags & PB_GEMM_C_F32) || (p.flags & PB_GEMM_GELU)) ? 32 : 16) : 0;
-            if ((p.flags & PB_GEMM_C_F32) && (p.flags & PB_GEMM_GELU)) pend = 0;
+            if (((p.flags & PB_GEMM_C_F32) && (p.flags & PB_GEMM_GELU)) || p.cs_ws) pend = 0;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -565,7 +597,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if (nsplit > 1 && nb1 * a.nb2 != 1) { pb_set_error("pb_gemm: split-K with batches is not supported"); return -2; }
     a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2; a.sC1 = d->sC1; a.sC2 = d->sC2;
     a.sCz = (long)d->M * d->N;
-    a.alpha = d->alpha; a.flags = d->flags;
+    a.alpha = d->alpha; a.flags = d->flags; a.cs_ws = nullptr;
     // Tile / kernel choice, from same-process A/B runs of every cfg-2 shape (tools/gemm_ab.py, T = 32768 tokens):
     // the 256x256 ping-pong kernel wherever the output is at least 512 wide -- NT fc1 910 vs 750 TF (128x128), fc2 1110 vs 1050,
     // NN dfc1 937 vs 899, TN w1 930 vs 820 (one-barrier 256x256) -- and 128x128 tiles (2 workgroups per CU) below that and for
@@ -583,7 +615,9 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, stream, a);                                                \
     } while (0)
-    if (big && !(d->flags & 2048)) {                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
+    bool cs_fused = false;
+    if (big && !(d->flags & 2048)) {
+        if (d->colsum_out && nsplit == 1 && nb1 * a.nb2 == 1) { a.cs_ws = d->colsum_ws; cs_fused = true; }                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
         auto kfn = gemm3_kernel<AK, BK_>;                                                                                  \
@@ -609,6 +643,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     }
 #undef PB_G2_LAUNCH
     if (hipGetLastError() != hipSuccess) { pb_set_error("pb_gemm2 launch failed"); return -1; }
+    if (cs_fused && pb_finalize_rows(d->colsum_ws, 2 * a.tiles_m, d->N, d->colsum_out, stream)) return -1;
     if (nsplit > 1) {
         if (d->ldc != d->N) { pb_set_error("pb_gemm: split-K needs a dense C (ldc == N)"); return -2; }
         const long n = (long)d->M * d->N;
@@ -616,5 +651,5 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(g), dim3(256), 0, stream, (const float*)d->slabs, nsplit, n, (float*)d->C);
         if (hipGetLastError() != hipSuccess) { pb_set_error("pb_reduce_slabs launch failed"); return -1; }
     }
-    return 0;
+    return (d->colsum_out && !cs_fused) ? 2 : 0;
 }

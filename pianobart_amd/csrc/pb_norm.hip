@@ -361,6 +361,10 @@ static int launch_finalize(const float* partials, int nblk, int nacc, int d, flo
     return 0;
 }
 
+int pb_finalize_rows(const float* partials, int nblk, int d, float* out, void* stream) {
+    return launch_finalize(partials, nblk, 1, d, out, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
 extern "C" int pb_add_ln_bwd(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
                              const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
                              float* partials, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32, int32_t accum_dres,

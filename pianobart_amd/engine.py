@@ -380,6 +380,12 @@ class Engine:
         """out(T,N) (+)= dy(T,K) @ W(K,N)   (NN GEMM, W stored [K][N])."""
         ops.gemm(dy, self.w[wname], out, M=T, N=N, K=K, dtype=self.code, b_kc=False, lda=ldy or K, ldb=N, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
 
+    def _cs_ws(self, M, N):
+        need = int(LIB.query('pb_gemm_colsum_ws_floats', M, N))
+        if getattr(self, '_csbuf', None) is None or self._csbuf.numel() < need:
+            self._csbuf = torch.empty(need, dtype=torch.float32, device=self.device)
+        return self._csbuf
+
     def _bwd_dbg(self):
         """Backward GEMMs that can run beside in-flight gradient all-reduces (data parallel: grad_hook set) are launched as ordinary
         grids (bit 12): a persistent one-workgroup-per-CU grid whose CUs are partly held by RCCL's kernels would run its stragglers as
@@ -396,8 +402,8 @@ class Engine:
         gb = gB if p > 0 else gA
         self._wgrad(gb, L['g'], pf + 'w2', d, ff, T)
         du = ws['du'][:, :ff] if ws['du'].shape[1] == ff else ws['du'].view(-1)[:T * ff].view(T, ff)
-        self._dgrad(gb, pf + 'w2', du, T, ff, d, False, gelu_grad_aux_in=L['u'], ldaux=ff)
-        ops.colsum(du, g[pf + 'b1'], self.partials, T, ff)
+        # dU = (dG W2) * gelu'(U), and db1 = column sums of dU straight from the same epilogue registers
+        self._dgrad(gb, pf + 'w2', du, T, ff, d, False, gelu_grad_aux_in=L['u'], ldaux=ff, colsum_out=g[pf + 'b1'], colsum_ws=self._cs_ws(T, ff))
         self._wgrad(du, y_in, pf + 'w1', ff, d, T)
         self._dgrad(du, pf + 'w1', gA, T, d, ff, True)
         return gA

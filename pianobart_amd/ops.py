@@ -48,7 +48,8 @@ def _p(t):
 
 def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=None, bias=None, alpha=1.0,
          accum=False, c_f32=False, gelu_aux_out=None, gelu_grad_aux_in=None, ldaux=0, nb1=1, nb2=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, splitk=1, slabs=None, force_v1=False, tile128=False, tile256=False, dbg=0):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, splitk=1, slabs=None, force_v1=False, tile128=False, tile256=False, dbg=0,
+         colsum_out=None, colsum_ws=None):
     """C[m,n] (+)= epi(alpha * sum_k A(m,k) B(n,k)). a_off/b_off/c_off are element offsets into the tensors."""
     d = GemmDesc()
     esz = 2 if dtype == PB_BF16 else 4
@@ -64,6 +65,8 @@ def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, l
               (16 if force_v1 else 0) | (32 if tile128 else 0) | (64 if tile256 else 0) | dbg
     d.splitk = splitk if (splitk > 1 and slabs is not None) else 1
     d.slabs = slabs.data_ptr() if (splitk > 1 and slabs is not None) else None
+    d.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
+    d.colsum_ws = colsum_ws.data_ptr() if colsum_ws is not None else None
     d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, nb1, nb2
     d.lda = lda if lda is not None else (K if a_kc else M)
     d.ldb = ldb if ldb is not None else (K if b_kc else N)

@@ -23,7 +23,7 @@ def test_header_parses_and_library_exports_all():
 
 def test_gemm_desc_layout_matches_header():
     # 6 pointers + 10 int32 + 10 int64 + 2 floats + 2 int32 + 1 pointer
-    assert ctypes.sizeof(_lib.GemmDesc) == 6 * 8 + 10 * 4 + 10 * 8 + 2 * 4 + 2 * 4 + 8
+    assert ctypes.sizeof(_lib.GemmDesc) == 6 * 8 + 10 * 4 + 10 * 8 + 2 * 4 + 2 * 4 + 8 + 2 * 8
 
 
 def test_ops_refuse_cpu_tensors():

@@ -366,3 +366,21 @@ def test_onehot_route_matches_atomic_scatter(ops):
     out = torch.ones(S, d, device='cuda')
     ops.batch_sum(dz, out, B, S * d)
     assert _rel(out, 1 + dz.double().reshape(B, S, d).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('M,N,K,dt', [(4096, 768, 256, torch.bfloat16), (520, 1280, 128, torch.bfloat16), (192, 320, 128, torch.bfloat16), (192, 320, 128, torch.float32)])
+def test_gemm_fused_column_sums(ops, M, N, K, dt):
+    """colsum_out += column sums of the stored C (bias gradient), from the 256x256 kernel's epilogue registers (first two shapes:
+    interior and ragged tiles) or by the streaming pass behind the other kernels."""
+    from pianobart_amd._lib import LIB
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    A = torch.randn(M, K, device='cuda', generator=g).to(dt)
+    W = (torch.randn(K, N, device='cuda', generator=g) / math.sqrt(K)).to(dt)       # NN layout, like dgrad
+    aux = torch.randn(M, N, device='cuda', generator=g).to(dt)
+    C = torch.empty(M, N, device='cuda', dtype=dt)
+    cs = torch.full((N,), 0.5, device='cuda')
+    ws = torch.empty(int(LIB.query('pb_gemm_colsum_ws_floats', M, N)), device='cuda')
+    ops.gemm(A, W, C, M=M, N=N, K=K, dtype=ops.dtype_code(dt), b_kc=False, ldb=N, gelu_grad_aux_in=aux, colsum_out=cs, colsum_ws=ws)
+    ref = (A.double() @ W.double()) * aux.double()
+    assert _rel(C, ref) < TOL[dt]
+    assert _rel(cs, 0.5 + ref.sum(0)) < (2e-3 if dt == torch.bfloat16 else 1e-5)
