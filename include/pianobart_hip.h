@@ -125,7 +125,12 @@ int pb_flash_bwd(const void* q, const void* k, const void* v, const void* o, con
                  int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss,
                  int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss,
                  int64_t dq_sb, int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss,
-                 float scale, int32_t causal, void* stream);
+                 float scale, int32_t causal,
+                 float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws /* optional (all or none; head_dim 64/96/128): dbias_x[c] +=
+                     column sums of dQ / dK / dV over (batch, position) = the bias gradients of the q / k / v projections, taken from the
+                     kernels' epilogue registers; dbias_ws: pb_flash_bias_ws_floats(B, H, Sq, Sk, hd) floats */,
+                 void* stream);
+int64_t pb_flash_bias_ws_floats(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd);
 
 /* ---- K9: fused 8-segment log-softmax + CE + argmax + masked accuracy (+ dlogits) ----------------
  * Replaces pretrain.py:112-118,163-189 (np.argmax x8, CrossEntropyLoss x8, masked means).

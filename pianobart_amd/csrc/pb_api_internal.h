@@ -4,5 +4,5 @@
 
 // pb_gemm2.hip: bf16 fast path; returns 1 when it declines (caller falls back), 0 ok, <0 error.
 int pb_gemm2_try(const pb_gemm_desc* d, void* stream);
-// out[c] += sum over nblk rows of partials (nblk, d) (pb_norm.hip)
-int pb_finalize_rows(const float* partials, int nblk, int d, float* out, void* stream);
+// o_k[c] += sum over nblk rows of partials (nblk, nacc, d), k < nacc <= 2 (pb_norm.hip)
+int pb_finalize_rows(const float* partials, int nblk, int d, float* out, void* stream, int nacc = 1, float* out1 = nullptr);

@@ -409,7 +409,7 @@ int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* 
 int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, const float* key_mask,
                    const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, int hd, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
-                   int causal, hipStream_t stream);
+                   int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream);
 
 namespace {
 __global__ void key_extent_kernel(const float* __restrict__ key_mask, int* __restrict__ kmax, int Sk) {
@@ -461,7 +461,8 @@ extern "C" int pb_flash_bwd(const void* q, const void* k, const void* v, const v
                             const float* key_mask, const int32_t* kmax, void* dq, void* dk, void* dv, float* delta, int32_t B, int32_t H, int32_t Sq,
                             int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb,
                             int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb, int64_t dq_ss, int64_t dk_sb, int64_t dk_ss,
-                            int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, void* stream_) {
+                            int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws,
+                            void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_common("pb_flash_bwd", hd, q_ss, k_ss, v_ss, o_ss)) return -2;
     PB_REQUIRE(dq_ss % 4 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0, "pb_flash_bwd: bad strides");
@@ -479,7 +480,8 @@ extern "C" int pb_flash_bwd(const void* q, const void* k, const void* v, const v
     PB_LAUNCH_CHECK();
     if ((hd == 64 || hd == 96 || hd == 128) && !(causal & 2))
         return pb_flash64_bwd(q, k, v, dout, lse, delta, key_mask, kmax, dq, dk, dv, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss,
-                              dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, scale, causal & 1, stream);
+                              dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, scale, causal & 1, dbias_q, dbias_k, dbias_v, dbias_ws, stream);
+    PB_REQUIRE(!dbias_q, "pb_flash_bwd: fused bias gradients exist in the pipelined kernels (head_dim 64 / 96 / 128) only");
     dim3 gk((Sk + TK - 1) / TK, H, B), gq((Sq + TQ - 1) / TQ, H, B);
     if (hd == 128) {   // 4 x 16 KiB tiles exceed the default 64 KiB dynamic-LDS limit
         PB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 512));

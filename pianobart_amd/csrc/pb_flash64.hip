@@ -24,6 +24,7 @@ struct Fa64Args {
     int B, H, Sq, Sk;
     long q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
     float scale; int causal;
+    float* cs_q; float* cs_kv;        // bias-gradient partials (column sums of dQ | of dK, dV), or NULL
     const bf16_t* zeros;              // >= 16 bytes of zeros (source of the column chunks beyond head_dim in a partly filled image)
 };
 
@@ -512,6 +513,9 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         __builtin_amdgcn_s_barrier();
         sidx = sidx == C::NS - 1 ? 0 : sidx + 1;
     }
+    float csk[DT], csv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { csk[dt] = 0.f; csv[dt] = 0.f; }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -523,11 +527,22 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
                 bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    DK[dt * 16 + lr] = (bf16_t)(kvis ? dk[kt][dt][r] * p.scale : 0.f);
-                    DV[dt * 16 + lr] = (bf16_t)(kvis ? dv[kt][dt][r] : 0.f);
+                    const float vk = kvis ? dk[kt][dt][r] * p.scale : 0.f, vv = kvis ? dv[kt][dt][r] : 0.f;
+                    DK[dt * 16 + lr] = (bf16_t)vk;
+                    DV[dt * 16 + lr] = (bf16_t)vv;
+                    csk[dt] += vk; csv[dt] += vv;
                 }
             }
         }
+    if (p.cs_kv) {      // bias gradients: column sums of this wave's dK / dV rows -> partial row (b, key block, wave), head h's columns
+        const int nkb = (p.Sk + BK_ - 1) / BK_, d_model = p.H * HDT;
+        float* row = p.cs_kv + ((long)(b * nkb + rb) * 4 + wave) * 2 * d_model + h * HDT;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float sk = grp_sum(csk[dt]), sv_ = grp_sum(csv[dt]);
+            if (g == 0) { row[dt * 16 + lr] = sk; row[d_model + dt * 16 + lr] = sv_; }
+        }
+    }
 }
 
 // ================================================================== backward dQ: block = 128 queries
@@ -669,16 +684,38 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         __builtin_amdgcn_s_barrier();
         sidx = sidx == C::NS - 1 ? 0 : sidx + 1;
     }
+    f32x4 csq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) csq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
         if (myq[qt] < p.Sq) {
             bf16_t* DQ = p.dq + b * p.dq_sb + (long)myq[qt] * p.dq_ss + h * HDT;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                bf16x4 r = {(bf16_t)(dq[qt][dt][0] * p.scale), (bf16_t)(dq[qt][dt][1] * p.scale), (bf16_t)(dq[qt][dt][2] * p.scale), (bf16_t)(dq[qt][dt][3] * p.scale)};
+                const f32x4 v = dq[qt][dt] * p.scale;
+                bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                 *reinterpret_cast<bf16x4*>(DQ + dt * 16 + g * 4) = r;
+                csq[dt] += v;
             }
         }
+    if (p.cs_q) {       // bias gradient of the q projection: the 16 lanes of a DPP row hold 16 queries of the same 4 columns
+        const int nqb = (p.Sq + 127) / 128, d_model = p.H * HDT;
+        float* row = p.cs_q + ((long)(b * nqb + rb) * 4 + wave) * d_model + h * HDT;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = csq[dt][e];
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+                csq[dt][e] = v;
+            }
+            if (lr == 0) *reinterpret_cast<f32x4*>(row + dt * 16 + g * 4) = csq[dt];
+        }
+    }
 }
 
 }  // namespace
@@ -738,7 +775,7 @@ static int fa64_bwd_launch(const Fa64Args& a, hipStream_t stream) {
 int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, const float* key_mask,
                    const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, int hd, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
-                   int causal, hipStream_t stream) {
+                   int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream) {
     Fa64Args a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask; a.kmax = kmax;
@@ -747,5 +784,19 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout
     a.scale = scale; a.causal = causal;
     a.zeros = fa_zero_page();
     PB_REQUIRE(a.zeros != nullptr, "pb_flash_bwd: cannot allocate the zero page");
-    return hd == 128 ? fa64_bwd_launch<128>(a, stream) : hd == 96 ? fa64_bwd_launch<96>(a, stream) : fa64_bwd_launch<64>(a, stream);
+    const int kt_ = hd == 64 ? 2 : 1, nkb = (Sk + 64 * kt_ - 1) / (64 * kt_), nqb = (Sq + 127) / 128, d_model = H * hd;
+    if (dbias_q) {
+        PB_REQUIRE(dbias_k && dbias_v && dbias_ws, "pb_flash_bwd: dbias_q/k/v and dbias_ws go together");
+        a.cs_kv = dbias_ws; a.cs_q = dbias_ws + (size_t)B * nkb * 4 * 2 * d_model;
+    }
+    const int rc = hd == 128 ? fa64_bwd_launch<128>(a, stream) : hd == 96 ? fa64_bwd_launch<96>(a, stream) : fa64_bwd_launch<64>(a, stream);
+    if (rc || !dbias_q) return rc;
+    if (pb_finalize_rows(a.cs_kv, B * nkb * 4, d_model, dbias_k, stream, 2, dbias_v)) return -1;
+    return pb_finalize_rows(a.cs_q, B * nqb * 4, d_model, dbias_q, stream);
+}
+
+// floats of workspace for the fused bias gradients of pb_flash_bwd (head_dim 64 / 96 / 128)
+extern "C" int64_t pb_flash_bias_ws_floats(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd) {
+    const int kt_ = hd == 64 ? 2 : 1, nkb = (Sk + 64 * kt_ - 1) / (64 * kt_), nqb = (Sq + 127) / 128;
+    return (int64_t)B * 4 * H * hd * (2 * nkb + nqb);
 }

@@ -361,8 +361,8 @@ static int launch_finalize(const float* partials, int nblk, int nacc, int d, flo
     return 0;
 }
 
-int pb_finalize_rows(const float* partials, int nblk, int d, float* out, void* stream) {
-    return launch_finalize(partials, nblk, 1, d, out, nullptr, nullptr, nullptr, (hipStream_t)stream);
+int pb_finalize_rows(const float* partials, int nblk, int d, float* out, void* stream, int nacc, float* out1) {
+    return launch_finalize(partials, nblk, nacc, d, out, out1, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int pb_add_ln_bwd(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,

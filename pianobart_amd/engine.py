@@ -249,15 +249,24 @@ class Engine:
         ops.gemm(P, vt, ot, M=Sq, N=hd, K=Sk, dtype=self.code, b_kc=False, lda=Sk, ldb=vl, ldc=ol, nb1=B, nb2=H,
                  sA=(H * Sq * Sk, Sq * Sk), sB=(Sk * vl, hd), sC=(Sq * ol, hd), b_off=vo, c_off=oo)
 
-    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save, out=None, key_mask=None, causal=False):
+    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save, out=None, key_mask=None, causal=False, dbias=None):
+        """dbias = (gq, gk, gv) bias-gradient vectors: filled here when the attention kernels can do it (returns True), else left to the caller."""
         H, hd = self.H, self.hd
         ws = self._cur_ws
         if self.use_flash:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
             assert dout[1] == 0 and dout[2] == out[2]
+            fuse = dbias is not None and hd in (64, 96, 128)
+            wsb = None
+            if fuse:
+                need = int(LIB.query('pb_flash_bias_ws_floats', B, H, Sq, Sk, hd))
+                if getattr(self, '_fbws', None) is None or self._fbws.numel() < need:
+                    self._fbws = torch.empty(need, dtype=torch.float32, device=self.device)
+                wsb = self._fbws
             ops.flash_bwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
-                          ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal, kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None)
-            return
+                          ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal, kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None,
+                          dbias=dbias if fuse else None, dbias_ws=wsb)
+            return fuse
         dP, dS, P = ws['scores'], ws['dS'], save['P']
         (qt, qo, ql), (kt, ko, kl), (vt, vo, vl) = q, k, v
         (dot, doo, dol) = dout
@@ -272,6 +281,7 @@ class Engine:
                  sA=bs, sB=(Sq * ql, hd), sC=(Sk * dkl, hd), b_off=qo, c_off=dko)
         ops.gemm(P, dot, dvt, M=Sk, N=hd, K=Sq, dtype=self.code, a_kc=False, b_kc=False, lda=Sk, ldb=dol, ldc=dvl, nb1=B, nb2=H,
                  sA=bs, sB=(Sq * dol, hd), sC=(Sk * dvl, hd), b_off=doo, c_off=dvo)
+        return False
 
     def _site(self, kind, layer=0, sub=0):
         return {'enc_emb': 0, 'dec_emb': 1}.get(kind, 2 + (layer * 8 + sub) * 2 + (0 if kind == 'enc' else 1))
@@ -413,7 +423,7 @@ class Engine:
             a, b = self.slots[first], self.slots[last or first]
             self.grad_hook(a.off, b.off + b.numel)
 
-    def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk, key_mask, causal):
+    def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk, key_mask, causal, dbias=None):
         """Backward of y = LN(x_in + drop(out_proj(attn(q,k,v)))) up to dq/dk/dv. gy: grad wrt y; gout receives grad wrt x_in
         (residual path only; the projection paths are added by the caller)."""
         ws, g, d, T = self._cur_ws, self.g, self.d, self._cur_ws['T']
@@ -424,7 +434,7 @@ class Engine:
         gb = gB if p > 0 else gout
         self._wgrad(gb, ctx, wo, d, d, T)
         self._dgrad(gb, wo, gC, T, d, d, False)
-        self._attn_bwd((gC, 0, d), q, k, v, dq, dk, dv, B, Sq, Sk, attn_save, out=(ctx, 0, d), key_mask=key_mask, causal=causal)
+        return self._attn_bwd((gC, 0, d), q, k, v, dq, dk, dv, B, Sq, Sk, attn_save, out=(ctx, 0, d), key_mask=key_mask, causal=causal, dbias=dbias)
 
     def backward(self, gy_dec, gy_enc_extra=None):
         """gy_dec: grad wrt decoder output (T,d) storage dtype (None for encoder-only). Writes all parameter gradients
@@ -447,21 +457,26 @@ class Engine:
                 gA = self._ffn_ln_bwd(L, pf, self.fd, cur, L['yc'], seed, self._site('dec', l, 2), p)
                 # cross-attention block: y_c = LN(y1 + drop(out_c(attn(q_c(y1), kv_c(enc)))))
                 g1 = gy if cur is not gy else galt
-                self._attn_block_bwd(L, pf, (pf + 'wo_c', pf + 'bo_c'), gA, L['y1'], (L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d),
-                                     (ws['dq'], 0, d), (ws['dkv'], 0, 2 * d), (ws['dkv'], d, 2 * d), L['ctxc'], L['ac'], L['attnc'],
-                                     L['mc'], L['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1, seed, self._site('dec', l, 1), p, B, S, S, emask, False)
-                ops.colsum(ws['dq'], g[pf + 'bq_c'], self.partials, T, d)
+                fused = self._attn_block_bwd(L, pf, (pf + 'wo_c', pf + 'bo_c'), gA, L['y1'], (L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d),
+                                             (ws['dq'], 0, d), (ws['dkv'], 0, 2 * d), (ws['dkv'], d, 2 * d), L['ctxc'], L['ac'], L['attnc'],
+                                             L['mc'], L['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1, seed, self._site('dec', l, 1), p, B, S, S, emask, False,
+                                             dbias=(g[pf + 'bq_c'], g[pf + 'bkv_c'][:d], g[pf + 'bkv_c'][d:]))
+                if not fused:
+                    ops.colsum(ws['dq'], g[pf + 'bq_c'], self.partials, T, d)
+                    ops.colsum(ws['dkv'], g[pf + 'bkv_c'], self.partials, T, 2 * d)
                 self._wgrad(ws['dq'], L['y1'], pf + 'wq_c', d, d, T)
                 self._dgrad(ws['dq'], pf + 'wq_c', g1, T, d, d, True)
-                ops.colsum(ws['dkv'], g[pf + 'bkv_c'], self.partials, T, 2 * d)
                 self._wgrad(ws['dkv'], sv['enc_out'], pf + 'wkv_c', 2 * d, d, T)
                 self._dgrad(ws['dkv'], pf + 'wkv_c', genc, T, d, 2 * d, l != self.ND - 1)
                 # self-attention block
                 g2 = gy if g1 is not gy else galt
-                self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), g1, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
-                                     (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
-                                     L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('dec', l, 0), p, B, S, S, dmask, True)
-                ops.colsum(ws['dqkv'], g[pf + 'bqkv'], self.partials, T, 3 * d)
+                bq = g[pf + 'bqkv']
+                fused = self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), g1, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
+                                             (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
+                                             L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('dec', l, 0), p, B, S, S, dmask, True,
+                                             dbias=(bq[:d], bq[d:2 * d], bq[2 * d:]))
+                if not fused:
+                    ops.colsum(ws['dqkv'], bq, self.partials, T, 3 * d)
                 self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
                 self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
                 cur = g2
@@ -493,10 +508,13 @@ class Engine:
             x_in = ws['enc'][l - 1]['y2'] if l > 0 else ws['x_enc']
             gA = self._ffn_ln_bwd(L, pf, self.fe, cur, L['y1'], seed, self._site('enc', l, 1), p)
             g2 = gy if cur is not gy else galt
-            self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), gA, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
-                                 (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
-                                 L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('enc', l, 0), p, B, S, S, emask, False)
-            ops.colsum(ws['dqkv'], g[pf + 'bqkv'], self.partials, T, 3 * d)
+            bq = g[pf + 'bqkv']
+            fused = self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), gA, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
+                                         (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
+                                         L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('enc', l, 0), p, B, S, S, emask, False,
+                                         dbias=(bq[:d], bq[d:2 * d], bq[2 * d:]))
+            if not fused:
+                ops.colsum(ws['dqkv'], bq, self.partials, T, 3 * d)
             self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
             self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
             cur = g2

@@ -196,13 +196,15 @@ def flash_fwd(q, k, v, o, lse, key_mask, B, H, Sq, Sk, hd, scale, causal, force_
              qb, qs, kb, ks, vb, vs, ob, os_, scale, int(causal) | (2 if force_generic else 0), _stream())
 
 
-def flash_bwd(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal, force_generic=False, kmax=None):
+def flash_bwd(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal, force_generic=False, kmax=None, dbias=None, dbias_ws=None):
+    """dbias = (gq, gk, gv): f32 vectors of H*hd that receive += the column sums of dq / dk / dv (bias gradients), with dbias_ws."""
     (qt, qo, qs, qb), (kt, ko, ks, kb), (vt, vo, vs, vb), (ot, oo, os_, ob) = q, k, v, o
     (dqt, dqo, dqs, dqb), (dkt, dko, dks, dkb), (dvt, dvo, dvs, dvb) = dq, dk, dv
     pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 2 * off)
     LIB.call('pb_flash_bwd', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), _p(key_mask), _p(kmax), pp(dqt, dqo),
              pp(dkt, dko), pp(dvt, dvo), _p(delta), B, H, Sq, Sk, hd, qb, qs, kb, ks, vb, vs, ob, os_, dqb, dqs, dkb, dks, dvb, dvs,
-             scale, int(causal) | (2 if force_generic else 0), _stream())
+             scale, int(causal) | (2 if force_generic else 0), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
+             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _stream())
 
 
 def corrupt(ids16, out16, loss_mask, choice, choice_out, mask_percent, seed, pad_row, mask_row, n_tokens):

@@ -304,10 +304,21 @@ def test_flash_attention_fwd_bwd(ops, hd, causal, S, generic):
     dqkv = torch.full((B, S, 3 * d), float('nan'), device='cuda', dtype=torch.bfloat16)
     delta = torch.empty(B, H, S, device='cuda')
     dsl = lambda off: (dqkv, off, 3 * d, S * 3 * d)
-    ops.flash_bwd(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), dout, lse, km, dsl(0), dsl(d), dsl(2 * d), delta, B, H, S, S, hd, scale, causal, force_generic=generic, kmax=kmax)
+    fused_bias = hd in (64, 96, 128) and not generic           # bias gradients of the q/k/v projections from the epilogue registers
+    db, dbws = None, None
+    if fused_bias:
+        from pianobart_amd._lib import LIB
+        db = [torch.full((d,), 0.25, device='cuda') for _ in range(3)]
+        dbws = torch.empty(int(LIB.query('pb_flash_bias_ws_floats', B, H, S, S, hd)), device='cuda')
+    ops.flash_bwd(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), dout, lse, km, dsl(0), dsl(d), dsl(2 * d), delta, B, H, S, S, hd, scale, causal, force_generic=generic, kmax=kmax,
+                  dbias=db, dbias_ws=dbws)
     gref = qd.grad
     err = float((dqkv.double() - gref).abs().max() / gref.abs().max())
     assert err < 3e-2, err
+    if fused_bias:
+        cs = gref.reshape(B * S, 3 * d).sum(0)
+        for i in range(3):
+            assert float((db[i].double() - 0.25 - cs[i * d:(i + 1) * d]).abs().max() / cs.abs().max()) < 2e-2, i
 
 
 @pytest.mark.parametrize('a_kc,b_kc', [(True, True), (True, False), (False, True), (False, False)])
