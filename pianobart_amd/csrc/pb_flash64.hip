@@ -534,13 +534,19 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
                 }
             }
         }
-    if (p.cs_kv) {      // bias gradients: column sums of this wave's dK / dV rows -> partial row (b, key block, wave), head h's columns
+    if (p.cs_kv) {      // bias gradients: column sums of the block's dK / dV rows -> partial row (b, key block), head h's columns
         const int nkb = (p.Sk + BK_ - 1) / BK_, d_model = p.H * HDT;
-        float* row = p.cs_kv + ((long)(b * nkb + rb) * 4 + wave) * 2 * d_model + h * HDT;
+        float* red = reinterpret_cast<float*>(smem);                      // [4 waves][2 HDT]: the tile ring is free after the last barrier
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const float sk = grp_sum(csk[dt]), sv_ = grp_sum(csv[dt]);
-            if (g == 0) { row[dt * 16 + lr] = sk; row[d_model + dt * 16 + lr] = sv_; }
+            if (g == 0) { red[wave * 2 * HDT + dt * 16 + lr] = sk; red[wave * 2 * HDT + HDT + dt * 16 + lr] = sv_; }
+        }
+        __syncthreads();
+        if (t < 2 * HDT) {
+            float* row = p.cs_kv + (long)(b * nkb + rb) * 2 * d_model + h * HDT;
+            const float v = red[t] + red[2 * HDT + t] + red[4 * HDT + t] + red[6 * HDT + t];
+            row[t < HDT ? t : d_model + t - HDT] = v;
         }
     }
 }
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         }
     if (p.cs_q) {       // bias gradient of the q projection: the 16 lanes of a DPP row hold 16 queries of the same 4 columns
         const int nqb = (p.Sq + 127) / 128, d_model = p.H * HDT;
-        float* row = p.cs_q + ((long)(b * nqb + rb) * 4 + wave) * d_model + h * HDT;
+        float* red = reinterpret_cast<float*>(smem);                      // [4 waves][HDT]
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -713,8 +719,10 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
                 v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
                 csq[dt][e] = v;
             }
-            if (lr == 0) *reinterpret_cast<f32x4*>(row + dt * 16 + g * 4) = csq[dt];
+            if (lr == 0) *reinterpret_cast<f32x4*>(red + wave * HDT + dt * 16 + g * 4) = csq[dt];
         }
+        __syncthreads();
+        if (t < HDT) p.cs_q[(long)(b * nqb + rb) * d_model + h * HDT + t] = red[t] + red[HDT + t] + red[2 * HDT + t] + red[3 * HDT + t];
     }
 }
 
@@ -787,16 +795,16 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout
     const int kt_ = hd == 64 ? 2 : 1, nkb = (Sk + 64 * kt_ - 1) / (64 * kt_), nqb = (Sq + 127) / 128, d_model = H * hd;
     if (dbias_q) {
         PB_REQUIRE(dbias_k && dbias_v && dbias_ws, "pb_flash_bwd: dbias_q/k/v and dbias_ws go together");
-        a.cs_kv = dbias_ws; a.cs_q = dbias_ws + (size_t)B * nkb * 4 * 2 * d_model;
+        a.cs_kv = dbias_ws; a.cs_q = dbias_ws + (size_t)B * nkb * 2 * d_model;
     }
     const int rc = hd == 128 ? fa64_bwd_launch<128>(a, stream) : hd == 96 ? fa64_bwd_launch<96>(a, stream) : fa64_bwd_launch<64>(a, stream);
     if (rc || !dbias_q) return rc;
-    if (pb_finalize_rows(a.cs_kv, B * nkb * 4, d_model, dbias_k, stream, 2, dbias_v)) return -1;
-    return pb_finalize_rows(a.cs_q, B * nqb * 4, d_model, dbias_q, stream);
+    if (pb_finalize_rows(a.cs_kv, B * nkb, d_model, dbias_k, stream, 2, dbias_v)) return -1;
+    return pb_finalize_rows(a.cs_q, B * nqb, d_model, dbias_q, stream);
 }
 
 // floats of workspace for the fused bias gradients of pb_flash_bwd (head_dim 64 / 96 / 128)
 extern "C" int64_t pb_flash_bias_ws_floats(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd) {
     const int kt_ = hd == 64 ? 2 : 1, nkb = (Sk + 64 * kt_ - 1) / (64 * kt_), nqb = (Sq + 127) / 128;
-    return (int64_t)B * 4 * H * hd * (2 * nkb + nqb);
+    return (int64_t)B * H * hd * (2 * nkb + nqb);
 }
