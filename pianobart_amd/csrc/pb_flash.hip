@@ -406,7 +406,7 @@ int check_common(const char* who, int hd, long a, long b2, long c2, long d2) {
 
 int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int* kmax, int B, int H, int Sq, int Sk, int hd,
                    long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream);
-int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, const float* key_mask,
+int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, const float* key_mask,
                    const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, int hd, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
                    int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream);
@@ -475,12 +475,11 @@ extern "C" int pb_flash_bwd(const void* q, const void* k, const void* v, const v
     a.scale = scale; a.causal = causal & 1;
     const long nrow = (long)B * H * Sq;
     PB_REQUIRE(hd != 96 || !(causal & 2), "pb_flash_bwd: head_dim 96 exists in the pipelined kernel family only");
-    if (hd == 96) hipLaunchKernelGGL((fa_delta_kernel<96>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, a.o, a.dout, delta, B, H, Sq, o_sb, o_ss);
-    else FA_DISPATCH(hd, hipLaunchKernelGGL((fa_delta_kernel<HD>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, a.o, a.dout, delta, B, H, Sq, o_sb, o_ss));
-    PB_LAUNCH_CHECK();
-    if ((hd == 64 || hd == 96 || hd == 128) && !(causal & 2))
-        return pb_flash64_bwd(q, k, v, dout, lse, delta, key_mask, kmax, dq, dk, dv, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss,
+    if ((hd == 64 || hd == 96 || hd == 128) && !(causal & 2))          // the pipelined family computes delta inside its dQ kernel
+        return pb_flash64_bwd(q, k, v, o, dout, lse, delta, key_mask, kmax, dq, dk, dv, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss,
                               dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, scale, causal & 1, dbias_q, dbias_k, dbias_v, dbias_ws, stream);
+    FA_DISPATCH(hd, hipLaunchKernelGGL((fa_delta_kernel<HD>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, a.o, a.dout, delta, B, H, Sq, o_sb, o_ss));
+    PB_LAUNCH_CHECK();
     PB_REQUIRE(!dbias_q, "pb_flash_bwd: fused bias gradients exist in the pipelined kernels (head_dim 64 / 96 / 128) only");
     dim3 gk((Sk + TK - 1) / TK, H, B), gq((Sq + TQ - 1) / TQ, H, B);
     if (hd == 128) {   // 4 x 16 KiB tiles exceed the default 64 KiB dynamic-LDS limit

@@ -591,12 +591,20 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
         const long li = ((long)b * p.H + h) * p.Sq + myq[qt];
         const float ls = myq[qt] < p.Sq ? p.lse[li] : INFINITY;
         nl[qt] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
-        nd[qt] = myq[qt] < p.Sq ? -p.delta[li] : 0.f;
+        // delta = rowsum(dO . O) of this lane's query, computed here (this kernel owns whole query rows and already holds dO) and
+        // published for the dK/dV kernel, which is launched after this one
+        float dl = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[qt][ks] = scale_frag(frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8), c);
             of[qt][ks] = frag_global(DO, p.o_ss, myq[qt], p.Sq, ks * 32 + g * 8);
+            const bf16x8 ov = frag_global(p.o + b * p.o_sb + h * HDT, p.o_ss, myq[qt], p.Sq, ks * 32 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf((float)of[qt][ks][e], (float)ov[e], dl);
         }
+        dl = grp_sum(dl);
+        nd[qt] = -dl;
+        if (g == 0 && myq[qt] < p.Sq) const_cast<float*>(p.delta)[li] = dl;
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -773,19 +781,19 @@ static int fa64_bwd_launch(const Fa64Args& a, hipStream_t stream) {
     if (lds_dkv > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dkv_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
     if (lds_dq > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_bwd_dq_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
     constexpr int BK_ = 64 * C::KT;
-    hipLaunchKernelGGL(fa64_bwd_dkv_kernel<HD>, dim3(((a.Sk + BK_ - 1) / BK_) * a.H * a.B), dim3(FT), lds_dkv, stream, a);
+    hipLaunchKernelGGL(fa64_bwd_dq_kernel<HD>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds_dq, stream, a);      // also writes delta
     PB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fa64_bwd_dq_kernel<HD>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds_dq, stream, a);
+    hipLaunchKernelGGL(fa64_bwd_dkv_kernel<HD>, dim3(((a.Sk + BK_ - 1) / BK_) * a.H * a.B), dim3(FT), lds_dkv, stream, a);
     PB_LAUNCH_CHECK();
     return 0;
 }
 
-int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, const float* key_mask,
+int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, const float* key_mask,
                    const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, int hd, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
                    int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream) {
     Fa64Args a = {};
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dout = (const bf16_t*)dout;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
