@@ -40,6 +40,8 @@ const char* pb_last_error(void);
 #define PB_GEMM_ONE_BARRIER 2048 /* A/B runs: 256x256 tile with the one-barrier kernel instead of the ping-pong one   */
 #define PB_GEMM_PLAIN_GRID 4096  /* 256x256 ping-pong kernel as an ordinary grid (one workgroup per work item) instead of the
                                     persistent one-per-CU grid: what to ask for when other kernels (RCCL) hold CUs        */
+#define PB_GEMM_NO_192 8192      /* A/B runs: never pick the 256x192 tile                                                */
+#define PB_GEMM_FORCE_192 16384  /* A/B runs: always pick the 256x192 tile when the 256-row kernel is used               */
 typedef struct pb_gemm_desc {
     const void* A; const void* B; void* C;
     const float* bias;            /* per-n, may be NULL */

@@ -145,8 +145,8 @@ __device__ __forceinline__ void block_tile(const Gemm2Args& p, int L, int& m0, i
 // columns of one output row, i.e. one 16-byte bf16 store (two for f32), 64 (128) contiguous bytes per row and
 // instruction, with bias / GELU / GELU-grad / accumulate applied in f32 in between. No LDS and no barrier: the f32 LDS
 // panel this replaces cost about a third of the store tail of a 256 x 256 tile, and its 8-byte stores another 6 %.
-template <int TM>
-__device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[TM][4], int mw /*wave's first row*/, int nw /*first column*/, long coff, int lane,
+template <int TM, int TNW = 4>
+__device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[TM][TNW], int mw /*wave's first row*/, int nw /*first column*/, long coff, int lane,
                                               const float* lds_bias = nullptr /*bias[nw ..] staged in LDS by the caller*/,
                                               float* cs_row = nullptr /*this wave row's column-sum partials: N floats*/) {
     const int lr = lane & 15, lg = lane >> 4;
@@ -178,13 +178,15 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
             f32x4 v0, v1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float xa = acc[i][2 * jp][r], xb = acc[i][2 * jp + 1][r];     // (a bit_cast applied directly to a vector element reads element 0)
+                // TNW = 3: the last column tile has no partner; its even 16-lane rows still end up with columns lg*4 .. +7
+                const float xa = acc[i][2 * jp][r], xb = (2 * jp + 1 < TNW) ? acc[i][(2 * jp + 1 < TNW) ? 2 * jp + 1 : 0][r] : 0.f;     // (a bit_cast applied directly to a vector element reads element 0)
                 auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
                 v0[r] = __uint_as_float(sw[0]);
                 v1[r] = __uint_as_float(sw[1]);
             }
             const int col = nw + jp * 32 + cb;
-            if (row < p.M && col < p.N) {
+            const bool lane_has = (2 * jp + 1 < TNW) || !(lg & 1);              // odd rows of an unpaired tile hold nothing
+            if (lane_has && row < p.M && col < p.N) {
                 v0 = v0 * p.alpha + bv[jp][0];
                 v1 = v1 * p.alpha + bv[jp][1];
                 if (do_gelu) {                                           // C = gelu(v), aux_out = gelu'(v): both from one exp + one rcp
@@ -235,7 +237,7 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 const int col = nw + jp * 32 + cb;
-                if (col < p.N) {
+                if (col < p.N && ((2 * jp + 1 < TNW) || !(lg & 1))) {
                     *reinterpret_cast<f32x4*>(cs_row + col) = cs[jp][0];
                     *reinterpret_cast<f32x4*>(cs_row + col + 4) = cs[jp][1];
                 }
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
 // MFMAs the other one issues its LDS reads and DMA. Barriers are raw s_barrier (a __syncthreads() would drain vmcnt).
 // RAW: DMA data is read one phase after the counted wait (wait -> barrier -> barrier of the staggered group -> read);
 // WAR: a half-tile is re-staged two phases after its last read, whose lgkmcnt(0) sits one interval before.
-template <bool KC, int GS>
+template <bool KC, int GS, int GSTRIDE = 2 * GS>
 __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ base, long ld, int r0, int k0, int R, char* lds, int h, int wave, int lane) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -325,13 +327,13 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ base, long
         if constexpr (KC) {
             const int hr = inst * 8 + (lane >> 3);                                  // row of the half-tile image [128][128 B]
             const int chunk = (lane & 7) ^ kswz(hr);
-            const int gr = min(r0 + (hr / GS) * (2 * GS) + h * GS + (hr % GS), R - 1);
+            const int gr = min(r0 + (hr / GS) * GSTRIDE + h * GS + (hr % GS), R - 1);
             glds16(base + (long)gr * ld + k0 + chunk * 8, lds + inst * 1024);
         } else {
             const int krow = inst * 4 + (lane >> 4);                                // image [64 k][128 columns = 256 B]
             const int chunk = (lane & 15) ^ rswz(krow);
             const int hc = chunk * 8;
-            const int gc = min(r0 + (hc / GS) * (2 * GS) + h * GS + (hc % GS), R - 8);
+            const int gc = min(r0 + (hc / GS) * GSTRIDE + h * GS + (hc % GS), R - 8);
             glds16(base + (long)(k0 + krow) * ld + gc, lds + inst * 1024);
         }
     }
@@ -371,8 +373,12 @@ __device__ __forceinline__ void tr_wait_ab(s16x4 (&ta)[4][2][2], s16x4 (&tb)[2][
 }
 #undef TRW4
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int TNW>
 __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
+    // TNW = column tiles (16 wide) per wave: 4 -> 256 x 256 block tile; 3 -> 256 x 192 (N = 768: 512 tiles = 2 full rounds of 256 CUs
+    // where 256 x 256 gives 384 = 1.5). With TNW = 3 the second B half still stages 32 columns per wave column (16 of them belong
+    // to the neighbour), so the DMA piece counts and with them every vmcnt stay as they are; its phases run 8 MFMAs instead of 16.
+    constexpr int BNT = 64 * TNW, GSB = 16 * TNW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALF = 16384, SLOT = 4 * HALF;
     const int t = threadIdx.x, lane = t & 63;
@@ -384,18 +390,18 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     const int total = p.tiles_m * p.tiles_n * p.nsplit;
     int L = blockIdx.x;
     int m0, n0, zs;
-    block_tile<256, 256>(p, L, m0, n0, zs);
+    block_tile<256, BNT>(p, L, m0, n0, zs);
     const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
     int kbeg = zs * p.Kc;
     int nk = max(0, min(p.K, kbeg + p.Kc) - kbeg) / BK;
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][TNW];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 a[4][2], b[2][2];
     s16x4 ta[4][2][2], tb[2][2][2];                                   // asm destinations of the transposed reads
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     for (int j = 0; j < 2; ++j) boff[j] = lds0 + tr_lane_off(wc * 32 + j * 16, lane);
 
 #define G3_ISSUE_A(T, H) stage_half<A_KC, 64>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
-#define G3_ISSUE_B(T, H) stage_half<B_KC, 32>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
+#define G3_ISSUE_B(T, H) stage_half<B_KC, 32, GSB>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
 #define G3_READ_A(SL, H)                                                                                          \
     do {                                                                                                          \
         if constexpr (A_KC) {                                                                                     \
@@ -444,7 +450,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)             \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-                acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+                if ((NH) * 2 + j < TNW)                                                                               \
+                    acc[(MH) * 4 + i][((NH) * 2 + j < TNW) ? (NH) * 2 + j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[(MH) * 4 + i][((NH) * 2 + j < TNW) ? (NH) * 2 + j : 0], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_barrier();                                                                             \
@@ -509,21 +516,21 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         if (wr == 0) __builtin_amdgcn_s_barrier();
         // all LDS reads of this item are complete: both slots are free for the next item's first pieces
         const int em0 = m0, en0 = n0;
-        const float* ebias = reinterpret_cast<const float*>(smem + 2 * SLOT + bslot * 1024) + wc * 64;
+        const float* ebias = reinterpret_cast<const float*>(smem + 2 * SLOT + bslot * 1024) + wc * GSB;
         const long ecoff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
         L += gridDim.x;
         const bool more = L < total;
         if (more) {
-            block_tile<256, 256>(p, L, m0, n0, zs);
+            block_tile<256, BNT>(p, L, m0, n0, zs);
             kbeg = zs * p.Kc;
             nk = max(0, min(p.K, kbeg + p.Kc) - kbeg) / BK;
             G3_PROLOGUE();
         }
-        if (!(p.flags & 128)) epilogue_regs<8>(p, acc, em0 + wr * 128, en0 + wc * 64, ecoff, lane, ebias,
+        if (!(p.flags & 128)) epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias,
                                                    p.cs_ws ? p.cs_ws + (long)((em0 >> 8) * 2 + wr) * p.N : nullptr);   // bit 7: profiling build without the epilogue
         if (!more) break;
         {   // an interior tile without read-modify-write issues exactly 8 x 2 (x 2 for f32 C or the GELU pair) stores per wave
-            const bool interior = em0 + 256 <= p.M && en0 + 256 <= p.N;
+            const bool interior = em0 + 256 <= p.M && en0 + BNT <= p.N;
             const bool plain = !(p.flags & (PB_GEMM_ACCUM | PB_GEMM_MUL_GELU_GRAD | 128));
             pend = (interior && plain) ? (((p.flags & PB_GEMM_C_F32) || (p.flags & PB_GEMM_GELU)) ? 32 : 16) : 0;
             if (((p.flags & PB_GEMM_C_F32) && (p.flags & PB_GEMM_GELU)) || p.cs_ws) pend = 0;
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #undef G3_PROLOGUE
 #undef G3_ISSUE_A
@@ -582,7 +589,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096 | 8192 | 16384)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue");
         return -2;
     }
@@ -604,7 +611,18 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // the small split-K wgrads (768 x 768: 692 vs 620 TF). TN callers pass PB_GEMM_TILE256 together with their split-K factor.
     const bool big = !(d->flags & PB_GEMM_TILE128) && d->M >= 256 && d->N >= 256 &&
                      ((d->flags & PB_GEMM_TILE256) || (nsplit == 1 && d->M >= 2048 && d->N >= 512));
-    const int BMs = big ? 256 : 128, BNs = big ? 256 : 128;
+    // 256 x 192 instead of 256 x 256 when it fills the persistent grid's rounds better. A 192-wide tile costs ~0.95 of a 256-wide one,
+    // not 0.75: the ping-pong interval is set by the load half (8 DMA pieces + fragment reads per K-tile and wave, unchanged), not by
+    // the MFMAs -- so it only pays where it repairs the round count: N = 768 at T = 32768 -> 512 tiles = 2 full rounds instead of
+    // 384 = 1.5 (fc2 1136 -> 1190 TF, out-proj 846 -> 914, dfc1 1014 -> 1070); N = 2304 (5 rounds vs 6) stays 256 wide.
+    bool wide192 = false;
+    if (big && !(d->flags & (2048 | 8192)) && nb1 * a.nb2 == 1) {
+        const int cus = pb_num_cus();
+        const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * nsplit, t192 = (long)((d->M + 255) / 256) * ((d->N + 191) / 192) * nsplit;
+        const double c256 = (double)((t256 + cus - 1) / cus), c192 = 0.95 * (double)((t192 + cus - 1) / cus);
+        wide192 = (d->flags & 16384) || c192 < 0.97 * c256;
+    }
+    const int BMs = big ? 256 : 128, BNs = big ? (wide192 ? 192 : 256) : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
     a.nsplit = nsplit;
     dim3 grid(a.tiles_m * a.tiles_n * nsplit, nb1 * a.nb2, 1);
@@ -620,10 +638,10 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         if (d->colsum_out && nsplit == 1 && nb1 * a.nb2 == 1) { a.cs_ws = d->colsum_ws; cs_fused = true; }                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
-        auto kfn = gemm3_kernel<AK, BK_>;                                                                                  \
+        auto kfn = wide192 ? gemm3_kernel<AK, BK_, 3> : gemm3_kernel<AK, BK_, 4>;                                          \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
         dim3 pgrid(std::min<unsigned>(grid.x, (d->flags & 4096) ? grid.x : (unsigned)pb_num_cus()), grid.y, 1);            \
-        hipLaunchKernelGGL(kfn, pgrid, dim3(512), 131072 + 2048, stream, a);                                                     \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(512), 131072 + 2048, stream, a);                                              \
     } while (0)
         if (a_kc && b_kc) PB_G3_LAUNCH(true, true);
         else if (a_kc && !b_kc) PB_G3_LAUNCH(true, false);

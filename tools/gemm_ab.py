@@ -1,4 +1,5 @@
-"""Same-process A/B of the two 256x256 GEMM kernels (bit 11 of the flags = the older one-barrier kernel) on the cfg-2 shapes."""
+"""Same-process A/B of the 256-row ping-pong GEMM kernel with 256- and 192-wide tiles (flag bits 13 / 14), the dispatcher's own
+choice and the 128x128 kernel, on the cfg-2 shapes."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,8 +23,8 @@ for name, M, N, K, a_kc, b_kc, sk in shapes:
     sk2 = sk if sk == 1 else max(1, 256 // (((M + 255) // 256) * ((N + 127) // 128)))
     sk3 = sk if sk == 1 else max(1, round(512 / (((M + 127) // 128) * ((N + 127) // 128))))
     slabs = torch.empty(max(sk, sk2, sk3) * M * N, device=dev) if sk > 1 else None
-    fs = [lambda C=Cs[0]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=True, dbg=2048),
-          lambda C=Cs[1]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=True, dbg=4096),
+    fs = [lambda C=Cs[0]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=True, dbg=8192),
+          lambda C=Cs[1]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=True, dbg=16384),
           lambda C=Cs[2]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=sk > 1 and M * N > 768 * 768),
           lambda C=Cs[3]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk3, slabs=slabs, tile128=True)]
     for f in fs:
@@ -41,5 +42,5 @@ for name, M, N, K, a_kc, b_kc, sk in shapes:
             e1.record(); torch.cuda.synchronize()
             ms[i] += e0.elapsed_time(e1) / 25
     tf = [2.0 * M * N * K / m / 1e9 for m in ms]
-    print('%-8s M=%6d N=%5d K=%6d sk=%2d/%2d/%2d  256-1bar %6.3f ms %5.0f TF | 256-pp-np %6.3f ms %5.0f TF | default %6.3f ms %5.0f TF | 128-1bar %6.3f ms %5.0f TF  same=%s maxdiff=%.3g'
+    print('%-8s M=%6d N=%5d K=%6d sk=%2d/%2d/%2d  256x256 %6.3f ms %5.0f TF | 256x192 %6.3f ms %5.0f TF | default %6.3f ms %5.0f TF | 128-1bar %6.3f ms %5.0f TF  same=%s maxdiff=%.3g'
           % (name, M, N, K, sk, sk2, sk3, ms[0], tf[0], ms[1], tf[1], ms[2], tf[2], ms[3], tf[3], same, err), flush=True)
