@@ -319,10 +319,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
 // MFMAs the other one issues its LDS reads and DMA. Barriers are raw s_barrier (a __syncthreads() would drain vmcnt).
 // RAW: DMA data is read one phase after the counted wait (wait -> barrier -> barrier of the staggered group -> read);
 // WAR: a half-tile is re-staged two phases after its last read, whose lgkmcnt(0) sits one interval before.
-template <bool KC, int GS, int GSTRIDE = 2 * GS>
+template <bool KC, int GS, int GSTRIDE = 2 * GS, int N0 = 0, int N1 = 2>
 __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ base, long ld, int r0, int k0, int R, char* lds, int h, int wave, int lane) {
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = N0; n < N1; ++n) {
         const int inst = wave * 2 + n;
         if constexpr (KC) {
             const int hr = inst * 8 + (lane >> 3);                                  // row of the half-tile image [128][128 B]
@@ -413,6 +413,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 
 #define G3_ISSUE_A(T, H) stage_half<A_KC, 64>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
 #define G3_ISSUE_B(T, H) stage_half<B_KC, 32, GSB>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
+#define G3_ISSUE_A1(T, H, PC) stage_half<A_KC, 64, 128, PC, PC + 1>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
+#define G3_ISSUE_B1(T, H, PC) stage_half<B_KC, 32, GSB, PC, PC + 1>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
 #define G3_READ_A(SL, H)                                                                                          \
     do {                                                                                                          \
         if constexpr (A_KC) {                                                                                     \
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         }                                                                                                         \
     } while (0)
     // RA / RB: this phase read A / B fragments (the asm destinations among them are named in the wait)
-#define G3_MMA(MH, NH, RA, RB)                                                                                    \
+#define G3_MMA(MH, NH, RA, RB, MID)                                                                               \
     do {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_barrier();                                                                             \
@@ -448,10 +450,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)             \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-                if ((NH) * 2 + j < TNW)                                                                               \
-                    acc[(MH) * 4 + i][((NH) * 2 + j < TNW) ? (NH) * 2 + j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[(MH) * 4 + i][((NH) * 2 + j < TNW) ? (NH) * 2 + j : 0], 0, 0, 0); \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                    if ((NH) * 2 + j < TNW)                                                                           \
+                        acc[(MH) * 4 + i][((NH) * 2 + j < TNW) ? (NH) * 2 + j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[(MH) * 4 + i][((NH) * 2 + j < TNW) ? (NH) * 2 + j : 0], 0, 0, 0); \
+            if (ks == 0) { __builtin_amdgcn_sched_barrier(0); MID; __builtin_amdgcn_sched_barrier(0); }           \
+        }                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_barrier();                                                                             \
@@ -493,25 +498,35 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             G3_READ_B(sl, 0);
             __builtin_amdgcn_sched_barrier(0);
             G3_READ_A(sl, 0);
-            if (kt + 1 < nk) G3_ISSUE_A(kt + 1, 1);
-            G3_MMA(0, 0, true, true);
+            // Where an operand needs transposed fragments (NN, TN) each phase's two DMA pieces are SPLIT: one in the load half, one
+            // between the two k-steps of the MFMA half -- there the load half (24 reads + a DMA pair) sets the interval and a DMA
+            // piece is its most expensive instruction (TN w1 999 -> 1037 TF, NN dfc1 1052 -> 1115). With two K-contiguous
+            // operands the load half is short and the split only delays MFMAs (NT 8192^3 1431 -> 1298): both pieces stay there.
+            constexpr bool SPLIT = !(A_KC && B_KC);
+#define G3_ISSUE2(ISS, T, H) do { if constexpr (SPLIT) { ISS##1(T, H, 0); } else { ISS(T, H); } } while (0)
+#define G3_MID(ISS, COND, T, H) do { if constexpr (SPLIT) { if (COND) ISS##1(T, H, 1); } } while (0)
+            if (kt + 1 < nk) G3_ISSUE2(G3_ISSUE_A, kt + 1, 1);
+            G3_MMA(0, 0, true, true, G3_MID(G3_ISSUE_A, kt + 1 < nk, kt + 1, 1));
             // phase 1: quadrant (0,1)
             G3_READ_B(sl, 1);
-            if (kt + 1 < nk) G3_ISSUE_B(kt + 1, 0);
-            G3_MMA(0, 1, false, true);
+            if (kt + 1 < nk) G3_ISSUE2(G3_ISSUE_B, kt + 1, 0);
+            G3_MMA(0, 1, false, true, G3_MID(G3_ISSUE_B, kt + 1 < nk, kt + 1, 0));
             // phase 2: quadrant (1,1)
             G3_READ_A(sl, 1);
-            if (kt + 2 < nk) G3_ISSUE_A(kt + 2, 0);
-            G3_MMA(1, 1, true, false);
+            if (kt + 2 < nk) G3_ISSUE2(G3_ISSUE_A, kt + 2, 0);
+            G3_MMA(1, 1, true, false, G3_MID(G3_ISSUE_A, kt + 2 < nk, kt + 2, 0));
             // phase 3: quadrant (1,0)
             G3_READ_B(sl, 0);
             if (kt + 2 < nk) {
-                G3_ISSUE_B(kt + 2, 1);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                G3_ISSUE2(G3_ISSUE_B, kt + 2, 1);
+                // in flight behind the wait: A0(t+2) (2 pieces) + B1(t+2) (both pieces, or the first one when split)
+                if constexpr (SPLIT) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            G3_MMA(1, 0, false, true);
+            G3_MMA(1, 0, false, true, G3_MID(G3_ISSUE_B, kt + 2 < nk, kt + 2, 1));
+#undef G3_ISSUE2
+#undef G3_MID
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
         // all LDS reads of this item are complete: both slots are free for the next item's first pieces
@@ -543,6 +558,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #undef G3_PROLOGUE
 #undef G3_ISSUE_A
 #undef G3_ISSUE_B
+#undef G3_ISSUE_A1
+#undef G3_ISSUE_B1
 #undef G3_READ_A
 #undef G3_READ_B
 #undef G3_MMA
