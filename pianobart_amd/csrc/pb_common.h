@@ -57,15 +57,29 @@ __device__ __forceinline__ void store4_nt(bf16_t* p, f32x4 v) {
 }
 
 // ---- wave64 reductions ------------------------------------------------------------
+// All-lanes butterfly without LDS: quad permutes and row mirrors (DPP) inside each 16-lane row, v_permlane16/32_swap across the
+// rows (after swap(v, v) one result is the lane's own value and the other its partner's). __shfl_xor compiles to ds_bpermute,
+// six LDS round trips per reduction on the latency path of every row kernel.
+#define PB_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += PB_DPP_F(v, 0xb1);      // quad_perm [1,0,3,2]
+    v += PB_DPP_F(v, 0x4e);      // quad_perm [2,3,0,1]
+    v += PB_DPP_F(v, 0x141);     // row_half_mirror
+    v += PB_DPP_F(v, 0x140);     // row_mirror
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, PB_DPP_F(v, 0xb1));
+    v = fmaxf(v, PB_DPP_F(v, 0x4e));
+    v = fmaxf(v, PB_DPP_F(v, 0x141));
+    v = fmaxf(v, PB_DPP_F(v, 0x140));
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // ---- exact-erf GELU (activation_function="gelu") -----------------------------------
