@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int LN_THREADS = 256, LN_WAVES = 4, LN_MAX_BLOCKS = 512;
+constexpr int LN_THREADS = 512, LN_WAVES = 8, LN_MAX_BLOCKS = 512;
 
 __device__ __forceinline__ DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
     DropCfg d;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void write_partials(f32x4 (&acc)[NACC][NIT], float* _
 }
 
 template <typename T, typename TR, int NIT>
-__global__ __launch_bounds__(LN_THREADS) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ res,
+__global__ __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ res,
         const T* __restrict__ a, const float* __restrict__ w, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
         TR* __restrict__ dres, T* __restrict__ da, float* __restrict__ partials, int rows, int d, int accum_dres,
         uint64_t seed, uint32_t site, float p) {
