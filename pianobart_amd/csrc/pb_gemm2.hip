@@ -628,17 +628,12 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // the small split-K wgrads (768 x 768: 692 vs 620 TF). TN callers pass PB_GEMM_TILE256 together with their split-K factor.
     const bool big = !(d->flags & PB_GEMM_TILE128) && d->M >= 256 && d->N >= 256 &&
                      ((d->flags & PB_GEMM_TILE256) || (nsplit == 1 && d->M >= 2048 && d->N >= 512));
-    // 256 x 192 instead of 256 x 256 when it fills the persistent grid's rounds better. A 192-wide tile costs ~0.95 of a 256-wide one,
-    // not 0.75: the ping-pong interval is set by the load half (8 DMA pieces + fragment reads per K-tile and wave, unchanged), not by
-    // the MFMAs -- so it only pays where it repairs the round count: N = 768 at T = 32768 -> 512 tiles = 2 full rounds instead of
-    // 384 = 1.5 (fc2 1136 -> 1190 TF, out-proj 846 -> 914, dfc1 1014 -> 1070); N = 2304 (5 rounds vs 6) stays 256 wide.
-    bool wide192 = false;
-    if (big && !(d->flags & (2048 | 8192)) && nb1 * a.nb2 == 1) {
-        const int cus = pb_num_cus();
-        const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * nsplit, t192 = (long)((d->M + 255) / 256) * ((d->N + 191) / 192) * nsplit;
-        const double c256 = (double)((t256 + cus - 1) / cus), c192 = 0.95 * (double)((t192 + cus - 1) / cus);
-        wide192 = (d->flags & 16384) || c192 < 0.97 * c256;
-    }
+    // 256 x 192 tiles (512 tiles = 2 full rounds at N = 768, T = 32768, where 256 x 256 gives 384 = 1.5) exist behind
+    // PB_GEMM_FORCE_192 only. Back-to-back launches of one shape measured them +4-6 % (fc2 1136 -> 1190 TF), but the same-box A/B of
+    // the whole training step lost 1.5 ms (77.9 vs 76.4 ms) with them: every A row panel is then streamed by 4 column tiles instead
+    // of 3, which the warm Infinity Cache of a repeated-launch benchmark hides and a real step does not. (A 192-wide tile also costs
+    // ~0.95 of a 256-wide one, not 0.75: the ping-pong interval is set by the load half, unchanged, not by the MFMAs.)
+    const bool wide192 = big && (d->flags & 16384) && !(d->flags & 2048) && nb1 * a.nb2 == 1;
     const int BMs = big ? 256 : 128, BNs = big ? (wide192 ? 192 : 256) : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
     a.nsplit = nsplit;
