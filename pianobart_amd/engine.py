@@ -12,12 +12,15 @@ Reference semantics followed (file:line into /root/reference; tf: = transformers
   loss:    pretrain.py:112-118,163-189 ; step: pretrain.py:192-196 (clip 3.0, HF AdamW)
 """
 import math
+import os
 
 import numpy as np
 import torch
 
 from . import ops
 from ._lib import LIB, PB_BF16, PB_F32, PBError
+
+_NO_FUSED_BIAS = bool(int(os.environ.get('PB_NO_FUSED_BIAS', '0')))     # developer aid: A/B the bias gradients fused into the GEMM / attention epilogues
 
 LN_EPS = 1e-5
 
@@ -256,7 +259,7 @@ class Engine:
         if self.use_flash:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
             assert dout[1] == 0 and dout[2] == out[2]
-            fuse = dbias is not None and hd in (64, 96, 128)
+            fuse = dbias is not None and hd in (64, 96, 128) and not _NO_FUSED_BIAS
             wsb = None
             if fuse:
                 need = int(LIB.query('pb_flash_bias_ws_floats', B, H, Sq, Sk, hd))
@@ -413,7 +416,11 @@ class Engine:
         self._wgrad(gb, L['g'], pf + 'w2', d, ff, T)
         du = ws['du'][:, :ff] if ws['du'].shape[1] == ff else ws['du'].view(-1)[:T * ff].view(T, ff)
         # dU = (dG W2) * gelu'(U), and db1 = column sums of dU straight from the same epilogue registers
-        self._dgrad(gb, pf + 'w2', du, T, ff, d, False, gelu_grad_aux_in=L['u'], ldaux=ff, colsum_out=g[pf + 'b1'], colsum_ws=self._cs_ws(T, ff))
+        if _NO_FUSED_BIAS:
+            self._dgrad(gb, pf + 'w2', du, T, ff, d, False, gelu_grad_aux_in=L['u'], ldaux=ff)
+            ops.colsum(du, g[pf + 'b1'], self.partials, T, ff)
+        else:
+            self._dgrad(gb, pf + 'w2', du, T, ff, d, False, gelu_grad_aux_in=L['u'], ldaux=ff, colsum_out=g[pf + 'b1'], colsum_ws=self._cs_ws(T, ff))
         self._wgrad(du, y_in, pf + 'w1', ff, d, T)
         self._dgrad(du, pf + 'w1', gA, T, d, ff, True)
         return gA

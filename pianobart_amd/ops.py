@@ -2,6 +2,7 @@
 device memory and the HIP stream; every op below launches a hand-written gfx950 kernel from
 libpianobart_hip.so on torch's current stream. There is no fallback path."""
 import ctypes
+import os
 
 import torch
 
@@ -46,6 +47,10 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+# developer aid for same-box A/B runs (tools/ab_step.sh): extra flag bits for every GEMM, e.g. PB_GEMM_FLAGS=4096 = ordinary grids
+_ENV_GEMM_FLAGS = int(os.environ.get('PB_GEMM_FLAGS', '0'))
+
+
 def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=None, bias=None, alpha=1.0,
          accum=False, c_f32=False, gelu_aux_out=None, gelu_grad_aux_in=None, ldaux=0, nb1=1, nb2=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, splitk=1, slabs=None, force_v1=False, tile128=False, tile256=False, dbg=0,
@@ -62,7 +67,7 @@ def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, l
     d.dtype, d.a_kcontig, d.b_kcontig = dtype, int(a_kc), int(b_kc)
     d.flags = (GEMM_ACCUM if accum else 0) | (GEMM_C_F32 if c_f32 else 0) | \
               (GEMM_GELU if gelu_aux_out is not None else 0) | (GEMM_MUL_GELU_GRAD if gelu_grad_aux_in is not None else 0) | \
-              (16 if force_v1 else 0) | (32 if tile128 else 0) | (64 if tile256 else 0) | dbg
+              (16 if force_v1 else 0) | (32 if tile128 else 0) | (64 if tile256 else 0) | dbg | _ENV_GEMM_FLAGS
     d.splitk = splitk if (splitk > 1 and slabs is not None) else 1
     d.slabs = slabs.data_ptr() if (splitk > 1 and slabs is not None) else None
     d.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
