@@ -5,7 +5,8 @@
 // A lane owns columns {4*(lane + 64*it) .. +3}; NIT = ceil(d/256) is a template parameter so the
 // row lives in registers. Parameter-gradient reductions (dgamma, dbeta, dbias) are accumulated in
 // registers over a grid-stride loop of rows, reduced across the 4 waves through LDS, written as
-// per-block partials and summed by a second tiny kernel: deterministic, no atomics.
+// per-block partials and summed by a second tiny kernel in a fixed order: deterministic, no atomics (the one exception is the
+// exact-f32 embedding backward, which scatter-adds into the projected table with f32 atomics).
 #include "pb_common.h"
 #include "pb_api_internal.h"
 
@@ -147,21 +148,48 @@ __global__ __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 }
 
 // out_k[c] += sum_blk partials[blk][k][c]   for k < nacc (NULL outputs skipped).
-// block = 64 columns x 4 row groups; grid (ceil(d/64), nacc).
-__global__ __launch_bounds__(256) void finalize_partials_kernel(const float* __restrict__ partials, int nblk, int nacc, int d,
-                                                                float* o0, float* o1, float* o2, float* o3) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+// block = 8 column quads (32 columns) x 128 row groups, grid (ceil(d/32), nacc): with <= 512 partial rows a thread has at most four
+// 16-byte loads, all in flight at once (the kernel is pure latency), and every output element is summed by ONE workgroup in a fixed
+// order (strided chain, then a fixed LDS tree) -- no atomics, so parameter gradients are bit-reproducible run to run.
+constexpr int FIN_GROUPS = 128;
+template <int V> struct FinVec;
+template <> struct FinVec<4> { using T = f32x4; static __device__ T ld(const float* p) { return load4(p); } static __device__ void st(float* p, T v) { store4(p, v); } };
+template <> struct FinVec<1> { using T = float; static __device__ T ld(const float* p) { return *p; } static __device__ void st(float* p, T v) { *p = v; } };
+
+template <int V>   // V = 4: 16-byte accesses (d % 4 == 0, 16-byte aligned pointers); V = 1: any d / alignment
+__global__ __launch_bounds__(8 * FIN_GROUPS) void finalize_partials_kernel(const float* __restrict__ partials, int nblk, int nacc, int d,
+                                                                           float* o0, float* o1, float* o2, float* o3) {
+    using F = FinVec<V>;
+    using T = typename F::T;
+    __shared__ T red[FIN_GROUPS][8];
+    const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    const int c = V * (blockIdx.x * 8 + cq);
     const int k = blockIdx.y;
     float* o = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
     if (!o) return;
-    float s = 0.f;
-    if (c < d)
-        for (int b = blockIdx.z * 4 + ry; b < nblk; b += 4 * gridDim.z) s += partials[((size_t)b * nacc + k) * d + c];
-    red[ry][cx] = s;
+    const bool live = c < d;
+    T s = T(0.f);
+    if (live) {
+        const float* src = partials + (size_t)k * d + c;
+        const size_t st = (size_t)nacc * d;
+        int b = rg;
+        for (; b + 3 * FIN_GROUPS < nblk; b += 4 * FIN_GROUPS) {
+            const T v0 = F::ld(src + (size_t)b * st), v1 = F::ld(src + (size_t)(b + FIN_GROUPS) * st);
+            const T v2 = F::ld(src + (size_t)(b + 2 * FIN_GROUPS) * st), v3 = F::ld(src + (size_t)(b + 3 * FIN_GROUPS) * st);
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; b < nblk; b += FIN_GROUPS) s += F::ld(src + (size_t)b * st);
+    }
+    red[rg][cq] = s;
     __syncthreads();
-    if (ry == 0 && c < d) atomicAdd(o + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);   // <= 8 addends per element
+    if (rg < 32) red[rg][cq] = (red[rg][cq] + red[rg + 32][cq]) + (red[rg + 64][cq] + red[rg + 96][cq]);
+    __syncthreads();
+    if (rg < 8) red[rg][cq] = (red[rg][cq] + red[rg + 8][cq]) + (red[rg + 16][cq] + red[rg + 24][cq]);
+    __syncthreads();
+    if (rg == 0 && live) {
+        const T t = ((red[0][cq] + red[1][cq]) + (red[2][cq] + red[3][cq])) + ((red[4][cq] + red[5][cq]) + (red[6][cq] + red[7][cq]));
+        F::st(o + c, F::ld(o + c) + t);
+    }
 }
 
 // ------------------------------------------------------------------ Octuple embed + pos + LN
@@ -356,7 +384,11 @@ extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, 
 
 static int launch_finalize(const float* partials, int nblk, int nacc, int d, float* o0, float* o1, float* o2, float* o3,
                            hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_partials_kernel, dim3((d + 63) / 64, nacc, nblk >= 64 ? 8 : 1), dim3(256), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
+    const uintptr_t al = (uintptr_t)partials | (uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2 | (uintptr_t)o3;
+    if (d % 4 == 0 && al % 16 == 0)
+        hipLaunchKernelGGL(finalize_partials_kernel<4>, dim3((d + 31) / 32, nacc), dim3(8 * FIN_GROUPS), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
+    else
+        hipLaunchKernelGGL(finalize_partials_kernel<1>, dim3((d + 7) / 8, nacc), dim3(8 * FIN_GROUPS), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
     PB_LAUNCH_CHECK();
     return 0;
 }

@@ -20,6 +20,8 @@ import torch
 from . import ops
 from ._lib import LIB, PB_BF16, PB_F32, PBError
 
+_WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second HIP stream, bits: 1 = weight-gradient GEMMs, 2 = cross-attention K/V projections, 4 = backward GEMMs as ordinary grids (0: everything on one stream, for A/B)
+_WG_TARGET = int(os.environ.get('PB_WG_TARGET', '192' if _WGRAD_STREAM & 1 else '256'))            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
 _NO_FUSED_BIAS = bool(int(os.environ.get('PB_NO_FUSED_BIAS', '0')))     # developer aid: A/B the bias gradients fused into the GEMM / attention epilogues
 
 LN_EPS = 1e-5
@@ -65,6 +67,7 @@ class Engine:
         self._versions = None
         self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 96, 128))
         self._slabs = None
+        self._side, self._side_last, self._readers = None, None, {}
         self._kmax = {}
         self.grad_hook = None          # callable(lo, hi): flat gradient range is final (data-parallel bucketing)
 
@@ -347,6 +350,20 @@ class Engine:
             ops.add_ln_fwd(ws['alt_pos'], dec_embeds, wf['dec.lne.w'], wf['dec.lne.b'], pre, ws['md'], ws['rd'], LN_EPS, 0, 0, 0.0)
             if p > 0.0:
                 ops.dropout(pre, y, seed, self._site('dec_emb'), p)
+        kv_ready = None
+        if (_WGRAD_STREAM & 2) and self._side_stream() is not None:
+            # every decoder layer's cross-attention K/V projection depends on the encoder output only: issue them all on the second
+            # stream now, to fill the CUs the decoder's N = d GEMMs leave idle
+            ev = torch.cuda.Event()
+            ev.record()
+            self._side.wait_event(ev)
+            kv_ready = []
+            with torch.cuda.stream(self._side):
+                for l in range(self.ND):
+                    pf = 'dec.%d.' % l
+                    self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', ws['dec'][l]['kvc'], T, 2 * d, d)
+                    kv_ready.append(torch.cuda.Event())
+                    kv_ready[-1].record()
         for l in range(self.ND):
             L, pf = ws['dec'][l], 'dec.%d.' % l
             self._linear(y, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
@@ -354,7 +371,10 @@ class Engine:
             self._linear(L['ctx'], pf + 'wo', pf + 'bo', L['a1'], T, d, d)
             ops.add_ln_fwd(y, L['a1'], wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], L['y1'], L['m1'], L['r1'], LN_EPS, seed, self._site('dec', l, 0), p)
             self._linear(L['y1'], pf + 'wq_c', pf + 'bq_c', L['qc'], T, d, d)
-            self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', L['kvc'], T, 2 * d, d)
+            if kv_ready is None:
+                self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', L['kvc'], T, 2 * d, d)
+            else:
+                torch.cuda.current_stream().wait_event(kv_ready[l])
             self._attn_fwd((L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d), (L['ctxc'], 0, d), emask, False, B, S, S, L['attnc'])
             self._linear(L['ctxc'], pf + 'wo_c', pf + 'bo_c', L['ac'], T, d, d)
             ops.add_ln_fwd(L['y1'], L['ac'], wf[pf + 'lnc.w'], wf[pf + 'lnc.b'], L['yc'], L['mc'], L['rc'], LN_EPS, seed, self._site('dec', l, 1), p)
@@ -380,17 +400,79 @@ class Engine:
             big = M >= 256 and N >= 256 and M * N > 768 * 768     # 256x256 tiles, one block per CU (768x768: 128x128 tiles measured 712 vs 636 TF)
             tl = 256 if big else 128
             tiles = ((M + tl - 1) // tl) * ((N + tl - 1) // tl)
-            nsplit = max(1, min(32, T // 64, round((256 if big else 512) / tiles)))
+            nsplit = max(1, min(32, T // 64, round((_WG_TARGET if big else 512) / tiles)))
             if nsplit > 1:
                 need = nsplit * M * N
                 if self._slabs is None or self._slabs.numel() < need:
+                    self._join_side()
                     self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
                 slabs = self._slabs
-        ops.gemm(dy, x, self.g[gname], M=M, N=N, K=T, dtype=self.code, a_kc=False, b_kc=False, lda=ldy or M, ldb=ldx or N, ldc=N,
-                 c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off, splitk=nsplit, slabs=slabs, tile256=big, dbg=self._bwd_dbg())
+        launch = lambda dbg: ops.gemm(dy, x, self.g[gname], M=M, N=N, K=T, dtype=self.code, a_kc=False, b_kc=False, lda=ldy or M, ldb=ldx or N, ldc=N,
+                                      c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off, splitk=nsplit, slabs=slabs, tile256=big, dbg=dbg)
+        if not (_WGRAD_STREAM & 1) or self._side_stream() is None:
+            return launch(self._bwd_dbg())
+        # the weight gradient is off the critical path of backward: run it on a second stream, where its workgroups fill the CUs the
+        # main stream's kernels leave idle (the half-empty last round of the N = d GEMMs). Writers of `dy` wait in _before_write.
+        ev = torch.cuda.Event()
+        ev.record()
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            launch(self._bwd_dbg())
+            done = torch.cuda.Event()
+            done.record()
+        self._readers[dy.untyped_storage().data_ptr()] = done
+        self._side_last = done
+
+    def _side_stream(self):
+        """A second HIP stream that really runs beside the current one, or None. HIP multiplexes streams onto a few hardware queues
+        (4 by default) and two streams that share one execute strictly one after the other, so candidates are probed once: a short
+        kernel on the candidate must finish while a ~2 ms train of kernels on the current stream is still running."""
+        if self._side is None:
+            self._side = False
+            main = torch.cuda.current_stream(self.device)
+            buf = torch.empty(256 << 20, dtype=torch.float32, device=self.device)      # 1 GiB: each fill runs ~0.2 ms, far longer than it takes to enqueue
+            tiny = torch.empty(64, dtype=torch.float32, device=self.device)
+            self._side_pool = []
+            for _ in range(8):
+                cand = torch.cuda.Stream(device=self.device)
+                self._side_pool.append(cand)            # keep the rejected ones referenced so the pool hands out a different stream next
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                torch.cuda.synchronize(self.device)
+                e0.record(main)
+                for _ in range(8):
+                    ops.fill_f32(buf, 0.0)
+                e1.record(main)
+                cand.wait_event(e0)
+                with torch.cuda.stream(cand):
+                    ops.fill_f32(tiny, 0.0)
+                    e2.record(cand)
+                torch.cuda.synchronize(self.device)
+                self._side_probe = (len(self._side_pool), e0.elapsed_time(e2), e0.elapsed_time(e1))
+                if self._side_probe[1] < 0.5 * self._side_probe[2]:
+                    self._side = cand
+                    break
+            if os.environ.get('PB_DEBUG'):
+                print('side stream probe (candidates tried, ms to the candidate kernel, ms of the main train):', self._side_probe, flush=True)
+        return self._side or None
+
+    def _before_write(self, *tensors):
+        """The main stream is about to overwrite these buffers: wait for the side-stream weight-gradient GEMMs still reading them."""
+        if self._readers:
+            for t in tensors:
+                if t is not None:
+                    ev = self._readers.pop(t.untyped_storage().data_ptr(), None)
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+
+    def _join_side(self):
+        if self._side_last is not None:
+            torch.cuda.current_stream().wait_event(self._side_last)
+            self._side_last = None
+        self._readers.clear()
 
     def _dgrad(self, dy, wname, out, T, N, K, accum, ldy=None, **kw):
         """out(T,N) (+)= dy(T,K) @ W(K,N)   (NN GEMM, W stored [K][N])."""
+        self._before_write(out)
         ops.gemm(dy, self.w[wname], out, M=T, N=N, K=K, dtype=self.code, b_kc=False, lda=ldy or K, ldb=N, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
 
     def _cs_ws(self, M, N):
@@ -403,13 +485,14 @@ class Engine:
         """Backward GEMMs that can run beside in-flight gradient all-reduces (data parallel: grad_hook set) are launched as ordinary
         grids (bit 12): a persistent one-workgroup-per-CU grid whose CUs are partly held by RCCL's kernels would run its stragglers as
         a second full round, twice the time, where an ordinary grid merely loses those CUs' share."""
-        return 4096 if self.grad_hook is not None else 0
+        return 4096 if (self.grad_hook is not None or ((_WGRAD_STREAM & 4) and self._side)) else 0
 
     def _ffn_ln_bwd(self, L, pf, ff, gy, y_in, seed, site, p):
         """Backward of y2 = LN2(y_in + drop(fc2(gelu(fc1(y_in))))). gy: grad wrt y2. Returns grad wrt y_in in ws['gA']."""
         ws, g, d, T = self._cur_ws, self.g, self.d, self._cur_ws['T']
         gA, gB = ws['gA'], ws['gB']
         da = gB if p > 0 else None
+        self._before_write(gA, da)
         ops.add_ln_bwd(gy, y_in, L['a2'], self.wf[pf + 'ln2.w'], L['m2'], L['r2'], gA, da, g[pf + 'ln2.w'], g[pf + 'ln2.b'], g[pf + 'b2'],
                        self.partials, False, seed, site, p)
         gb = gB if p > 0 else gA
@@ -428,7 +511,15 @@ class Engine:
     def _ready(self, first, last=None):
         if self.grad_hook is not None and self.Gcur is self.G32:
             a, b = self.slots[first], self.slots[last or first]
-            self.grad_hook(a.off, b.off + b.numel)
+            if self._side_last is None:
+                return self.grad_hook(a.off, b.off + b.numel)
+            # the range was produced by both streams: let the second stream catch up with this one and issue the exchange from it
+            # (the collective's own stream orders itself after the stream that is current at the call), so this one never waits
+            ev = torch.cuda.Event()
+            ev.record()
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                self.grad_hook(a.off, b.off + b.numel)
 
     def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk, key_mask, causal, dbias=None):
         """Backward of y = LN(x_in + drop(out_proj(attn(q,k,v)))) up to dq/dk/dv. gy: grad wrt y; gout receives grad wrt x_in
@@ -437,6 +528,7 @@ class Engine:
         gB, gC = ws['gB'], ws['gC']
         wo, bo = names
         da = gB if p > 0 else None
+        self._before_write(gout, da, dq[0], dk[0], dv[0])
         ops.add_ln_bwd(gy, x_in, a, lnw, mean, rstd, gout, da, lnw_g, lnb_g, g[bo], self.partials, False, seed, site, p)
         gb = gB if p > 0 else gout
         self._wgrad(gb, ctx, wo, d, d, T)
@@ -538,6 +630,7 @@ class Engine:
             if dec_tab:
                 ops.onehot_build(sv['dec16'], ws['onehot'][T:], padded=True)
             need = 16 * ops.TAB_TOTAL * d
+            self._join_side()
             if self._slabs is None or self._slabs.numel() < need:
                 self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
             ops.gemm(ws['onehot'], ws['dz'], self.dptab, M=ops.TAB_TOTAL, N=d, K=K2, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.TAB_TOTAL, ldb=d, dbg=self._bwd_dbg(),
@@ -549,6 +642,7 @@ class Engine:
         ops.gemm(self.dptab, E, g['lin.w'], M=d, N=256, K=R, dtype=PB_F32, a_kc=False, b_kc=False, lda=d, ldb=256, ldc=2048, alpha=16.0,
                  c_f32=True, nb1=8, sA=(R * d, 0), sB=(R * 256, 0), sC=(256, 0))
         self._ready('emb', 'lin.w')
+        self._join_side()
         if self.grad_hook is not None and self.Gcur is self.G32:
             self.grad_hook(self.n_matrix, self.n_total)          # vectors / position tables (accumulated region)
 
