@@ -229,6 +229,18 @@ typedef struct pb_decode_plan {
 } pb_decode_plan;
 int pb_decode_step(const pb_decode_plan* plan, int32_t i, void* stream);
 
+/* ---- K15: deferred parameter-gradient reductions -----------------------------------------------------------------------
+ * The bias / LayerNorm-parameter gradients of one backward pass (the `db = grad.sum(0)` of every nn.Linear and nn.LayerNorm autograd
+ * node under BartModel, modeling_bart.py:280-390) leave their kernels as per-workgroup partial rows. Between pb_defer_begin and
+ * pb_defer_flush (same host thread) pb_add_ln_bwd, pb_gemm (colsum_out) and pb_flash_bwd (dbias_*) keep those rows in `arena`
+ * instead of reducing them one small launch at a time, and pb_defer_flush sums all of them in ONE launch, in a fixed order
+ * (bit-reproducible). arena: device floats, 16-byte aligned; table: device bytes, table_entries * pb_defer_desc_bytes(). When either
+ * is full the calls fall back to the immediate reduction. Outputs are accumulated (+=) exactly as without deferral, so they must
+ * not be read, nor written by anything else, before the flush. */
+int pb_defer_begin(float* arena, int64_t arena_floats, void* table, int32_t table_entries);
+int pb_defer_flush(void* stream);
+int32_t pb_defer_desc_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -803,7 +803,9 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* o, c
     const int kt_ = hd == 64 ? 2 : 1, nkb = (Sk + 64 * kt_ - 1) / (64 * kt_), nqb = (Sq + 127) / 128, d_model = H * hd;
     if (dbias_q) {
         PB_REQUIRE(dbias_k && dbias_v && dbias_ws, "pb_flash_bwd: dbias_q/k/v and dbias_ws go together");
-        a.cs_kv = dbias_ws; a.cs_q = dbias_ws + (size_t)B * nkb * 2 * d_model;
+        const size_t n_kv = (size_t)B * nkb * 2 * d_model;
+        if (float* slice = pb_defer_alloc(n_kv + (size_t)B * nqb * d_model)) dbias_ws = slice;     // deferred reduction: the partial rows must outlive this call
+        a.cs_kv = dbias_ws; a.cs_q = dbias_ws + n_kv;
     }
     const int rc = hd == 128 ? fa64_bwd_launch<128>(a, stream) : hd == 96 ? fa64_bwd_launch<96>(a, stream) : fa64_bwd_launch<64>(a, stream);
     if (rc || !dbias_q) return rc;

@@ -647,7 +647,11 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     } while (0)
     bool cs_fused = false;
     if (big && !(d->flags & 2048)) {
-        if (d->colsum_out && nsplit == 1 && nb1 * a.nb2 == 1) { a.cs_ws = d->colsum_ws; cs_fused = true; }                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
+        if (d->colsum_out && nsplit == 1 && nb1 * a.nb2 == 1) {
+            float* slice = pb_defer_alloc((size_t)2 * a.tiles_m * d->N);          // deferred reduction: the partial rows must outlive this call
+            a.cs_ws = slice ? slice : d->colsum_ws;
+            cs_fused = true;
+        }                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
         auto kfn = wide192 ? gemm3_kernel<AK, BK_, 3> : gemm3_kernel<AK, BK_, 4>;                                          \
@@ -673,7 +677,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     }
 #undef PB_G2_LAUNCH
     if (hipGetLastError() != hipSuccess) { pb_set_error("pb_gemm2 launch failed"); return -1; }
-    if (cs_fused && pb_finalize_rows(d->colsum_ws, 2 * a.tiles_m, d->N, d->colsum_out, stream)) return -1;
+    if (cs_fused && pb_finalize_rows(a.cs_ws, 2 * a.tiles_m, d->N, d->colsum_out, stream)) return -1;
     if (nsplit > 1) {
         if (d->ldc != d->N) { pb_set_error("pb_gemm: split-K needs a dense C (ldc == N)"); return -2; }
         const long n = (long)d->M * d->N;

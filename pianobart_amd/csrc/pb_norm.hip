@@ -9,6 +9,9 @@
 // exact-f32 embedding backward, which scatter-adds into the projected table with f32 atomics).
 #include "pb_common.h"
 #include "pb_api_internal.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 namespace {
 
@@ -157,16 +160,12 @@ template <> struct FinVec<4> { using T = f32x4; static __device__ T ld(const flo
 template <> struct FinVec<1> { using T = float; static __device__ T ld(const float* p) { return *p; } static __device__ void st(float* p, T v) { *p = v; } };
 
 template <int V>   // V = 4: 16-byte accesses (d % 4 == 0, 16-byte aligned pointers); V = 1: any d / alignment
-__global__ __launch_bounds__(8 * FIN_GROUPS) void finalize_partials_kernel(const float* __restrict__ partials, int nblk, int nacc, int d,
-                                                                           float* o0, float* o1, float* o2, float* o3) {
+__device__ __forceinline__ void finalize_block(const float* __restrict__ partials, int nblk, int nacc, int d, float* o, int k, int bx) {
     using F = FinVec<V>;
     using T = typename F::T;
     __shared__ T red[FIN_GROUPS][8];
     const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
-    const int c = V * (blockIdx.x * 8 + cq);
-    const int k = blockIdx.y;
-    float* o = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
-    if (!o) return;
+    const int c = V * (bx * 8 + cq);
     const bool live = c < d;
     T s = T(0.f);
     if (live) {
@@ -190,6 +189,28 @@ __global__ __launch_bounds__(8 * FIN_GROUPS) void finalize_partials_kernel(const
         const T t = ((red[0][cq] + red[1][cq]) + (red[2][cq] + red[3][cq])) + ((red[4][cq] + red[5][cq]) + (red[6][cq] + red[7][cq]));
         F::st(o + c, F::ld(o + c) + t);
     }
+}
+
+template <int V>
+__global__ __launch_bounds__(8 * FIN_GROUPS) void finalize_partials_kernel(const float* __restrict__ partials, int nblk, int nacc, int d,
+                                                                           float* o0, float* o1, float* o2, float* o3) {
+    const int k = blockIdx.y;
+    float* o = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : o3;
+    if (!o) return;
+    finalize_block<V>(partials, nblk, nacc, d, o, k, blockIdx.x);
+}
+
+// Deferred form: one launch sums MANY partial sets (blockIdx.z walks a descriptor table). The ~160 bias / LayerNorm-parameter
+// reductions of one backward pass are 6 us of pure launch + latency each when issued one by one behind their producers; collected
+// in a table they are a single ~0.1 ms launch at the end of backward (pb_defer_begin / pb_defer_flush).
+struct FinDesc { const float* partials; float* o[3]; int nblk, nacc, d, pad; };
+__global__ __launch_bounds__(8 * FIN_GROUPS) void finalize_batch_kernel(const FinDesc* __restrict__ table) {
+    const FinDesc D = table[blockIdx.z];
+    const int k = blockIdx.y;
+    if (k >= D.nacc || (int)blockIdx.x * 32 >= D.d) return;
+    float* o = k == 0 ? D.o[0] : k == 1 ? D.o[1] : D.o[2];
+    if (!o) return;
+    finalize_block<4>(D.partials, D.nblk, D.nacc, D.d, o, k, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ Octuple embed + pos + LN
@@ -382,8 +403,72 @@ extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, 
     return 0;
 }
 
+// ---- deferred reductions (see finalize_batch_kernel). State is per host thread: a backward pass is issued by one thread.
+struct DeferState {
+    bool active = false;
+    float* arena = nullptr; size_t cap = 0, used = 0;       // device floats handed out as partial-sum storage
+    FinDesc* table = nullptr; int table_cap = 0, n = 0, maxd = 0;
+    std::vector<FinDesc> host, uploaded;                   // this pass / what the device table currently holds
+};
+static thread_local DeferState g_defer;
+
+float* pb_defer_alloc(size_t nfloats) {
+    DeferState& S = g_defer;
+    nfloats = (nfloats + 3) & ~(size_t)3;
+    if (!S.active || S.n >= S.table_cap || S.used + nfloats > S.cap) return nullptr;
+    float* p = S.arena + S.used;
+    S.used += nfloats;
+    return p;
+}
+
+static bool defer_push(const float* partials, int nblk, int nacc, int d, float* o0, float* o1, float* o2, float* o3) {
+    DeferState& S = g_defer;
+    if (!S.active || partials < S.arena || partials >= S.arena + S.cap || S.n >= S.table_cap || o3 || nacc > 3) return false;
+    const uintptr_t al = (uintptr_t)partials | (uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2;
+    if (d % 4 || al % 16) return false;
+    FinDesc D = {partials, {o0, o1, o2}, nblk, nacc, d, 0};
+    S.host.push_back(D);
+    S.n++;
+    S.maxd = std::max(S.maxd, d);
+    return true;
+}
+
+extern "C" int pb_defer_begin(float* arena, int64_t arena_floats, void* table, int32_t table_entries) {
+    DeferState& S = g_defer;
+    PB_REQUIRE(arena && table && arena_floats > 0 && table_entries > 0 && (uintptr_t)arena % 16 == 0, "pb_defer_begin: bad arena / table");
+    if (S.table != (FinDesc*)table) S.uploaded.clear();
+    S.active = true; S.arena = arena; S.cap = (size_t)arena_floats; S.used = 0;
+    S.table = (FinDesc*)table; S.table_cap = table_entries; S.n = 0; S.maxd = 0;
+    S.host.clear();
+    return 0;
+}
+
+extern "C" int32_t pb_defer_desc_bytes(void) { return (int32_t)sizeof(FinDesc); }
+
+extern "C" int pb_defer_flush(void* stream_) {
+    DeferState& S = g_defer;
+    if (!S.active) return 0;
+    S.active = false;
+    if (S.n == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    // the table of a training loop is the same every step: upload only when it changed (synchronously -- it is rare, and the
+    // host vector must not be rewritten under an in-flight copy)
+    if (S.uploaded.size() != S.host.size() || memcmp(S.uploaded.data(), S.host.data(), S.host.size() * sizeof(FinDesc)) != 0) {
+        if (hipStreamSynchronize(stream) != hipSuccess ||
+            hipMemcpy(S.table, S.host.data(), S.host.size() * sizeof(FinDesc), hipMemcpyHostToDevice) != hipSuccess) {
+            pb_set_error("pb_defer_flush: descriptor upload failed");
+            return -1;
+        }
+        S.uploaded = S.host;
+    }
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3((S.maxd + 31) / 32, 3, S.n), dim3(8 * FIN_GROUPS), 0, stream, S.table);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
 static int launch_finalize(const float* partials, int nblk, int nacc, int d, float* o0, float* o1, float* o2, float* o3,
                            hipStream_t stream) {
+    if (defer_push(partials, nblk, nacc, d, o0, o1, o2, o3)) return 0;
     const uintptr_t al = (uintptr_t)partials | (uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2 | (uintptr_t)o3;
     if (d % 4 == 0 && al % 16 == 0)
         hipLaunchKernelGGL(finalize_partials_kernel<4>, dim3((d + 31) / 32, nacc), dim3(8 * FIN_GROUPS), 0, stream, partials, nblk, nacc, d, o0, o1, o2, o3);
@@ -406,6 +491,7 @@ extern "C" int pb_add_ln_bwd(const void* dy, const void* res, const void* a, con
     if (T == 0) return 0;
     const int grid = ln_grid(T);
     const size_t lds = (size_t)LN_WAVES * d * sizeof(float);
+    if (float* slice = pb_defer_alloc((size_t)grid * 3 * d)) partials = slice;     // deferred reduction: the partial rows must outlive this call
     PB_LN_DISPATCH(nit_for(d),
         if (dtype == PB_BF16) {
             if (dres_f32)

@@ -22,6 +22,7 @@ from ._lib import LIB, PB_BF16, PB_F32, PBError
 
 _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second HIP stream, bits: 1 = weight-gradient GEMMs, 2 = cross-attention K/V projections, 4 = backward GEMMs as ordinary grids (0: everything on one stream, for A/B)
 _WG_TARGET = int(os.environ.get('PB_WG_TARGET', '192' if _WGRAD_STREAM & 1 else '256'))            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
+_NO_DEFER = bool(int(os.environ.get('PB_NO_DEFER', '0')))                  # developer aid: reduce every bias / LayerNorm gradient right behind its producer (A/B)
 _NO_FUSED_BIAS = bool(int(os.environ.get('PB_NO_FUSED_BIAS', '0')))     # developer aid: A/B the bias gradients fused into the GEMM / attention epilogues
 
 LN_EPS = 1e-5
@@ -548,6 +549,15 @@ class Engine:
         gy, galt = ws['gy']
         genc = ws['genc']
         onehot_route = self.code == PB_BF16 and (B * S) % 64 == 0
+        if not _NO_DEFER:
+            # ~160 bias / LayerNorm-parameter reductions per pass: keep their partial rows and sum them in one launch at the end
+            if 'defer' not in ws:
+                H, hd, ff = self.H, self.hd, max(self.fe, self.fd)
+                per_layer = 3 * self.partials.numel() + int(LIB.query('pb_gemm_colsum_ws_floats', T, ff)) + \
+                    2 * int(LIB.query('pb_flash_bias_ws_floats', B, H, S, S, hd if hd in (64, 96, 128) else 64)) + 64
+                ws['defer'] = (torch.empty((self.NE + self.ND) * per_layer, dtype=torch.float32, device=self.device),
+                               torch.empty(64 * (8 * (self.NE + self.ND) + 8), dtype=torch.uint8, device=self.device))
+            ops.defer_begin(*ws['defer'])
         if gy_dec is not None:
             cur = gy_dec
             for l in reversed(range(self.ND)):
@@ -642,6 +652,8 @@ class Engine:
         ops.gemm(self.dptab, E, g['lin.w'], M=d, N=256, K=R, dtype=PB_F32, a_kc=False, b_kc=False, lda=d, ldb=256, ldc=2048, alpha=16.0,
                  c_f32=True, nb1=8, sA=(R * d, 0), sB=(R * 256, 0), sC=(256, 0))
         self._ready('emb', 'lin.w')
+        if not _NO_DEFER:
+            ops.defer_flush()
         self._join_side()
         if self.grad_hook is not None and self.Gcur is self.G32:
             self.grad_hook(self.n_matrix, self.n_total)          # vectors / position tables (accumulated region)

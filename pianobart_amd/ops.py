@@ -260,3 +260,12 @@ def gather_rows_bwd(dout, ids32, dtable):
 
 def dropout(x, y, seed, site, p):
     LIB.call('pb_dropout', _p(x), _p(y), x.numel(), dtype_code(x.dtype), seed, site, p, _stream())
+
+
+def defer_begin(arena, table):
+    """Open a deferred-reduction window (K15): bias / LayerNorm-parameter partial sums collect in `arena` until defer_flush."""
+    LIB.call('pb_defer_begin', _p(arena), arena.numel(), _p(table), table.numel() // int(LIB.query('pb_defer_desc_bytes')))
+
+
+def defer_flush():
+    LIB.call('pb_defer_flush', _stream())
