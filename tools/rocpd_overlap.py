@@ -1,0 +1,35 @@
+"""Two-stream view of a rocprofv3 rocpd database of `bench.py`: per-stream busy time, their union and the main stream's gaps over the
+last full step (steps are delimited by the AdamW kernel). Usage: python tools/rocpd_overlap.py <results.db>"""
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+kd = [t for t in tabs if 'kernel_dispatch' in t][0]; ks = [t for t in tabs if 'kernel_symbol' in t][0]
+rows = list(db.execute(f"select d.start, d.end, d.stream_id, d.queue_id, s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+ad = [r for r in rows if 'adamw' in r[4]]
+t0, t1 = ad[-2][1], ad[-1][1]
+R = [r for r in rows if r[0] >= t0 and r[1] <= t1]
+
+
+def busy(rs):
+    ev = sorted((r[0], r[1]) for r in rs)
+    if not ev:
+        return 0.0
+    tot, (cs, ce) = 0, ev[0]
+    for s, e in ev[1:]:
+        if s > ce:
+            tot += ce - cs; cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    return (tot + ce - cs) / 1e6
+
+
+streams = sorted({(r[2], r[3]) for r in R})
+print('last step: %.2f ms between AdamW ends; %d kernels' % ((t1 - t0) / 1e6, len(R)))
+for st, q in streams:
+    rs = [r for r in R if r[2] == st]
+    print('  stream %d (hw queue %d): %5d kernels, busy %.2f ms, sum of durations %.2f ms' % (st, q, len(rs), busy(rs), sum(r[1] - r[0] for r in rs) / 1e6))
+print('  union of all streams busy %.2f ms; sum of all durations %.2f ms' % (busy(R), sum(r[1] - r[0] for r in R) / 1e6))
+main = max(streams, key=lambda s: len([r for r in R if r[2] == s[0]]))[0]
+ev = sorted((r[0], r[1]) for r in R if r[2] == main)
+gaps = [s1 - e0 for (s0, e0), (s1, e1) in zip(ev, ev[1:]) if s1 - e0 > 5000]
+print('  main-stream gaps > 5 us: %d, total %.2f ms' % (len(gaps), sum(gaps) / 1e6))
