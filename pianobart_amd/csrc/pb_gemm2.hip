@@ -108,6 +108,17 @@ __device__ __forceinline__ void store8(bf16_t* p, f32x4 a, f32x4 b) {
     bf16x8 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
     *reinterpret_cast<bf16x8*>(p) = r;
 }
+// streaming variants (nt): written / read exactly once before the other pass of the step, so they should not push the operands
+// the NEXT kernel re-reads (g for fc2, dU for the fc1 weight / input gradients) out of L2 and the Infinity Cache
+__device__ __forceinline__ void store8_nt(bf16_t* p, f32x4 a, f32x4 b) {
+    bf16x8 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    __builtin_nontemporal_store(r, reinterpret_cast<bf16x8*>(p));
+}
+__device__ __forceinline__ void load8_nt(const bf16_t* p, f32x4& a, f32x4& b) {
+    const bf16x8 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+    a = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    b = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+}
 __device__ __forceinline__ void load8(const bf16_t* p, f32x4& a, f32x4& b) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
     a = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
@@ -197,11 +208,11 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
                         gelu_both_fast(v0[e], y, dy); v0[e] = y; d0[e] = dy;
                         gelu_both_fast(v1[e], y, dy); v1[e] = y; d1[e] = dy;
                     }
-                    store8(p.aux_out + (long)row * p.ldaux + col, d0, d1);
+                    store8_nt(p.aux_out + (long)row * p.ldaux + col, d0, d1);
                 }
                 if (mul_gg) {                                            // aux_in holds gelu'(pre-activation) from the forward
                     f32x4 u0, u1;
-                    load8(p.aux_in + (long)row * p.ldaux + col, u0, u1);
+                    load8_nt(p.aux_in + (long)row * p.ldaux + col, u0, u1);
                     v0 *= u0; v1 *= u1;
                 }
                 const long ci = (long)row * p.ldc + col;
