@@ -9,7 +9,7 @@
 namespace {
 
 struct Seg9 { int off[9]; };
-constexpr int CE_MAX_BLOCKS = 1024;
+constexpr int CE_MAX_BLOCKS = 2048;
 
 template <typename T>
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int16_t* __restrict__ target,
@@ -63,19 +63,104 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
         partials[(size_t)blockIdx.x * 24 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ sums) {
-    __shared__ float red[8][32];
+// Register-resident form for heads of at most 64 * CE_K classes (the Octuple heads: <= 262): the row's logits are loaded ONCE, all
+// loads of a row in flight together, lane l holding classes l, l + 64, ... of every head; max / first-argmax / sum-exp are VALU-only
+// wave reductions (DPP + permlane swaps). The generic kernel above re-reads the row three times behind dependent LDS-routed
+// shuffles and was pure latency: 310 us for the 168 MB of cfg-2 logits (0.8 TB/s). Same per-lane summation order -> same bits.
+constexpr int CE_K = 5;
+template <typename T>
+__global__ __launch_bounds__(256) void ce_rows_reg_kernel(const float* __restrict__ logits, const int16_t* __restrict__ target,
+        const float* __restrict__ loss_mask, const Seg9 so, float* __restrict__ partials, const float* __restrict__ coef,
+        T* __restrict__ dlogits, int16_t* __restrict__ argmax_out, int rows, int V) {
+    __shared__ float red[4][24];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a_ce = 0.f, a_m = 0.f, a_ok = 0.f;       // lane i<8: running sums of head i
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float* x = logits + row * V;
+        float v[8][CE_K];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = so.off[i], n = so.off[i + 1] - o;
+#pragma unroll
+            for (int k = 0; k < CE_K; ++k) {
+                const int c = lane + 64 * k;
+                v[i][k] = c < n ? x[o + c] : -INFINITY;
+            }
+        }
+        const int my_t = lane < 8 ? (int)target[row * 8 + lane] : 0;
+        const float my_m = lane < 8 ? loss_mask[row * 8 + lane] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = so.off[i], n = so.off[i + 1] - o;
+            const int tgt = __builtin_amdgcn_readlane(my_t, i);
+            const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_m), i));
+            float mx = v[i][0];
+#pragma unroll
+            for (int k = 1; k < CE_K; ++k) mx = fmaxf(mx, v[i][k]);
+            mx = wave_max(mx);
+            // first index attaining the maximum (np.argmax tie rule): class ids < 2^24 are exact in f32
+            float neg_first = -16777216.f;
+#pragma unroll
+            for (int k = CE_K - 1; k >= 0; --k) neg_first = v[i][k] == mx ? -(float)(lane + 64 * k) : neg_first;
+            const int am = (int)(-wave_max(neg_first));
+            float e[CE_K], se = 0.f;
+#pragma unroll
+            for (int k = 0; k < CE_K; ++k) {
+                e[k] = lane + 64 * k < n ? __expf(v[i][k] - mx) : 0.f;
+                se += e[k];                                         // same order as the generic kernel's strided loop
+            }
+            se = wave_sum(se);
+            float xt = 0.f;
+            if (tgt >= 0 && tgt < n) {                              // wave-uniform
+                const int tk = tgt >> 6, tl = tgt & 63;
+                float sel = v[i][0];
+#pragma unroll
+                for (int k = 1; k < CE_K; ++k) sel = tk == k ? v[i][k] : sel;
+                xt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sel), tl));
+            }
+            const float ce = __logf(se) + mx - xt;
+            if (lane == i) {
+                a_ce += ce * m; a_m += m; a_ok += (am == tgt ? 1.f : 0.f) * m;
+                if (argmax_out) argmax_out[row * 8 + i] = (int16_t)am;
+            }
+            if (dlogits) {
+                const float kk = m != 0.f ? coef[i] * m : 0.f;
+                const float inv = 1.0f / se;
+                T* g = dlogits + row * V + o;
+#pragma unroll
+                for (int k = 0; k < CE_K; ++k) {
+                    const int c = lane + 64 * k;
+                    if (c < n) g[c] = from_f<T>(kk * (e[k] * inv - (c == tgt ? 1.f : 0.f)));
+                }
+            }
+        }
+    }
+    if (lane < 8) { red[wave][lane] = a_ce; red[wave][8 + lane] = a_m; red[wave][16 + lane] = a_ok; }
+    __syncthreads();
+    if (threadIdx.x < 24)
+        partials[(size_t)blockIdx.x * 24 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// 24 sums over the block partials: 32 row groups x 32 columns, 8 independent loads in flight per thread, fixed-order LDS tree
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ sums) {
+    __shared__ float red[32][32];
     const int k = threadIdx.x & 31, rg = threadIdx.x >> 5;
     float s = 0.f;
-    if (k < 24)
-        for (int b = rg; b < nblk; b += 8) s += partials[(size_t)b * 24 + k];
+    if (k < 24) {
+        int b = rg;
+        for (; b + 7 * 32 < nblk; b += 8 * 32) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = partials[(size_t)(b + 32 * u) * 24 + k];
+            s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        for (; b < nblk; b += 32) s += partials[(size_t)b * 24 + k];
+    }
     red[rg][k] = s;
     __syncthreads();
-    if (rg == 0 && k < 24) {
-        float t = 0.f;
-        for (int r = 0; r < 8; ++r) t += red[r][k];
-        sums[k] += t;
-    }
+    if (rg < 8) red[rg][k] = (red[rg][k] + red[rg + 8][k]) + (red[rg + 16][k] + red[rg + 24][k]);
+    __syncthreads();
+    if (rg == 0 && k < 24) sums[k] += ((red[0][k] + red[1][k]) + (red[2][k] + red[3][k])) + ((red[4][k] + red[5][k]) + (red[6][k] + red[7][k]));
 }
 
 // counts: stage 1 = per-block column sums of a row range, stage 2 = sum of the block partials (deterministic)
@@ -123,12 +208,19 @@ extern "C" int pb_ce_fwd_bwd(const float* logits, const int16_t* target, const f
     Seg9 so;
     for (int i = 0; i < 9; ++i) so.off[i] = seg_off[i];
     const int grid = max(1, min(CE_MAX_BLOCKS, (T + 3) / 4));
-    if (dtype == PB_BF16)
+    bool small_heads = true;
+    for (int i = 0; i < 8; ++i) small_heads = small_heads && (seg_off[i + 1] - seg_off[i]) <= 64 * CE_K;
+    if (small_heads) {
+        if (dtype == PB_BF16)
+            hipLaunchKernelGGL((ce_rows_reg_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, logits, target, loss_mask, so, partials, coef, (bf16_t*)dlogits, argmax_out, T, V);
+        else
+            hipLaunchKernelGGL((ce_rows_reg_kernel<float>), dim3(grid), dim3(256), 0, stream, logits, target, loss_mask, so, partials, coef, (float*)dlogits, argmax_out, T, V);
+    } else if (dtype == PB_BF16)
         hipLaunchKernelGGL((ce_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, logits, target, loss_mask, so, partials, coef, (bf16_t*)dlogits, argmax_out, T, V);
     else
         hipLaunchKernelGGL((ce_kernel<float>), dim3(grid), dim3(256), 0, stream, logits, target, loss_mask, so, partials, coef, (float*)dlogits, argmax_out, T, V);
     PB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, stream, partials, grid, sums);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, grid, sums);
     PB_LAUNCH_CHECK();
     return 0;
 }
