@@ -431,7 +431,10 @@ class Engine:
         if self._side is None:
             self._side = False
             main = torch.cuda.current_stream(self.device)
-            buf = torch.empty(256 << 20, dtype=torch.float32, device=self.device)      # 1 GiB: each fill runs ~0.2 ms, far longer than it takes to enqueue
+            try:
+                buf = torch.empty(256 << 20, dtype=torch.float32, device=self.device)  # 1 GiB: each fill runs ~0.2 ms, far longer than it takes to enqueue
+            except RuntimeError:                                                       # no room for the probe: stay on one stream
+                return None
             tiny = torch.empty(64, dtype=torch.float32, device=self.device)
             self._side_pool = []
             for _ in range(12):
