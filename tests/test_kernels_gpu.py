@@ -395,3 +395,57 @@ def test_gemm_fused_column_sums(ops, M, N, K, dt):
     ref = (A.double() @ W.double()) * aux.double()
     assert _rel(C, ref) < TOL[dt]
     assert _rel(cs, 0.5 + ref.sum(0)) < (2e-3 if dt == torch.bfloat16 else 1e-5)
+
+
+def test_deferred_reductions_match_immediate(ops):
+    """K15: between pb_defer_begin and pb_defer_flush the LayerNorm-backward and GEMM column-sum producers keep their partial rows in
+    the arena and ONE launch reduces them; results must be bit-identical to the immediate reductions, also when the descriptor table
+    or the arena is too small (those calls fall back to the immediate path) and for outputs that are not 16-byte aligned."""
+    from pianobart_amd._lib import LIB
+    dt, d, T = torch.bfloat16, 768, 2048
+    g = torch.Generator(device='cuda').manual_seed(77)
+    mk = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    cases = []
+    for k in range(3):
+        res, a, dy = mk(T, d).to(dt), mk(T, d).to(dt), mk(T, d).to(dt)
+        w = 1 + 0.2 * mk(d)
+        y = torch.empty(T, d, device='cuda', dtype=dt); mean = torch.empty(T, device='cuda'); rstd = torch.empty(T, device='cuda')
+        ops.add_ln_fwd(res, a, w, torch.zeros(d, device='cuda'), y, mean, rstd, 1e-5, 99, k, 0.1)
+        cases.append((dy, res, a, w, mean, rstd, k))
+    A, W = mk(T, 256).to(dt), (mk(256, 512) / 16).to(dt)
+    aux = mk(T, 512).to(dt)
+    part = torch.empty(int(LIB.query('pb_ln_partials_floats', d)), device='cuda')
+    csw = torch.empty(int(LIB.query('pb_gemm_colsum_ws_floats', T, 512)), device='cuda')
+
+    def run(arena_floats, table_entries, misalign=False):
+        outs = []
+        # one flat output buffer; `misalign` shifts every output vector by one float (no 16-byte alignment -> immediate path)
+        flat = torch.zeros(16 * 1024 + 1, device='cuda')
+        pos = [1 if misalign else 0]
+
+        def vec(n):
+            v = flat[pos[0]:pos[0] + n]
+            pos[0] += ((n + 3) // 4) * 4
+            outs.append(v)
+            return v
+        arena = torch.empty(max(arena_floats, 4), device='cuda')
+        table = torch.empty(max(table_entries, 1) * int(LIB.query('pb_defer_desc_bytes')), dtype=torch.uint8, device='cuda')
+        if arena_floats:
+            ops.defer_begin(arena, table)
+        dres = torch.empty(T, d, device='cuda', dtype=dt); da = torch.empty_like(dres)
+        for dy, res, a, w, mean, rstd, k in cases:
+            ops.add_ln_bwd(dy, res, a, w, mean, rstd, dres, da, vec(d), vec(d), vec(d), part, False, 99, k, 0.1)
+        C = torch.empty(T, 512, device='cuda', dtype=dt)
+        ops.gemm(A, W, C, M=T, N=512, K=256, dtype=ops.PB_BF16, b_kc=False, ldb=512, gelu_grad_aux_in=aux, colsum_out=vec(512), colsum_ws=csw)
+        if arena_floats:
+            ops.defer_flush()
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs]
+
+    ref = run(0, 0)
+    big = 3 * part.numel() + csw.numel() + 64
+    for arena_floats, entries, mis in [(big, 16, False), (big, 2, False), (part.numel() + 8, 16, False), (big, 16, True), (big, 16, False)]:
+        got = run(arena_floats, entries, mis)
+        for r, o in zip(ref, got):
+            assert torch.equal(r, o), (arena_floats, entries, mis, float((r - o).abs().max()))
+    assert all(float(r.abs().max()) > 0 for r in ref)
