@@ -197,6 +197,11 @@ int pb_ce_rows(const float* logits, const int32_t* target, const float* weight, 
 int pb_gather_rows(const float* table, const int32_t* ids, const float* bias, float* out, int64_t T, int32_t d, int32_t nrows, void* stream);
 int pb_gather_rows_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t T, int32_t d, int32_t nrows, void* stream);
 int pb_dropout(const void* x, void* y, int64_t n, int32_t dtype, uint64_t seed, uint32_t site, float p_drop, void* stream);
+/* The optional regulariser of the fine-tune loop, `loss += weight * torch.norm(param, p=2)` for every parameter tensor
+ * (finetune.py:241-243): *loss_acc += weight * ||p||_2 (if loss_acc != NULL) and g += weight * p / ||p||_2 (if g != NULL; 0 where the
+ * norm is 0, as torch's norm backward). p, g: n f32 elements, any alignment; scratch: pb_l2_penalty_scratch_floats() floats. */
+int pb_l2_penalty(const float* p, float* g, int64_t n, float weight, float* scratch, float* loss_acc, void* stream);
+int64_t pb_l2_penalty_scratch_floats(void);
 
 /* ---- K13: batch-1 KV-cached decode (model.py:28-66) --------------------------------------------------------------
  * pb_gemv: y[n] = act(sum_k W[n][k] x[k] + bias[n]), W (N,K) row-major in dtype, x (K) dtype, y dtype or f32, gelu = exact erf GELU.

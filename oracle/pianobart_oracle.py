@@ -427,6 +427,11 @@ def finetune_loss(predict, target, loss_mask, seq):
     return torch.sum(loss) / loss.shape[0]
 
 
+def l2_penalty(params, weight):
+    """finetune.py:241-243: `for param in self.model.parameters(): loss += self.weight * torch.norm(param, p=2)`."""
+    return sum(weight * torch.norm(p, p=2) for p in params)
+
+
 def loss_weights(e2w):
     """pretrain.py:185-189: weights are len(e2w[etype]) in *dict order*, applied to heads
     in classes order (SURVEY a-8)."""

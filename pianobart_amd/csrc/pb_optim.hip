@@ -6,6 +6,7 @@
 //   p -= lr * wd * p        (decoupled decay AFTER the update)
 #include "pb_common.h"
 #include "pb_api_internal.h"
+#include <algorithm>
 #include <cmath>
 
 namespace {
@@ -96,6 +97,48 @@ __global__ __launch_bounds__(OPT_THREADS) void fill_kernel(float* __restrict__ d
 int opt_grid(long n4) { return (int)std::max(1L, std::min((long)OPT_BLOCKS, (n4 + OPT_THREADS - 1) / OPT_THREADS)); }
 
 }  // namespace
+
+// ---- fine-tune regulariser `loss += weight * torch.norm(param, p=2)` per parameter tensor (finetune.py:241-243)
+constexpr int L2_BLOCKS = 256;
+__global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ p, long n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += p[i] * p[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// every block re-derives ||p||^2 from the (<= 256) partials in the same fixed order, then g += weight * p / ||p||
+// (0 where ||p|| = 0, torch's norm backward); block 0 adds weight * ||p|| to the loss accumulator.
+__global__ __launch_bounds__(256) void l2_apply_kernel(const float* __restrict__ p, float* __restrict__ g, long n, const float* __restrict__ part,
+                                                       int nblk, float weight, float* __restrict__ loss_acc) {
+    __shared__ float red[4];
+    float s = (int)threadIdx.x < nblk ? part[threadIdx.x] : 0.f;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float sq = (red[0] + red[1]) + (red[2] + red[3]);
+    const float nrm = sqrtf(sq);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_acc) *loss_acc += weight * nrm;
+    if (!g || sq <= 0.f) return;
+    const float k = weight / nrm;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] += k * p[i];
+}
+
+extern "C" int64_t pb_l2_penalty_scratch_floats(void) { return L2_BLOCKS; }
+
+extern "C" int pb_l2_penalty(const float* p, float* g, int64_t n, float weight, float* scratch, float* loss_acc, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PB_REQUIRE(n >= 0 && p && scratch, "pb_l2_penalty: p and scratch are required");
+    if (n == 0) return 0;
+    const int grid = (int)std::max<long>(1, std::min<long>(L2_BLOCKS, (n + 1023) / 1024));
+    hipLaunchKernelGGL(l2_partial_kernel, dim3(grid), dim3(256), 0, stream, p, (long)n, scratch);
+    PB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(l2_apply_kernel, dim3(g ? grid : 1), dim3(256), 0, stream, p, g, (long)n, scratch, grid, weight, loss_acc);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int64_t pb_norm_partials_floats(void) { return OPT_BLOCKS; }
 

@@ -16,7 +16,7 @@ import torch
 from torch.utils.data import Dataset
 
 from . import heads, ops
-from ._lib import PBError
+from ._lib import LIB, PBError
 from .model import SequenceClassification, TokenClassification
 
 
@@ -120,8 +120,6 @@ class FinetuneTrainer:
             raise PBError('pianobart_amd has no CPU execution path')
         if cuda_devices is not None and len(cuda_devices) > 1:
             raise PBError('nn.DataParallel is replaced by one process per GPU (torch.distributed.run)')
-        if weight is not None:
-            raise PBError('--weight (L2 penalty through autograd on every parameter, finetune.py:219-221) is not built')
         self.device = torch.device('cuda', cuda_devices[0] if cuda_devices else 0)
         print('   device:', self.device)
         self.pianobart, self.SeqClass, self.class_num = pianobart, SeqClass, class_num
@@ -140,6 +138,26 @@ class FinetuneTrainer:
         self.lr = lr
         self.testset_shape = testset_shape if not error else testset_shape[:-1]
         self.error = error
+        self.weight = weight
+        if weight is not None:
+            self._l2_scratch = torch.empty(int(LIB.query('pb_l2_penalty_scratch_floats')), dtype=torch.float32, device=self.device)
+            self._l2_acc = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._engine_slot = {id(p): i for i, p in enumerate(self.engine.params)}
+
+    def l2_penalty(self, with_grad):
+        """finetune.py:241-243: `loss += weight * torch.norm(param, p=2)` over model.parameters(). Returns the penalty (device scalar);
+        with_grad adds weight * p / ||p|| to every gradient (for the backbone: in the engine's flat gradient buffer the optimizer reads).
+        BART's never-read `shared` table has no gradient here (SURVEY a-3): it only contributes its norm to the reported loss."""
+        ops.fill_f32(self._l2_acc, 0.0)
+        for p in self.model.parameters():
+            if not p.is_cuda or p.dtype != torch.float32 or not p.data.is_contiguous():
+                raise PBError('l2_penalty: parameters must be contiguous f32 HIP tensors')
+            g = None
+            if with_grad:
+                i = self._engine_slot.get(id(p))
+                g = self.engine.grad_views[i] if i is not None else p.grad
+            ops.l2_penalty(p.data, g, self.weight, self._l2_scratch, self._l2_acc)
+        return self._l2_acc
 
     def compute_loss(self, predict, target, loss_mask, seq):
         """finetune.py:121-129; predict (..., C) (the reference permutes to (B, C, S) for nn.CrossEntropyLoss)."""
@@ -199,6 +217,9 @@ class FinetuneTrainer:
                     self.model.zero_grad()
                     self.head_optim.zero_grad()
                     loss.backward()
+                if self.weight is not None:                                  # the regulariser is part of the reported loss in every mode
+                    total_loss += float(self.l2_penalty(mode == 0))
+                if mode == 0:
                     self.engine.optimizer_step(lr=self.lr, max_norm=float('inf'))          # no clipping in fine-tune (finetune.py:227)
                     self.head_optim.step()
         res = (round(total_loss / len(training_data), 4), round(total_acc / total_cnt, 4))

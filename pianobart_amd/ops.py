@@ -269,3 +269,8 @@ def defer_begin(arena, table):
 
 def defer_flush():
     LIB.call('pb_defer_flush', _stream())
+
+
+def l2_penalty(p, g, weight, scratch, loss_acc):
+    """finetune.py:241-243 for one parameter tensor: loss_acc += weight * ||p||, g += weight * p / ||p|| (g may be None)."""
+    LIB.call('pb_l2_penalty', _p(p), _p(g), p.numel(), float(weight), _p(scratch), _p(loss_acc), _stream())

@@ -114,3 +114,52 @@ def test_finetune_trainer_end_to_end(task):
     assert tuple(out.shape) == tuple(y.shape) and 0.0 <= ta <= 1.0
     assert all(not torch.equal(a, b.detach()) for a, b in zip(head_before, tr.head_optim.params))
     assert not torch.equal(bb_before, pb.bart.encoder.layers[0].fc1.weight.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['seq', 'tok4'])
+def test_weight_regulariser_matches_oracle(tag):
+    """--weight (finetune.py:241-243): penalty value and the gradients it adds (per parameter TENSOR: q / k / v separately, zero-norm
+    tensors get 0) against the oracle's autograd on the same weights and inputs."""
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a HIP device')
+    from torch.utils.data import DataLoader
+    from oracle import pianobart_oracle as O
+    from pianobart_amd import model as M
+    from pianobart_amd.finetune import FinetuneDataset, FinetuneTrainer
+    z = np.load(os.path.join(GOLD, 'g12_finetune_heads.npz'))
+    W = 0.01
+    mo = _build(O, O.BartConfig, O.PianoBart, tag)
+    yo, lo = _run(mo, z, tag, 'cpu', O.finetune_loss)
+    live = [p for k, p in mo.named_parameters() if 'shared' not in k and 'embed_tokens' not in k]
+    pen_all = float(O.l2_penalty(list(mo.parameters()), W))
+    mo.zero_grad()
+    (lo + O.l2_penalty(live, W)).backward()
+    ref = {k: p.grad.clone() for k, p in mo.named_parameters() if p.grad is not None}
+
+    m = _build(M, M.BartConfig, M.PianoBart, tag, precision='fp32').cuda()
+    seq = tag == 'seq'
+    dl = DataLoader(FinetuneDataset(z['enc'], z[tag + '_y']), batch_size=z['enc'].shape[0])
+    tr = FinetuneTrainer(m.pianobart, dl, dl, dl, lr=1e-3, class_num=8 if seq else 3, hs=D, testset_shape=z[tag + '_y'].shape, cpu=False,
+                         cuda_devices=[0], model=m, SeqClass=seq, weight=W)
+    lossf = lambda yh, y, mask, s: tr.compute_loss(yh, y, mask, s)
+    yh, loss = _run(m, z, tag, 'cuda', lossf)
+    m.zero_grad()
+    loss.backward()
+    pen = float(tr.l2_penalty(True))
+    assert abs(pen - pen_all) < 1e-5 * pen_all
+    eng = tr.engine
+    slot = {id(p): i for i, p in enumerate(eng.params)}
+    n = 0
+    for k, p in m.named_parameters():
+        if k not in ref:
+            continue
+        g = eng.grad_views[slot[id(p)]] if id(p) in slot else p.grad
+        r = _rel(g.detach().cpu(), ref[k])
+        assert r < 2e-3, (k, r)
+        n += 1
+    assert n > 40
+    # evaluation mode: value only, gradients untouched
+    before = eng.G32.clone()
+    assert abs(float(tr.l2_penalty(False)) - pen_all) < 1e-5 * pen_all
+    assert torch.equal(before, eng.G32)
