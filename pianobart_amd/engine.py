@@ -305,6 +305,7 @@ class Engine:
         B, S = enc16.shape[:2]
         if S > self.Smax:
             raise PBError('sequence length %d exceeds max_position_embeddings %d' % (S, self.Smax))
+        self._fwd_token += 1          # any forward (generate included) overwrites the activation workspace: older autograd graphs are stale
         d, T = self.d, B * S
         ws = self._ws(B, S)
         self._cur_ws = ws

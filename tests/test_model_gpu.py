@@ -384,3 +384,21 @@ def test_second_stream_gives_identical_gradients(precision, train):
                 assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), name
             else:
                 assert torch.equal(a, b), (name, float((a - b).abs().max()))
+
+
+def test_backward_after_an_intervening_forward_fails_loudly():
+    """The engine keeps the activations of the most recent forward only: a backward through an older graph (here: after a generate
+    call reused the workspace) must raise, not return gradients computed from overwritten activations."""
+    _need_gpu()
+    from pianobart_amd._lib import PBError
+    m = _lm(64, 64, 2, 128, 4, 5, 'fp32', dropout=0.0).train().cuda()
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(1, 64, seed=2)]
+    out = m(enc, dec, emask, dmask)
+    loss = sum(o.float().sum() for o in out)
+    with torch.no_grad():
+        m.eval()
+        np.random.seed(0)
+        m(enc, encoder_attention_mask=emask, generate=True)
+        m.train()
+    with pytest.raises(PBError):
+        loss.backward()
