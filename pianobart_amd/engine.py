@@ -816,13 +816,20 @@ class Engine:
                 L.ln2_w, L.ln2_b = P(wf[pf + 'ln2.w']), P(wf[pf + 'ln2.b'])
                 L.kv_self, L.kv_cross = P(kvs[l]), P(kvc[l])
             pref = ctypes.byref(plan)
+            stream = ops._stream()
+            tok_pin = torch.empty(8, dtype=torch.int16).pin_memory()         # one small H2D per position; the result goes up once at the end
+            logit_pin = torch.empty(ops.VOCAB, dtype=torch.float32).pin_memory()
+            res_cpu = pad_cpu.repeat(S, 1)
             for i in range(S):
-                LIB.call('pb_decode_step', pref, i, ops._stream())
-                tok = sample_row(logits[0].cpu())
+                LIB.call('pb_decode_step', pref, i, stream)
+                logit_pin.copy_(logits[0])                                  # D2H on the current stream, returns when the row has landed
+                tok = sample_row(logit_pin)
                 if (tok >= pad_cpu).any():
                     break
-                result[:, i, :] = tok.to(dev)
-                tok16.copy_(tok.to(torch.int16))
+                res_cpu[i] = tok
+                tok_pin.copy_(tok)
+                tok16.copy_(tok_pin, non_blocking=True)                     # stream-ordered before the next step's kernels
+            result = res_cpu.to(dev).unsqueeze(0)
         return result
 
     def _generate_pyloop(self, enc_ids, emask, sample_row):
