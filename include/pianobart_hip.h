@@ -206,7 +206,7 @@ int64_t pb_l2_penalty_scratch_floats(void);
 /* ---- K13: batch-1 KV-cached decode (model.py:28-66) --------------------------------------------------------------
  * pb_gemv: y[n] = act(sum_k W[n][k] x[k] + bias[n]), W (N,K) row-major in dtype, x (K) dtype, y dtype or f32, gelu = exact erf GELU.
  * pb_attn_decode: one query (H*hd) against cached K/V rows (element (j,h,c) at ptr[j*ss + h*hd + c]), keys 0..Sk-1, optional
- * key mask (Sk) float; a row with no visible key gives zeros. head_dim 32, 64 or 128, Sk <= 8192.
+ * key mask (Sk) float; a row with no visible key gives zeros. head_dim 32, 64, 96 or 128, Sk <= 8192.
  * pb_decode_step: one decoder token through all layers: embed(tok16) + pos[i] -> ND x [self-attn with K/V appended at row i,
  * cross-attn on the cached encoder K/V, FFN] -> logits (vocab) f32. All pointers device pointers, weights in dtype storage,
  * biases / LayerNorm / tables f32. */

@@ -97,19 +97,24 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, cons
 // on this multi-XCD part (20 us), more than the parallelism returns at these sizes.
 constexpr int AD_WAVES = 16;
 
-template <typename T, int CPR>
+// CPR = lanes per key row (a power of two), CR = 16-byte chunks a row really has (head_dim 96: 12 of 16 bf16 / 24 of 32 f32 lanes
+// carry data, the others hold zeros and load nothing).
+template <typename T, int CPR, int CR = CPR>
 __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                                     const T* __restrict__ vc, T* __restrict__ out,
                                                                     const float* __restrict__ key_mask, int Sk, long k_ss, long v_ss,
                                                                     float scale) {
-    constexpr int EPV = 16 / sizeof(T), HD = CPR * EPV, KPW = 64 / CPR;       // keys per wave-wide load
+    constexpr int EPV = 16 / sizeof(T), HD = CR * EPV, KPW = 64 / CPR;        // keys per wave-wide load
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem);            // [Sk] scores -> probabilities
     float* red = sc + ((Sk + 3) & ~3);                     // [16] reductions, then [16][HD] partial outputs
     const int h = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, sub = lane % CPR, grp = lane / CPR;
+    const bool live = CR == CPR || sub < CR;
     float qv[EPV];
-    {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) qv[e] = 0.f;
+    if (live) {
         T qq[EPV];
         *reinterpret_cast<uint4*>(qq) = *reinterpret_cast<const uint4*>(q + h * HD + sub * EPV);
 #pragma unroll
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const T* __r
 #pragma unroll
         for (int r = 0; r < UR; ++r) {
             const int j = jb + r * STEP + grp;
-            if (j < Sk) kraw[r] = *reinterpret_cast<const uint4*>(kc + (long)j * k_ss + h * HD + sub * EPV);
+            kraw[r] = uint4{0u, 0u, 0u, 0u};
+            if (j < Sk && live) kraw[r] = *reinterpret_cast<const uint4*>(kc + (long)j * k_ss + h * HD + sub * EPV);
         }
 #pragma unroll
         for (int r = 0; r < UR; ++r) {
@@ -170,7 +176,8 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const T* __r
 #pragma unroll
             for (int r = 0; r < UR; ++r) {
                 const int j = jb + r * STEP + grp;
-                if (j < Sk) vraw[r] = *reinterpret_cast<const uint4*>(vc + (long)j * v_ss + h * HD + sub * EPV);
+                vraw[r] = uint4{0u, 0u, 0u, 0u};
+                if (j < Sk && live) vraw[r] = *reinterpret_cast<const uint4*>(vc + (long)j * v_ss + h * HD + sub * EPV);
             }
 #pragma unroll
             for (int r = 0; r < UR; ++r) {
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const T* __r
     for (int e = 0; e < EPV; ++e)
 #pragma unroll
         for (int o = CPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
-    if (grp == 0)
+    if (grp == 0 && live)
 #pragma unroll
         for (int e = 0; e < EPV; ++e) red[wave * HD + sub * EPV + e] = acc[e];
     __syncthreads();
@@ -228,30 +235,32 @@ extern "C" int pb_gemv(const void* W, const void* x, const float* bias, void* y,
     return gemv_launch(W, x, bias, y, nullptr, N, N, K, dtype, y_f32, gelu, (hipStream_t)stream_);
 }
 
-template <typename T, int CPR>
+template <typename T, int CPR, int CR = CPR>
 static void attn_decode_launch(const void* q, const void* kc, const void* vc, void* out, const float* key_mask, int H, int Sk, long k_ss,
                                long v_ss, float scale, hipStream_t stream) {
-    constexpr int HD = CPR * (16 / (int)sizeof(T));
+    constexpr int HD = CR * (16 / (int)sizeof(T));
     const size_t lds = (size_t)(((Sk + 3) & ~3) + AD_WAVES * HD) * sizeof(float);
-    hipLaunchKernelGGL((attn_decode_kernel<T, CPR>), dim3(H), dim3(AD_WAVES * 64), lds, stream, (const T*)q, (const T*)kc, (const T*)vc, (T*)out,
+    hipLaunchKernelGGL((attn_decode_kernel<T, CPR, CR>), dim3(H), dim3(AD_WAVES * 64), lds, stream, (const T*)q, (const T*)kc, (const T*)vc, (T*)out,
                        key_mask, Sk, k_ss, v_ss, scale);
 }
 
 extern "C" int pb_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const float* key_mask, int32_t H, int32_t Sk,
                               int32_t hd, int64_t k_ss, int64_t v_ss, float scale, int32_t dtype, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    PB_REQUIRE(H > 0 && Sk > 0 && Sk <= 8192 && (hd == 32 || hd == 64 || hd == 128),
-               "pb_attn_decode: H=%d Sk=%d hd=%d (head_dim must be 32, 64 or 128; Sk <= 8192)", H, Sk, hd);
+    PB_REQUIRE(H > 0 && Sk > 0 && Sk <= 8192 && (hd == 32 || hd == 64 || hd == 96 || hd == 128),
+               "pb_attn_decode: H=%d Sk=%d hd=%d (head_dim must be 32, 64, 96 or 128; Sk <= 8192)", H, Sk, hd);
     const int epv = dtype == PB_BF16 ? 8 : 4;
     PB_REQUIRE(k_ss % epv == 0 && v_ss % epv == 0 && ((uintptr_t)k_cache % 16 == 0) && ((uintptr_t)v_cache % 16 == 0) && ((uintptr_t)q % 16 == 0),
                "pb_attn_decode: rows must be 16-byte aligned");
     if (dtype == PB_BF16) {
         if (hd == 32) attn_decode_launch<bf16_t, 4>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
         else if (hd == 64) attn_decode_launch<bf16_t, 8>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
+        else if (hd == 96) attn_decode_launch<bf16_t, 16, 12>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
         else attn_decode_launch<bf16_t, 16>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
     } else {
         if (hd == 32) attn_decode_launch<float, 8>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
         else if (hd == 64) attn_decode_launch<float, 16>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
+        else if (hd == 96) attn_decode_launch<float, 32, 24>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
         else attn_decode_launch<float, 32>(q, k_cache, v_cache, out, key_mask, H, Sk, k_ss, v_ss, scale, stream);
     }
     PB_LAUNCH_CHECK();

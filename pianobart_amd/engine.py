@@ -771,7 +771,7 @@ class Engine:
         only depend on decoder inputs <= i (causal), so the tokens are identical (tests/test_model_gpu.py)."""
         if not use_cache:
             return self._generate_nocache(enc_ids, emask, sample_row)
-        if self.hd not in (32, 64, 128):                     # pb_attn_decode's row-chunk layouts; other head sizes use the training kernels
+        if self.hd not in (32, 64, 96, 128):                 # pb_attn_decode's row-chunk layouts; other head sizes use the training kernels
             return self._generate_pyloop(enc_ids, emask, sample_row)
         import ctypes
         from ._lib import DecodePlan

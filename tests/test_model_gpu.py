@@ -235,11 +235,12 @@ def test_cpu_tensors_fail_loudly():
         m(enc, dec, emask, dmask)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-def test_generate_kv_cache_equals_full_rerun(precision):
-    """KV-cached decode (encoder once, cross K/V once, one token per step) == re-running the decoder over all positions."""
+@pytest.mark.parametrize('precision,d,heads', [('fp32', 128, 4), ('bf16', 128, 4), ('fp32', 192, 2), ('bf16', 192, 2), ('bf16', 256, 4)])
+def test_generate_kv_cache_equals_full_rerun(precision, d, heads):
+    """KV-cached decode (encoder once, cross K/V once, one token per step) == re-running the decoder over all positions
+    (head_dim 32, 96 and 64 through the native single-query attention kernel)."""
     _need_gpu()
-    m = _lm(48, 128, 2, 256, 4, 77, precision).eval()
+    m = _lm(48, d, 2, 256, heads, 77, precision).eval()
     with torch.no_grad():                                   # make special tokens unsamplable: the decode runs all 48 steps
         for i, p0 in enumerate([256, 128, 129, 256, 128, 32, 254, 49]):
             m.mask_lm.proj[i].bias[p0:] = -30.0
