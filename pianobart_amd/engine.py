@@ -797,7 +797,12 @@ class Engine:
             logits = torch.empty(1, ops.VOCAB, dtype=torch.float32, device=dev)
             tok16 = torch.tensor(pb.sos_word_np, dtype=torch.int16, device=dev)
             plan = DecodePlan()
-            plan.dtype, plan.d, plan.H, plan.ffn, plan.S, plan.S_enc, plan.n_layers, plan.vocab = self.code, d, self.H, ff, S, S, self.ND, ops.VOCAB
+            s_enc = S
+            if em is not None:                                               # keys behind the last visible encoder position are masked for every query: stop there
+                km = torch.empty(1, dtype=torch.int32, device=dev)
+                ops.key_extent(em, km)
+                s_enc = max(1, min(S, int(km.item())))
+            plan.dtype, plan.d, plan.H, plan.ffn, plan.S, plan.S_enc, plan.n_layers, plan.vocab = self.code, d, self.H, ff, S, s_enc, self.ND, ops.VOCAB
             for k in range(9):
                 plan.tab_off[k] = ops.TAB_OFF[k]
             P = lambda t: t.data_ptr()
