@@ -20,7 +20,7 @@ extern "C" {
 #define PB_F32 0
 #define PB_BF16 1
 
-#define PB_ABI_VERSION 1
+#define PB_ABI_VERSION 2
 int pb_abi_version(void);
 const char* pb_last_error(void);
 
@@ -170,10 +170,26 @@ int pb_shift_right(const int16_t* ids, const int16_t* sos_row /*device 8*/, int1
 /* Replaces Pretrainer.gen_mask (pretrain.py:211-546): one workgroup corrupts one (S,8) sequence in LDS.
  * choice (B) int32 device, 1..5 (other values / NULL: drawn uniformly in-kernel, reported in choice_out if given);
  * out (B,S,8) int16, loss_mask (B,S,8) f32 (per-position mask repeated over the 8 columns, pretrain.py:141-142).
- * pad_row / mask_row / n_tokens: HOST arrays of 8. Same distributions as the reference, Philox instead of MT19937. */
+ * pad_row / mask_row / n_tokens: HOST arrays of 8. mask_percent is a double: int(l * p) and round(l * p) must come out as in
+ * Python. Same distributions as the reference, Philox instead of MT19937. */
 int pb_corrupt(const int16_t* ids, int16_t* out, float* loss_mask, const int32_t* choice, int32_t* choice_out, int32_t B,
-               int32_t S, float mask_percent, uint64_t seed, const int16_t* pad_row, const int16_t* mask_row,
+               int32_t S, double mask_percent, uint64_t seed, const int16_t* pad_row, const int16_t* mask_row,
                const int32_t* n_tokens, void* stream);
+/* The same kernel with its random DECISIONS supplied by the caller instead of drawn from Philox: what is left is the deterministic
+ * part of gen_mask, which must reproduce the reference's outputs bit for bit when fed the reference's own decisions
+ * (tests/test_corrupt_gpu.py, tests/golden/g6_gen_mask.npz). choice (B) int32 device, required. decisions: (B, dec_stride) int32
+ * device, dec_stride >= pb_corrupt_replay_stride(S); per sample, by choice:
+ *   1 TokenDeletion        dec[i] != 0: position i is deleted (the shuffled maskpos of pretrain.py:221-226); i < S
+ *   2 TokenMask            dec[i] = 0 untouched, 1 in mask80 (MASK row), 2 in rand10 (row i of rand_rows), 3 in cur10; i < S
+ *   3 SentencePermutation  dec[bar] = place of bar value `bar` in the shuffled bar order (pretrain.py:385-386)
+ *   4 TokenInfilling       dec[attempt * S + step] = -1 (random.random() >= p/3: copy the row) or the np.random.poisson(3) draw of a
+ *                          span that starts at this step; attempt < 10, steps in the order the reference's while loop takes them
+ *   5 DocumentRotation     dec[0] = the rotation offset (random.randint(0, l-1))
+ * rand_rows: (B,S,8) int16 device, the get_rand_tok() rows of choice 2 (may be NULL when no decision is 2). */
+int pb_corrupt_replay(const int16_t* ids, int16_t* out, float* loss_mask, const int32_t* choice, int32_t B, int32_t S,
+                      double mask_percent, const int32_t* decisions, int64_t dec_stride, const int16_t* rand_rows,
+                      const int16_t* pad_row, const int16_t* mask_row, void* stream);
+int64_t pb_corrupt_replay_stride(int32_t S);
 
 /* ---- K14: fine-tune heads, exact f32 (model.py:128-143 SelfAttention, :165-218 SequenceClassification, :220-232 Excitation,
  * :236-272 TokenClassification; loss finetune.py:121-129). Their matrix products are pb_gemm (f32) calls.

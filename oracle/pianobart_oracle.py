@@ -500,6 +500,9 @@ class Corruptor:
         self.max_seq_len = max_seq_len
         self.mask_percent = mask_percent
         self.Lseq = list(range(max_seq_len))
+        # test aid: when set to a dict, every corruption also records the random DECISIONS it drew (never the RNG calls
+        # themselves, so the streams are untouched) in the layout pb_corrupt_replay takes (include/pianobart_hip.h)
+        self.trace = None
 
     def token_deletion(self, ids):
         l = ids.shape[0]
@@ -507,6 +510,8 @@ class Corruptor:
         maskpos = [1 if i < length else 0 for i in range(l)]
         random.shuffle(maskpos)
         maskpos = np.array(maskpos)
+        if self.trace is not None:
+            self.trace.update(choice=1, dec=maskpos.astype(np.int32).copy())
         masked = ids.numpy()[maskpos == 0]
         pos = np.where(maskpos == 1)[0]
         if len(pos) > 0:
@@ -531,6 +536,12 @@ class Corruptor:
             loss_mask[i] = 1
         for i in cur10:
             loss_mask[i] = 1
+        if self.trace is not None:
+            dec = np.zeros(self.max_seq_len, dtype=np.int32)
+            dec[mask80] = 1; dec[rand10] = 2; dec[cur10] = 3
+            rr = np.zeros((self.max_seq_len, 8), dtype=np.int16)
+            rr[rand10] = out[rand10].numpy()
+            self.trace.update(choice=2, dec=dec, rand_rows=rr)
         return out, loss_mask
 
     def sentence_permutation(self, ids):
@@ -543,6 +554,11 @@ class Corruptor:
             sentence.append(bar)
         sentence = list(set(sentence))
         random.shuffle(sentence)
+        if self.trace is not None:
+            dec = np.zeros(65536, dtype=np.int32)
+            for place, b in enumerate(sentence):
+                dec[int(b)] = place
+            self.trace.update(choice=3, dec=dec)
         out = []
         for b in sentence:
             out += sentences[b]
@@ -554,12 +570,18 @@ class Corruptor:
         mask_row = torch.from_numpy(self.pb.mask_word_np)
         pad_row = torch.from_numpy(self.pb.pad_word_np)
         l = ids.shape[0]
+        if self.trace is not None:
+            self.trace.update(choice=4, dec=np.full(10 * l, -1, dtype=np.int32))
         for k in range(10):
             rows = []
             i = 0
+            step = 0
             while i < l:
+                step += 1
                 if random.random() < self.mask_percent / max(1, lamda):
                     p = np.random.poisson(lamda)
+                    if self.trace is not None:
+                        self.trace['dec'][k * l + step - 1] = p
                     if p == 0:
                         rows.append(ids[i])
                         rows.append(mask_row)
@@ -583,6 +605,8 @@ class Corruptor:
     def document_rotation(self, ids):
         l = ids.shape[0]
         ran = random.randint(0, l - 1)
+        if self.trace is not None:
+            self.trace.update(choice=5, dec=np.array([ran], dtype=np.int32))
         masked = torch.cat((ids[ran:], ids[0:ran]), dim=0)
         maskpos = torch.full((l,), 1 if ran != 0 else 0, dtype=torch.int64)
         return masked, maskpos

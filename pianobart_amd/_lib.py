@@ -45,7 +45,7 @@ class DecodePlan(ctypes.Structure):
 
 
 _SCALARS = {'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64,
-            'uint32_t': ctypes.c_uint32, 'float': ctypes.c_float, 'int': ctypes.c_int}
+            'uint32_t': ctypes.c_uint32, 'float': ctypes.c_float, 'double': ctypes.c_double, 'int': ctypes.c_int}
 
 
 def parse_header(path=HEADER):
@@ -90,8 +90,8 @@ class _Lib:
                 fn.restype = restype
                 fn.argtypes = argtypes
             ver = dll.pb_abi_version()
-            if ver != 1:
-                raise PBError('ABI version mismatch: library %d, binding 1' % ver)
+            if ver != 2:
+                raise PBError('ABI version mismatch: library %d, binding 2' % ver)
             self._dll = dll
         return self._dll
 

@@ -218,7 +218,17 @@ def corrupt(ids16, out16, loss_mask, choice, choice_out, mask_percent, seed, pad
     pr = (ctypes.c_int16 * 8)(*[int(x) for x in pad_row])
     mr = (ctypes.c_int16 * 8)(*[int(x) for x in mask_row])
     nt = (ctypes.c_int32 * 8)(*[int(x) for x in n_tokens])
-    LIB.call('pb_corrupt', _p(ids16), _p(out16), _p(loss_mask), _p(choice), _p(choice_out), B, S, mask_percent, seed, pr, mr, nt, _stream())
+    LIB.call('pb_corrupt', _p(ids16), _p(out16), _p(loss_mask), _p(choice), _p(choice_out), B, S, float(mask_percent), seed, pr, mr, nt, _stream())
+
+
+def corrupt_replay(ids16, out16, loss_mask, choice, mask_percent, decisions, rand_rows, pad_row, mask_row):
+    """pb_corrupt with caller-supplied random decisions (layout: include/pianobart_hip.h). decisions (B, stride) int32 device,
+    rand_rows (B,S,8) int16 device or None."""
+    B, S = ids16.shape[:2]
+    pr = (ctypes.c_int16 * 8)(*[int(x) for x in pad_row])
+    mr = (ctypes.c_int16 * 8)(*[int(x) for x in mask_row])
+    LIB.call('pb_corrupt_replay', _p(ids16), _p(out16), _p(loss_mask), _p(choice), B, S, float(mask_percent), _p(decisions),
+             decisions.shape[1], _p(rand_rows), pr, mr, _stream())
 
 
 def key_extent(key_mask, kmax):

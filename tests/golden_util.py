@@ -97,3 +97,91 @@ def synth_octuple_batch(B, S, seed, min_len=None):
     dmask = (dec[:, :, 0] != 256).astype(np.float32)
     t = torch.from_numpy
     return t(enc), t(dec), t(loss_mask), t(emask), t(dmask), t(tgt)
+
+
+# ---------------------------------------------------------------- gen_mask decision replay (SURVEY a-9)
+def g6_replay_cases():
+    """The 25 single-sequence cases (choices 1-5 x seeds 0-4) and the 3-sample batch of tests/golden/g6_gen_mask.npz, each with the
+    random DECISIONS the oracle drew under the golden's seeds (oracle Corruptor.trace; layout: include/pianobart_hip.h,
+    pb_corrupt_replay). Returns (single, batch): lists of dicts with ids (S,8) int64, choice, dec int32, rand_rows (S,8) int16 or
+    None, masked (S,8) int64 and pos (S,) int64 = the reference's outputs."""
+    import random
+    from oracle import pianobart_oracle as O
+    e2w, w2e = load_vocab()
+    z = np.load(os.path.join(GOLD, 'g6_gen_mask.npz'))
+    pb = O.PianoBart(O.BartConfig(max_position_embeddings=64, d_model=32, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=64,
+                                  decoder_ffn_dim=64, encoder_attention_heads=4, decoder_attention_heads=4), e2w, w2e)
+    corr = O.Corruptor(pb, 64, 0.15)
+    ids = torch.from_numpy(z['ids']).long()
+
+    def case(ids_row, masked, pos):
+        tr = corr.trace
+        return dict(ids=ids_row.numpy().astype(np.int64), choice=tr['choice'], dec=tr['dec'], rand_rows=tr.get('rand_rows'),
+                    masked=np.asarray(masked).astype(np.int64), pos=np.asarray(pos).astype(np.int64).reshape(len(ids_row), -1)[:, 0])
+
+    single = []
+    for choice in range(1, 6):
+        for seed in range(5):
+            random.seed(seed); np.random.seed(seed)
+            corr.trace = {}
+            masked, pos = corr.gen_mask(ids.clone(), choice)
+            c = case(ids, z['masked_c%d_s%d' % (choice, seed)], z['pos_c%d_s%d' % (choice, seed)])
+            assert np.array_equal(np.asarray(masked).astype(np.int64), c['masked'])          # oracle == reference (G6)
+            single.append(c)
+    batch = []
+    random.seed(7); np.random.seed(7)
+    ori = torch.from_numpy(z['batch']).long()
+    for b in range(ori.shape[0]):                                   # pretrain.py:127-153 draws the choice, then the corruption, per sample
+        corr.trace = {}
+        corr.gen_mask(ori[b].clone())
+        batch.append(case(ori[b], z['batch_enc'][b], z['batch_loss_mask'][b][:, 0]))
+    corr.trace = None
+    return single, batch
+
+
+def apply_decisions_numpy(c, mask_percent=0.15):
+    """Host restatement of the APPLY stage of pb_corrupt (csrc/pb_corrupt.hip) on one case of g6_replay_cases(): decisions + input ->
+    (out (S,8), loss mask (S,)). Shows that the decision layout carries all of gen_mask's randomness (CPU test); the kernel itself is
+    checked on the GPU."""
+    ids, dec, ch = c['ids'], c['dec'], c['choice']
+    S = ids.shape[0]
+    mask_row = PAD + 1
+    out = np.zeros_like(ids); lm = np.zeros(S, dtype=np.int64)
+    if ch == 1:
+        k = int(S * mask_percent)
+        dele = dec[:S] != 0
+        first = int(np.argmax(dele)) if dele.any() else S
+        kept = ids[~dele]
+        out[:len(kept)] = kept; out[S - k:] = PAD
+        lm[first:] = 1
+    elif ch == 2:
+        out = ids.copy()
+        out[dec[:S] == 1] = mask_row
+        out[dec[:S] == 2] = c['rand_rows'][dec[:S] == 2]
+        lm = (dec[:S] != 0).astype(np.int64)
+    elif ch == 3:
+        order = sorted(range(S), key=lambda i: (dec[ids[i, 0]], i))
+        out = ids[order]
+        lm = (out != ids).any(1).astype(np.int64)
+    elif ch == 4:
+        ok = False
+        for att in range(10):
+            rows, i, s = [], 0, 0
+            while i < S:
+                v = dec[att * S + s]; s += 1
+                if v == 0:
+                    rows += [ids[i], mask_row]; i += 1
+                elif v > 0:
+                    rows.append(mask_row); i += v
+                else:
+                    rows.append(ids[i]); i += 1
+            if len(rows) <= S:
+                rows += [PAD] * (S - len(rows)); ok = True
+                break
+        out = np.stack(rows) if ok else ids.copy()
+        lm = (out != ids).any(1).astype(np.int64) if ok else np.zeros(S, dtype=np.int64)
+    else:
+        ran = int(dec[0])
+        out = np.roll(ids, -ran, axis=0)
+        lm[:] = 1 if ran != 0 else 0
+    return out, lm

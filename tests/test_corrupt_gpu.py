@@ -1,7 +1,8 @@
 """GPU: device corruption kernel (counterpart of Pretrainer.gen_mask, pretrain.py:211-546).
-The Python/NumPy random streams of the reference cannot be reproduced bit-for-bit on the device (that is
-the oracle's job, tests/test_oracle_golden.py::test_g6_*); here the structure the reference's own hand-made
-gen_mask inputs are about (pretrain.py:582-688) is asserted exactly, plus the distributions."""
+Bit parity: the kernel's DECIDE stage is replaced by the reference's own random decisions (recorded by the oracle under the golden
+seeds) and its outputs must equal tests/golden/g6_gen_mask.npz exactly (test_replay_*). The Philox-driven DECIDE stage cannot
+reproduce the Mersenne-Twister streams of Python's `random`; for it the structure the reference's own hand-made gen_mask inputs
+are about (pretrain.py:582-688) is asserted exactly, plus the distributions."""
 import collections
 
 import numpy as np
@@ -57,7 +58,8 @@ def test_deletion(ops, batch):
         m = lm[b, :, 0]
         first = int(np.argmax(m)) if m.any() else S
         assert (m[first:] == 1).all() and (m[:first] == 0).all() and (lm[b] == lm[b, :, :1]).all()
-        assert first <= removed[0] + 0 or True
+        # the loss mask starts at the first deleted index (identical neighbouring rows -- the PAD tail -- make the greedy match late)
+        assert first <= removed[0] and (ids[b, first:removed[0] + 1] == ids[b, first]).all()
     # different seeds delete different positions
     out2, _, _ = _run(ops, batch, 1, 6)
     assert (out != out2).any()
@@ -130,3 +132,75 @@ def test_rotation_and_random_choice(ops, batch):
     assert set(cnt) <= {1, 2, 3, 4, 5} and len(cnt) == 5
     _, _, ch2 = _run(ops, big, 0, 17)
     assert (ch == ch2).all()                                                      # deterministic per seed
+
+
+def _replay(ops, cases, p=0.15):
+    from pianobart_amd._lib import LIB
+    B, S = len(cases), cases[0]['ids'].shape[0]
+    stride = int(LIB.query('pb_corrupt_replay_stride', S))
+    dec = np.zeros((B, stride), dtype=np.int32)
+    rr = np.zeros((B, S, 8), dtype=np.int16)
+    for b, c in enumerate(cases):
+        dec[b, :len(c['dec'])] = c['dec']
+        if c['rand_rows'] is not None:
+            rr[b] = c['rand_rows']
+    ids16 = ops.ids_to_i16(torch.from_numpy(np.stack([c['ids'] for c in cases])).cuda())
+    out = torch.full_like(ids16, -1); lm = torch.full((B, S, 8), -1.0, device='cuda')
+    ch = torch.tensor([c['choice'] for c in cases], dtype=torch.int32, device='cuda')
+    ops.corrupt_replay(ids16, out, lm, ch, p, torch.from_numpy(dec).cuda(), torch.from_numpy(rr).cuda(), PAD, MASK)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().astype(np.int64), lm.cpu().numpy()
+
+
+def test_replay_matches_reference_goldens_bit_exact(ops):
+    """SURVEY a-9: with the reference's random decisions (seeds 0-4 x choices 1-5 of G6) the kernel's outputs and loss masks are
+    the reference's, bit for bit: 25 cases in one launch."""
+    from tests.golden_util import g6_replay_cases
+    single, _ = g6_replay_cases()
+    out, lm = _replay(ops, single)
+    for b, c in enumerate(single):
+        assert np.array_equal(out[b], c['masked']), ('rows', c['choice'], b % 5)
+        assert np.array_equal(lm[b], np.repeat(c['pos'][:, None], 8, 1).astype(np.float32)), ('loss mask', c['choice'], b % 5)
+
+
+def test_replay_batch_construction_matches_reference(ops):
+    """pretrain.py:127-153 on the golden 3-sample batch (choices drawn by random.randint under seed 7): corrupted encoder ids, loss mask,
+    shift-right decoder ids and both attention masks equal the reference's."""
+    from tests.golden_util import GOLD, g6_replay_cases
+    import os
+    z = np.load(os.path.join(GOLD, 'g6_gen_mask.npz'))
+    _, batch = g6_replay_cases()
+    out, lm = _replay(ops, batch)
+    assert np.array_equal(out, z['batch_enc'].astype(np.int64))
+    assert np.array_equal(lm.astype(np.uint8), z['batch_loss_mask'])
+    tgt16 = ops.ids_to_i16(torch.from_numpy(z['batch'].astype(np.int64)).cuda())
+    dec16 = torch.empty_like(tgt16)
+    ops.shift_right(tgt16, torch.tensor(PAD + 2, dtype=torch.int16, device='cuda'), dec16, 3, 64)
+    assert np.array_equal(dec16.cpu().numpy(), z['batch_dec'])
+    assert np.array_equal((out[:, :, 0] != 256).astype(np.float32), z['batch_emask'])
+    assert np.array_equal((dec16[:, :, 0] != 256).float().cpu().numpy(), z['batch_dmask'])
+
+
+def test_philox_and_replay_share_the_apply_stage(ops, batch):
+    """Decisions read back from a Philox run (what was deleted / masked / where rows went) and replayed give the identical output:
+    the two DECIDE sources feed one APPLY stage."""
+    ids = batch.numpy()
+    B, S = ids.shape[:2]
+    out1, lm1, _ = _run(ops, batch, 1, 5)
+    cases = []
+    for b in range(B):
+        # recover the deleted flags of the Philox run: greedy subsequence match, ambiguous only among identical neighbouring rows
+        k = int(S * 0.15); kept = out1[b, :S - k]; j = 0; dec = np.zeros(S, dtype=np.int32)
+        for i in range(S):
+            if j < S - k and (ids[b, i] == kept[j]).all():
+                j += 1
+            else:
+                dec[i] = 1
+        cases.append(dict(ids=ids[b], choice=1, dec=dec, rand_rows=None))
+    out2, lm2 = _replay(ops, cases)
+    assert np.array_equal(out1, out2)
+    out5, lm5, _ = _run(ops, batch, 5, 13)
+    cases = [dict(ids=ids[b], choice=5, dec=np.array([[r for r in range(S) if (np.roll(ids[b], -r, axis=0) == out5[b]).all()][0]], dtype=np.int32),
+                  rand_rows=None) for b in range(B)]
+    out6, lm6 = _replay(ops, cases)
+    assert np.array_equal(out5, out6) and np.array_equal(lm5, lm6)

@@ -163,3 +163,14 @@ def test_hf_adamw_formula():
     exp = torch.tensor([1.0, -2.0]) - upd
     exp = exp - 0.1 * 0.01 * exp
     assert torch.allclose(p, exp, atol=1e-7)
+
+
+def test_g6_decision_trace_carries_all_randomness():
+    """The decisions recorded by the oracle (the replay input of pb_corrupt_replay) + the deterministic APPLY stage reproduce the
+    reference's gen_mask outputs for all 25 golden cases and the golden batch."""
+    from tests.golden_util import apply_decisions_numpy, g6_replay_cases
+    single, batch = g6_replay_cases()
+    assert sorted(set(c['choice'] for c in single)) == [1, 2, 3, 4, 5] and len(single) == 25 and len(batch) == 3
+    for c in single + batch:
+        out, lm = apply_decisions_numpy(c)
+        assert np.array_equal(out, c['masked']) and np.array_equal(lm, c['pos']), c['choice']
