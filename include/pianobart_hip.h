@@ -163,6 +163,9 @@ int pb_adamw_step(float* p, const float* g, float* m, float* v, void* shadow /*b
 int pb_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int pb_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 int pb_fill_f32(float* dst, float value, int64_t n, void* stream);
+/* dst[i] = bf16(sum_r f32(src[r*n + i])), r < rows; n % 8 == 0: the f32 accumulation of the bf16 gradient chunks a rank owns in the
+ * data-parallel exchange (pianobart_amd/parallel.py; replaces the logits gather + gradient reduce of nn.DataParallel, pretrain.py:63-65) */
+int pb_sum_rows_bf16(const void* src, void* dst, int32_t rows, int64_t n, void* stream);
 
 /* ---- device-side corruption for the pre-train step (distributional counterpart of gen_mask's
  * TokenMask n=0 branch, pretrain.py:276-295) and decoder shift-right (pretrain.py:132-139) ---------*/

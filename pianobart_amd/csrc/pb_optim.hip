@@ -94,6 +94,23 @@ __global__ __launch_bounds__(OPT_THREADS) void fill_kernel(float* __restrict__ d
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) dst[i] = v;
 }
 
+// dst[i] = bf16( sum_r f32(src[r][i]) ): the owner's f32 accumulation of the bf16 gradient chunks its peers sent (parallel.py)
+__global__ __launch_bounds__(OPT_THREADS) void sum_rows_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, long n) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n8; i += (long)gridDim.x * OPT_THREADS) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * n + 8 * i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
+        *reinterpret_cast<bf16x8*>(dst + 8 * i) = o;
+    }
+}
+
 int opt_grid(long n4) { return (int)std::max(1L, std::min((long)OPT_BLOCKS, (n4 + OPT_THREADS - 1) / OPT_THREADS)); }
 
 }  // namespace
@@ -188,6 +205,15 @@ extern "C" int pb_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void*
 extern "C" int pb_fill_f32(float* dst, float value, int64_t n, void* stream_) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(fill_kernel, dim3(opt_grid(n >> 2)), dim3(OPT_THREADS), 0, (hipStream_t)stream_, dst, value, (long)n);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pb_sum_rows_bf16(const void* src, void* dst, int32_t rows, int64_t n, void* stream_) {
+    PB_REQUIRE(rows >= 1 && n >= 0 && n % 8 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0),
+               "pb_sum_rows_bf16: n must be a multiple of 8 and the buffers 16-byte aligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sum_rows_bf16_kernel, dim3(opt_grid(n >> 3)), dim3(OPT_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)src, (bf16_t*)dst,
+                       rows, (long)n);
     PB_LAUNCH_CHECK();
     return 0;
 }

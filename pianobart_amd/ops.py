@@ -185,6 +185,10 @@ def cast_bf16_to_f32(src, dst):
     LIB.call('pb_cast_bf16_to_f32', _p(src), _p(dst), src.numel(), _stream())
 
 
+def sum_rows_bf16(src, dst, rows):
+    LIB.call('pb_sum_rows_bf16', _p(src), _p(dst), rows, dst.numel(), _stream())
+
+
 def fill_f32(dst, value):
     LIB.call('pb_fill_f32', _p(dst), value, dst.numel(), _stream())
 

@@ -20,6 +20,14 @@ class _FakeEngine:
         self.grad_hook = None
 
 
+class _TorchXfer:
+    """Stand-in for the three elementwise HIP kernels of the bf16 exchange (cast, f32 row sum, cast back): there is no CPU product
+    path, and what this test is about is the exchange scheme around them."""
+    to_bf16 = staticmethod(lambda src, dst: dst.copy_(src.to(torch.bfloat16)))
+    sum_rows = staticmethod(lambda src, dst, rows: dst.copy_(src.view(rows, -1).float().sum(0).to(torch.bfloat16)))
+    to_f32 = staticmethod(lambda src, dst: dst.copy_(src.float()))
+
+
 def _worker(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -27,14 +35,29 @@ def _worker(rank, world, port, q):
     try:
         from pianobart_amd.parallel import GradReducer
         # ---- (1) bucket hook
+        # ---- (0) bf16 exchange: all-to-all of bf16 chunks, f32 accumulation at the owner, all-gather; ragged bucket sizes
         eng = _FakeEngine(1000)
-        red = GradReducer(eng, world)
+        red = GradReducer(eng, world, mode='bf16', xfer=_TorchXfer)
+        base = torch.linspace(-3.0, 7.0, 1000) ** 3
+        eng.G32[:] = base * (rank + 1) * 1.01
+        eng.grad_hook(600, 1000); eng.grad_hook(0, 597); eng.grad_hook(597, 600)
+        got_ranges = list(red.ranges)
+        red.all_reduce_grads()
+        bf = lambda t: t.to(torch.bfloat16).float()
+        want = bf(bf(base * 1.01) + bf(base * 2.02))
+        ok0 = torch.equal(eng.G32, want) and got_ranges == [(600, 1000), (0, 597), (597, 600)] and red.ranges == []
+        both = [torch.empty_like(eng.G32) for _ in range(world)]
+        dist.all_gather(both, eng.G32)
+        ok0 = ok0 and torch.equal(both[0], both[1])                       # every rank holds bit-identical gradients
+        ok0 = ok0 and float((want - base * 3.03).abs().max() / (base * 3.03).abs().max()) < 8e-3
+        eng = _FakeEngine(1000)
+        red = GradReducer(eng, world, mode='f32')
         eng.G32[:] = torch.arange(1000, dtype=torch.float32) * (rank + 1)
         eng.grad_hook(600, 1000)
         eng.grad_hook(0, 600)
         eng.grad_hook(5, 5)               # empty bucket is ignored
         red.all_reduce_grads()
-        ok1 = torch.allclose(eng.G32, torch.arange(1000, dtype=torch.float32) * 3) and red.pending == []
+        ok1 = ok0 and torch.allclose(eng.G32, torch.arange(1000, dtype=torch.float32) * 3) and red.pending == []
         counts = torch.tensor([1.0 + rank] * 8)
         red.reduce_counts(counts)
         ok1 = ok1 and torch.allclose(counts, torch.full((8,), 3.0))

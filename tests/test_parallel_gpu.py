@@ -1,0 +1,108 @@
+"""GPU, world size 1 over RCCL: the data-parallel step as the engine really issues it (the 8-GPU node is the driver's).
+
+With the GradReducer installed the engine (a) announces flat gradient ranges as their kernels are enqueued -- they must tile
+[0, n_total) exactly once -- (b) launches its backward GEMMs as ordinary grids instead of persistent ones, and (c) hands every
+bucket to the exchange from the stream that produced it. At world size 1 the exchange is the identity (f32 mode) or one bf16
+rounding (bf16 mode), so the step must reproduce the plain step bit for bit / to bf16 rounding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load_vocab, randomize_params, synth_octuple_batch
+
+pytestmark = pytest.mark.gpu
+E2W, W2E = load_vocab()
+
+
+@pytest.fixture(scope='module')
+def pg():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.distributed as dist
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(29600 + os.getpid() % 300)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _engine(precision):
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    cfg = BartConfig(max_position_embeddings=256, d_model=256, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+                     encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.1)
+    m = PianoBartLM(PianoBart(cfg, E2W, W2E, precision=precision))
+    randomize_params(m, 31)
+    m = m.train().cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    return m, eng
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_reducer_step_equals_plain_step_and_ranges_tile_the_buffer(pg, precision, mode):
+    from pianobart_amd import ops
+    from pianobart_amd.parallel import GradReducer
+    m, eng = _engine(precision)
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(4, 256, seed=3)]
+    args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+    plain = []
+    for it in range(2):
+        eng._seed = 500 + it
+        s = eng.loss_and_grads(*args, train=True)
+        torch.cuda.synchronize()
+        plain.append((eng.G32.clone(), s.clone()))
+    red = GradReducer(eng, 1, mode=mode)
+    seen = []
+    inner = red._on_ready
+    eng.grad_hook = lambda lo, hi: (seen.append((lo, hi)), inner(lo, hi))[1]
+    try:
+        for it in range(2):
+            seen.clear()
+            eng._seed = 500 + it
+            s = eng.loss_and_grads(*args, train=True, count_hook=red.reduce_counts)
+            red.all_reduce_grads()
+            torch.cuda.synchronize()
+            # (a) every flat gradient element is announced exactly once
+            cover = np.zeros(eng.n_total, dtype=np.int32)
+            for lo, hi in seen:
+                assert 0 <= lo <= hi <= eng.n_total
+                cover[lo:hi] += 1
+            assert (cover == 1).all(), 'gradient ranges announced %s times' % sorted(set(cover.tolist()))
+            g0, s0 = plain[it]
+            assert torch.equal(s0, s)
+            if mode == 'f32':
+                # (b)+(c): ordinary grids + exchange from the producing stream give the plain step's gradients, bit for bit
+                atomic = ('emb', 'lin.w', 'enc.pos', 'dec.pos') if precision == 'fp32' else ()       # f32 route: atomics, order varies
+                for name, sl in eng.slots.items():
+                    a, b = g0[sl.off:sl.off + sl.numel], eng.G32[sl.off:sl.off + sl.numel]
+                    if name in atomic:
+                        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), name
+                    else:
+                        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+            else:
+                # one bf16 rounding of the input, an f32 sum of one term, one more (idempotent) rounding
+                want = g0.to(torch.bfloat16).float()
+                if precision == 'bf16':
+                    assert torch.equal(want, eng.G32), float((want - eng.G32).abs().max())
+                else:
+                    assert float((want - eng.G32).abs().max() / want.abs().max()) < 1e-5
+    finally:
+        eng.grad_hook = None
+
+
+def test_sum_rows_bf16_kernel(pg):
+    from pianobart_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(2)
+    for rows, n in ((8, 4096), (2, 8), (5, 100000)):
+        src = torch.randn(rows, n, device='cuda', generator=g).to(torch.bfloat16)
+        dst = torch.empty(n, device='cuda', dtype=torch.bfloat16)
+        ops.sum_rows_bf16(src, dst, rows)
+        acc = torch.zeros(n, device='cuda')
+        for r in range(rows):
+            acc += src[r].float()
+        assert torch.equal(dst, acc.to(torch.bfloat16))
