@@ -172,11 +172,26 @@ template <int NB> struct FaCfg {
     static constexpr int KT = NB == 1 ? 2 : 1;            // key tiles (16 keys) per wave in the dK/dV kernel
 };
 
+// scale a bf16x8 fragment by c (operand prescale: S = (c K) Q^T comes out of the MFMA in log2 units)
+__device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float c) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((float)v[e] * c);
+    return r;
+}
+
 // ================================================================== forward: block = 128 queries
 // LDS: ring of {K tile, V tile} | key bias (0 / -inf) of every key this block visits | one "has a masked key" word per tile.
 // Pipeline: the DMA of tile it+NS-1 is issued at the top of tile it and waited for, with a counted vmcnt, at the bottom of
 // tile it+NS-2 in front of a raw s_barrier; nothing in the loop drains it (no ordinary global load, no __syncthreads(), no
 // ds_read_tr builtin). V's transposed fragments are requested before the softmax and collected after.
+// Softmax with a LAZY reference maximum: Q is prescaled by scale * log2(e) and each query's current reference m_ref rides into
+// the S chains as their INITIAL ACCUMULATOR, so the MFMAs deliver s' = s - m_ref and the common tile costs one v_exp_f32 per
+// score -- no subtraction, no cross-lane maximum, no rescale of O. The reference only moves when a tile holds a score more than
+// LAZY_THR (log2 units) above it, or the row has none yet; then, and on masked / causal-diagonal tiles, the exact path runs
+// (true row maximum, alpha rescale of O and l, new reference). p <= 2^LAZY_THR is harmless: bf16 has f32's exponent range and l
+// is summed from the same bf16 p the PV product sees.
+constexpr float LAZY_THR = 8.0f;
 template <int HD>
 __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     constexpr int NB = (HD + 63) / 64, KS = HD / 32, DT = HD / 16, HDT = HD;
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     for (int qt = 0; qt < 2; ++qt) {
         myq[qt] = q0 + wave * 32 + qt * 16 + lr;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8);
+        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = scale_frag(frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8), c);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[0][ks]), "+v"(qf[1][ks]));   // ordinary loads are done before the first DMA
@@ -219,7 +234,8 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int i = 0; i < DT; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m[2] = {-INFINITY, -INFINITY};
+    float m[2] = {-INFINITY, -INFINITY};                 // reference maximum of the row in log2 units (-inf: no visible key seen yet)
+    f32x4 cinit[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // -m (0 while m = -inf): initial accumulator of the S chains
     // row sums ride on the MFMA pipe: l^T += 1 P^T with an all-ones A operand gives sum_k p[q][k] (of the bf16 p the PV product
     // sees) in every register of the accumulator -- 4 MFMAs per tile instead of 32 v_add + 2 cross-row reductions per lane
     f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qt = 0; qt < 2; ++qt) s[qt][kt] = cinit[qt];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -270,31 +286,34 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) if (dt < DT) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * C::STB));
         bf16x8 pf[2][2];
-        // Online softmax of the tile: the common tile -- no masked key, not on the causal diagonal -- takes a path without
-        // bias add, compare and select: max on the raw scores, then exp2(fma(s, c, -max)).
-        auto softmax_tile = [&](auto tag) {
+        auto finish_row = [&](int qt) {                                   // p -> bf16 operand; row sums on the MFMA pipe
+            pf[qt][0] = pack_pair(s[qt][0], s[qt][1]);
+            pf[qt][1] = pack_pair(s[qt][2], s[qt][3]);
+            lacc[qt] = MFMA16(ones, pf[qt][1], MFMA16(ones, pf[qt][0], lacc[qt]));
+        };
+        float resc[2] = {1.f, 1.f};                                       // rescale of O, applied behind the paths' merge point (in place)
+        // exact path: s' + m_ref (+ key bias, causal compare) -> true row maximum -> rescale -> new reference
+        auto exact_tile = [&](auto tag) {
             constexpr bool MASKED = decltype(tag)::value;
+            asm volatile("; exact softmax path" ::: "memory");          // keeps hipcc from speculating this (rare) path into the common one
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
+                const float mold = m[qt] == -INFINITY ? 0.f : m[qt];      // what the chains subtracted
                 float mx = -INFINITY;
-                if constexpr (MASKED) {
 #pragma unroll
-                    for (int kt = 0; kt < 4; ++kt) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
+                for (int kt = 0; kt < 4; ++kt) {
+                    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (MASKED) bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float x = fmaf(s[qt][kt][r], c, bias[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        float x = s[qt][kt][r] + mold;
+                        if constexpr (MASKED) {
+                            x += bias[r];
                             if (diag && (k0 + kt * 16 + g * 4 + r) > myq[qt]) x = -INFINITY;
-                            s[qt][kt][r] = x;
-                            mx = fmaxf(mx, x);
                         }
+                        s[qt][kt][r] = x;
+                        mx = fmaxf(mx, x);
                     }
-                } else {
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
-                    mx *= c;                                              // c > 0: scaling commutes with the max
                 }
                 mx = grp_max(mx);
                 const float mnew = fmaxf(m[qt], mx);
@@ -303,18 +322,44 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        s[qt][kt][r] = MASKED ? __builtin_amdgcn_exp2f(s[qt][kt][r] - muse) : __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], c, -muse));
+                    for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r] - muse);
                 lacc[qt] *= alpha;
                 m[qt] = mnew;
-#pragma unroll
-                for (int i = 0; i < DT; ++i) oacc[qt][i] *= alpha;    // (skipping this when no row moved its maximum costs more in copies than it saves)
-                pf[qt][0] = pack_pair(s[qt][0], s[qt][1]);
-                pf[qt][1] = pack_pair(s[qt][2], s[qt][3]);
-                lacc[qt] = MFMA16(ones, pf[qt][1], MFMA16(ones, pf[qt][0], lacc[qt]));
+                cinit[qt] = f32x4{-muse, -muse, -muse, -muse};
+                resc[qt] = alpha;
+                finish_row(qt);
             }
         };
-        if (masked) softmax_tile(BoolTag<true>{}); else softmax_tile(BoolTag<false>{});
+        bool exact = masked;
+        if (masked) {
+            exact_tile(BoolTag<true>{});
+        } else {
+            // lazy path: does any score of the tile sit more than LAZY_THR above its row's reference (or has a row no reference)?
+            float t0 = m[0] == -INFINITY ? INFINITY : -INFINITY, t1 = m[1] == -INFINITY ? INFINITY : -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { t0 = fmaxf(t0, s[0][kt][r]); t1 = fmaxf(t1, s[1][kt][r]); }
+            if (__builtin_amdgcn_ballot_w64(fmaxf(t0, t1) > LAZY_THR) == 0ull) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+                    finish_row(qt);
+                }
+            } else {
+                exact = true;
+                exact_tile(BoolTag<false>{});
+            }
+        }
+        if (exact) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int i = 0; i < DT; ++i) oacc[qt][i] *= resc[qt];
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             if (nb > 0) {                                                 // next V image into the same registers (the compiler keeps the anti-dependence)
@@ -344,17 +389,9 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
                 bf16x4 r = {(bf16_t)(oacc[qt][dt][0] * inv), (bf16_t)(oacc[qt][dt][1] * inv), (bf16_t)(oacc[qt][dt][2] * inv), (bf16_t)(oacc[qt][dt][3] * inv)};
                 *reinterpret_cast<bf16x4*>(O + dt * 16 + g * 4) = r;
             }
-            if (g == 0) p.lse[((long)b * p.H + h) * p.Sq + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;
+            if (g == 0) p.lse[((long)b * p.H + h) * p.Sq + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;   // m = the reference l was summed against
         }
     }
-}
-
-// scale a bf16x8 fragment by c (operand prescale: S = (c K) Q^T comes out of the MFMA in log2 units)
-__device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float c) {
-    bf16x8 r;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((float)v[e] * c);
-    return r;
 }
 
 // ================================================================== backward dK, dV: block = 64 KT keys

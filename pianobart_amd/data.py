@@ -1,7 +1,12 @@
 """Input side of the pre-train path: the reference stores `(N, 1024, 8)` Octuple arrays as int64 `.npy`
-(Data/data_generation/convert.py:560-565) and wraps them row by row in `torch.tensor` (dataset.py:4-16). All Octuple ids are
-< 262, so the same data as memory-mapped int16 shards is 4x smaller, needs no parsing and is exactly what the kernels read
-(one 16-byte row per token). `MidiDataset` keeps the reference's name and semantics; int16 rows go to the device as they are."""
+(Data/data_generation/convert.py:560-565), concatenates and shuffles them in memory (pretrain.py:548-576) and wraps them row by
+row in `torch.tensor` (dataset.py:4-16). All Octuple ids are < 262, so the same data as int16 is 4x smaller and is exactly what
+the kernels read (one 16-byte row per token).
+
+`OctupleShards` keeps every `.npy` file memory-mapped where it lies and addresses sequences through ONE index array: the
+reference's concatenate / shuffle / 85-15 split become operations on that index (no copy of the data), and a sample is
+materialised as an int16 tensor only when a batch asks for it. `MidiDataset` keeps the reference's name and semantics
+(an array or a path), returning int16 rows. `convert_to_int16` rewrites a reference file as an int16 shard (checked lossless)."""
 import os
 
 import numpy as np
@@ -18,14 +23,68 @@ def convert_to_int16(src_npy, dst_npy):
     return b.shape
 
 
+def _open(path):
+    """Memory-map a plain integer .npy (an `<name>.i16.npy` sibling written by convert_to_int16 is preferred); object arrays (which
+    cannot be mapped) are loaded."""
+    i16 = path[:-4] + '.i16.npy'
+    if os.path.exists(i16):
+        path = i16
+    try:
+        return np.load(path, mmap_mode='r')
+    except ValueError:
+        return np.asarray(np.load(path, allow_pickle=True).tolist(), dtype=np.int64)
+
+
+def _row_i16(a, i):
+    row = np.asarray(a[i])
+    if row.dtype != np.int16:
+        r16 = row.astype(np.int16)
+        if not np.array_equal(r16, row):
+            raise ValueError('Octuple id outside the int16 range')
+        row = r16
+    return torch.from_numpy(np.ascontiguousarray(row))
+
+
+class OctupleShards(torch.utils.data.Dataset):
+    """Sequences of several (N_k, S, 8) arrays addressed through one index: element j is global row index[j] of the virtual
+    concatenation. `subset(idx)` shares the arrays."""
+
+    def __init__(self, arrays, index=None):
+        self.arrays = list(arrays)
+        self.starts = np.cumsum([0] + [len(a) for a in self.arrays])
+        self.index = np.arange(self.starts[-1]) if index is None else np.asarray(index)
+
+    @classmethod
+    def from_files(cls, paths):
+        return cls([_open(p) for p in paths])
+
+    def subset(self, idx):
+        return OctupleShards(self.arrays, self.index[np.asarray(idx)])
+
+    def __len__(self):
+        return len(self.index)
+
+    @property
+    def shape(self):
+        return (len(self),) + tuple(self.arrays[0].shape[1:])
+
+    def __getitem__(self, j):
+        g = int(self.index[j])
+        k = int(np.searchsorted(self.starts, g, side='right')) - 1
+        return _row_i16(self.arrays[k], g - int(self.starts[k]))
+
+
 class MidiDataset(torch.utils.data.Dataset):
-    """dataset.py:4-16. `X` may be an in-memory array or the path of an .npy shard (opened memory-mapped)."""
+    """dataset.py:4-16. `X` may be an in-memory array, an OctupleShards view, or the path of an .npy shard (opened memory-mapped).
+    Items are int16 (S, 8) tensors."""
 
     def __init__(self, X):
-        self.data = np.load(X, mmap_mode='r') if isinstance(X, (str, os.PathLike)) else X
+        self.data = _open(X) if isinstance(X, (str, os.PathLike)) else X
 
     def __len__(self):
         return len(self.data)
 
     def __getitem__(self, index):
-        return torch.from_numpy(np.ascontiguousarray(self.data[index]))
+        if isinstance(self.data, OctupleShards):
+            return self.data[index]
+        return _row_i16(self.data, index)

@@ -62,7 +62,8 @@ class Engine:
         self._ws_cache = {}
         self._saved = None
         self._fwd_token = 0
-        self._seed = 0x5EED1234
+        # dropout stream: one LCG walk per process, keyed by the rank (data-parallel replicas must not share dropout masks)
+        self._seed = (0x5EED1234 + 0x9E3779B97F4A7C15 * int(os.environ.get('RANK', 0))) & 0xFFFFFFFFFFFFFFFF
         self.step_count = 0
         self.opt_m = self.opt_v = None
         self._versions = None

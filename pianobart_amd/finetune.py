@@ -82,10 +82,13 @@ def load_data_finetune(dataset, task, data_root=None):
 
 class HeadAdamW:
     """HF AdamW (eps added before the bias correction, decay after the update: SURVEY 8a-11) over the head parameters, which are
-    re-homed as views of one flat f32 buffer so that a step is one pb_adamw_step launch."""
+    re-homed as views of one flat f32 buffer so that a step is one pb_adamw_step launch per run of neighbouring parameters.
+    Like transformers.AdamW (`if p.grad is None: continue`) a parameter without a gradient is left alone -- no update, no weight
+    decay, its own step count does not advance; parameters in `never` (BART's dead `shared` table) are not re-homed at all."""
 
-    def __init__(self, params, lr, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6):
-        self.params = [p for p in params]
+    def __init__(self, params, lr, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6, never=()):
+        skip = {id(p) for p in never}
+        self.params = [p for p in params if id(p) not in skip]
         dev = self.params[0].device
         n = sum((p.numel() + 3) // 4 * 4 for p in self.params)
         self.P, self.G = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
@@ -95,18 +98,26 @@ class HeadAdamW:
             v = self.P[o:o + p.numel()].view_as(p)
             v.copy_(p.data)
             p.data = v
-            self.views.append((o, p.numel()))
+            self.views.append((o, (p.numel() + 3) // 4 * 4))
             o += (p.numel() + 3) // 4 * 4
+        self.steps = [0] * len(self.params)                                # per-parameter step counts, as in the HF optimizer state
         self.lr, self.wd, self.betas, self.eps, self.t = lr, weight_decay, betas, eps, 0
 
     def step(self):
         self.t += 1
-        for p, (o, n) in zip(self.params, self.views):
+        runs = []                                                          # (offset, length, step): neighbours with a gradient and equal step count
+        for i, (p, (o, n)) in enumerate(zip(self.params, self.views)):
             if p.grad is None:
-                self.G[o:o + n].zero_()
+                continue
+            self.G[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            self.steps[i] += 1
+            if runs and runs[-1][0] + runs[-1][1] == o and runs[-1][2] == self.steps[i]:
+                runs[-1] = (runs[-1][0], runs[-1][1] + n, self.steps[i])
             else:
-                self.G[o:o + n].copy_(p.grad.reshape(-1))
-        ops.adamw_step(self.P, self.G, self.m, self.v, None, None, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t)
+                runs.append((o, n, self.steps[i]))
+        for o, n, t in runs:
+            ops.adamw_step(self.P[o:o + n], self.G[o:o + n], self.m[o:o + n], self.v[o:o + n], None, None, self.lr, self.betas[0],
+                           self.betas[1], self.eps, self.wd, t)
 
     def zero_grad(self):
         for p in self.params:
@@ -134,7 +145,8 @@ class FinetuneTrainer:
         self.engine.bind(self.device)
         self.train_data, self.valid_data, self.test_data = train_dataloader, valid_dataloader, test_dataloader
         in_engine = {id(p) for p in self.engine.params}              # everything else (heads, swapped decoder label embedding) is stepped here
-        self.head_optim = HeadAdamW([p for p in self.model.parameters() if id(p) not in in_engine], lr=lr, weight_decay=0.01)
+        self.head_optim = HeadAdamW([p for p in self.model.parameters() if id(p) not in in_engine], lr=lr, weight_decay=0.01,
+                                    never=[pianobart.bart.shared.weight])      # never read, never a gradient (SURVEY a-3)
         self.lr = lr
         self.testset_shape = testset_shape if not error else testset_shape[:-1]
         self.error = error
@@ -248,7 +260,7 @@ def finetune(argv=None):
     print('Loading Dictionary')
     with open(args.dict_file, 'rb') as f:
         e2w, w2e = pickle.load(f)
-    print('\\nLoading Dataset')
+    print('\nLoading Dataset')
     seq_class = args.task in ('composer', 'emotion')
     X_train, X_val, X_test, y_train, y_val, y_test = load_data_finetune(args.dataset, args.task, args.dataroot)
     mk = lambda X, y, sh: DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=sh)
@@ -256,7 +268,7 @@ def finetune(argv=None):
     print('   len of train_loader', len(train_loader))
     print('   len of valid_loader', len(valid_loader))
     print('   len of valid_loader', len(test_loader))
-    print('\\nBuilding BART model')
+    print('\nBuilding BART model')
     configuration = BartConfig(max_position_embeddings=args.max_seq_len, d_model=args.hs, encoder_layers=args.layers, encoder_ffn_dim=args.ffn_dims,
                                encoder_attention_heads=args.heads, decoder_layers=args.layers, decoder_ffn_dim=args.ffn_dims,
                                decoder_attention_heads=args.heads)
@@ -266,17 +278,17 @@ def finetune(argv=None):
         best_mdl = args.ckpt
         print('   Loading pre-trained model from', best_mdl.split('/')[-1])
         pianobart.load_state_dict(torch.load(best_mdl, map_location='cpu')['state_dict'])
-    print('\\nCreating Finetune Trainer')
+    print('\nCreating Finetune Trainer')
     trainer = FinetuneTrainer(pianobart, train_loader, valid_loader, test_loader, args.lr, args.class_num, args.hs, y_test.shape, args.cpu,
                               args.cuda_devices[:1], None, seq_class, args.error_correction, args.weight)
-    print('\\nTraining Start')
+    print('\nTraining Start')
     save_dir = os.path.join('result/finetune/', args.task + '_' + args.name)
     os.makedirs(save_dir, exist_ok=True)
     filename = os.path.join(save_dir, 'model.ckpt')
     print('   save model at {}'.format(filename))
     best_acc, best_epoch, bad_cnt = 0, 0, 0
     with open(os.path.join(save_dir, 'log'), 'a') as outfile:
-        outfile.write('Loading pre-trained model from ' + best_mdl.split('/')[-1] + '\\n')
+        outfile.write('Loading pre-trained model from ' + best_mdl.split('/')[-1] + '\n')
         for epoch in range(args.epochs):
             train_loss, train_acc = trainer.train()
             valid_loss, valid_acc = trainer.valid()
@@ -290,7 +302,7 @@ def finetune(argv=None):
             print('epoch: {}/{} | Train Loss: {} | Train acc: {} | Valid Loss: {} | Valid acc: {} | Test loss: {} | Test acc: {}'.format(
                 epoch + 1, args.epochs, train_loss, train_acc, valid_loss, valid_acc, test_loss, test_acc))
             trainer.save_checkpoint(epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename)
-            outfile.write('Epoch {}: train_loss={}, valid_loss={}, test_loss={}, train_acc={}, valid_acc={}, test_acc={}\\n'.format(
+            outfile.write('Epoch {}: train_loss={}, valid_loss={}, test_loss={}, train_acc={}, valid_acc={}, test_acc={}\n'.format(
                 epoch + 1, train_loss, valid_loss, test_loss, train_acc, valid_acc, test_acc))
             if bad_cnt > 3:
                 print('valid acc not improving for 3 epochs')

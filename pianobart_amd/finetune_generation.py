@@ -7,8 +7,11 @@ Same forward/backward as the pre-train step with a different mask and weights:
     times len(e2w[etype]) in dict order, divided by sum(n_tok) (finetune_generation.py:236-250);
   * accuracy over the same mask (finetune_generation.py:188-193); argmax ids collected in test mode.
 The shape-similarity "FAD" metrics (finetune_generation.py:185-223) need the third-party `shapesimilarity` package, which is
-not installed in this image: they are reported as 0.0 (host-side metric, outside the hot path).
+not installed in this image (a host-side metric, outside the hot path): they are reported as `n/a` / None, never as a number.
+`get_args_generation` and `finetune_generation()` are the counterparts of finetune_generation.py:15-55 and main.py:214-321.
 """
+import argparse
+import os
 import shutil
 import sys
 
@@ -20,6 +23,43 @@ from ._lib import PBError
 from .model import PianoBartLM
 
 HEAD_WEIGHT = [1.0, 1.0, 0.3, 1.5, 1.0, 1.0, 0.3, 0.3]          # finetune_generation.py:241-248 (index = head i)
+
+
+def get_args_generation(argv=None):
+    """finetune_generation.py:15-55, flag for flag (+ --precision, absent from the reference)."""
+    parser = argparse.ArgumentParser(description='')
+    parser.add_argument("--datasets", type=str, default='maestro')
+    parser.add_argument('--dict_file', type=str, default='./Data/Octuple.pkl')
+    parser.add_argument('--name', type=str, default='pianobart')
+    parser.add_argument('--ckpt', default='result/pretrain/pianobart/model_best.ckpt')
+    parser.add_argument('--num_workers', type=int, default=5)
+    parser.add_argument('--batch_size', type=int, default=8)
+    parser.add_argument('--max_seq_len', type=int, default=1024, help='all sequences are padded to `max_seq_len`')
+    parser.add_argument('--hs', type=int, default=1024)
+    parser.add_argument('--layers', type=int, default=8)
+    parser.add_argument('--ffn_dims', type=int, default=2048)
+    parser.add_argument('--heads', type=int, default=8)
+    parser.add_argument('--epochs', type=int, default=500, help='number of training epochs')
+    parser.add_argument('--lr', type=float, default=2e-6, help='initial learning rate')
+    parser.add_argument('--nopretrain', action="store_true")
+    parser.add_argument('--dataroot', type=str, default=None, help='path to dataset')
+    parser.add_argument("--cpu", action="store_true")
+    parser.add_argument("--cuda_devices", type=int, nargs='+', default=[0], help="HIP device ids (one per process)")
+    parser.add_argument("--eval", action="store_true")
+    parser.add_argument('--precision', choices=['bf16', 'fp32'], default='bf16', help='backbone arithmetic (not in the reference)')
+    return parser.parse_args(argv)
+
+
+def load_data_generation(dataset, data_root=None):
+    """finetune.py:259-330, task "gen": <root>/<dataset>_{train,valid,test}.npy and ..._ans.npy (prompt / continuation pairs)."""
+    if data_root is None:
+        data_root = 'Data/finetune/gen'
+    ld = lambda name: np.load(os.path.join(data_root, name), allow_pickle=True)
+    X = [ld(f'{dataset}_{part}.npy') for part in ('train', 'valid', 'test')]
+    y = [ld(f'{dataset}_{part}_ans.npy') for part in ('train', 'valid', 'test')]
+    print('X_train: {}, X_valid: {}, X_test: {}'.format(*[a.shape for a in X]))
+    print('y_train: {}, y_valid: {}, y_test: {}'.format(*[a.shape for a in y]))
+    return X[0], X[1], X[2], y[0], y[1], y[2]
 
 
 class GenerationTrainer:
@@ -37,6 +77,14 @@ class GenerationTrainer:
         self.train_data, self.valid_data, self.test_data = train_dataloader, valid_dataloader, test_dataloader
         self.testset_shape = testset_shape
         self.lr = lr
+        self.world = int(os.environ.get('WORLD_SIZE', 1))
+        self.reducer = None
+        if self.world > 1:                                                   # one process per GPU, same exchange as the pre-train step
+            import torch.distributed as dist
+            from .parallel import GradReducer
+            if not dist.is_initialized():
+                dist.init_process_group('nccl', device_id=self.device)
+            self.reducer = GradReducer(self.engine, self.world)
         n_tok = np.array([len(pianobart.e2w[k]) for k in pianobart.e2w], dtype=np.float64)       # dict order, as the reference
         w = np.array(HEAD_WEIGHT) * n_tok
         self._hw = torch.tensor(w, dtype=torch.float32, device=self.device)
@@ -68,9 +116,13 @@ class GenerationTrainer:
             loss_mask = attn_dec[:, :, None].expand(B, S, 8).contiguous()
             am = torch.empty(B * S, 8, dtype=torch.int16, device=self.device) if mode == 2 else None
             sums = eng.loss_and_grads(x16, x16, y16, loss_mask, attn_enc, attn_dec, train=(mode == 0), head_w=self._hw, w_scale=self._scale,
-                                      argmax_out=am)
+                                      argmax_out=am, count_hook=self.reducer.reduce_counts if self.reducer else None)
             if mode == 0:
+                if self.reducer:
+                    self.reducer.all_reduce_grads()
                 eng.optimizer_step(lr=self.lr)
+            if self.reducer:
+                self.reducer.reduce_sums(sums)
             s = sums.double().cpu().numpy()
             losses = s[0:8] / s[8:16] * self._wnp                      # the reference logs the weighted per-head losses
             accs = s[16:24] / s[8:16]
@@ -80,11 +132,11 @@ class GenerationTrainer:
                 cnt += B
             sys.stdout.write('Loss: {:06f} | loss: {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}\n'.format(loss, *losses))
             sys.stdout.write('Acc: {:06f} | acc: {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}, {:03f}\n'.format(np.average(accs), *accs))
-            sys.stdout.write('FAD(BAR) Similarity: {:0.6f} , FAD Similarity {:0.6f} \n'.format(0.0, 0.0))
+            sys.stdout.write('FAD(BAR) Similarity: n/a , FAD Similarity n/a \n')            # `shapesimilarity` is not installed: not measured
             total_acc += accs
             total_loss += loss
         n = max(1, len(training_data))
-        out = (round(total_loss / n, 4), [round(float(a) / n, 4) for a in total_acc], 0.0, 0.0)
+        out = (round(total_loss / n, 4), [round(float(a) / n, 4) for a in total_acc], None, None)           # FAD(BAR), FAD: not measured
         return out + (all_output,) if mode == 2 else out
 
     def save_checkpoint(self, epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename):
@@ -97,3 +149,86 @@ class GenerationTrainer:
         torch.save(state, filename)
         if is_best:
             shutil.copyfile(filename, filename.split('.')[0] + '_best.ckpt')
+
+
+def finetune_generation(argv=None):
+    """The generation fine-tune driver (reference: main.py:214-321): seeds 2023, maestro-style (prompt, continuation) arrays, a
+    pre-trained PianoBart checkpoint (or a whole fine-tuned PianoBartLM with --eval), per epoch train -> valid -> test, best model by
+    the n_tokens-weighted validation accuracy, the reference's checkpoint keys and log / stdout line formats."""
+    import pickle
+    import random
+    from torch.utils.data import DataLoader
+    from .finetune import FinetuneDataset
+    from .model import BartConfig, PianoBart
+    for seed_fn in (torch.manual_seed, np.random.seed, random.seed):
+        seed_fn(2023)
+    args = get_args_generation(argv)
+    print("Loading Dictionary")
+    if args.dict_file.endswith('.json'):
+        import json
+        e2w = json.load(open(args.dict_file))['e2w']
+        w2e = {k: {v: w for w, v in d.items()} for k, d in e2w.items()}
+    else:
+        with open(args.dict_file, 'rb') as f:
+            e2w, w2e = pickle.load(f)
+    print("\nLoading Dataset")
+    X_train, X_val, X_test, y_train, y_val, y_test = load_data_generation(args.datasets, args.dataroot)
+    loaders = []
+    for X, y, shuffle, tag in ((X_train, y_train, True, 'train'), (X_val, y_val, False, 'valid'), (X_test, y_test, False, 'valid')):
+        loaders.append(DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=shuffle))
+        print("   len of %s_loader" % tag, len(loaders[-1]))
+    print("\nBuilding BART model")
+    pianobart = PianoBart(bartConfig=BartConfig(max_position_embeddings=args.max_seq_len, d_model=args.hs, encoder_layers=args.layers,
+                                                encoder_ffn_dim=args.ffn_dims, encoder_attention_heads=args.heads, decoder_layers=args.layers,
+                                                decoder_ffn_dim=args.ffn_dims, decoder_attention_heads=args.heads),
+                          e2w=e2w, w2e=w2e, precision=args.precision)
+    best_mdl, model = '', None
+    if args.eval or not args.nopretrain:
+        best_mdl = args.ckpt
+        print("   Loading pre-trained model from", best_mdl.split('/')[-1])
+        sd = torch.load(best_mdl, map_location='cpu', weights_only=False)['state_dict']
+        if args.eval:                                                          # a whole fine-tuned PianoBartLM
+            model = PianoBartLM(pianobart)
+            model.load_state_dict(sd)
+        else:
+            pianobart.load_state_dict(sd)
+    print("\nCreating Finetune Trainer")
+    trainer = GenerationTrainer(pianobart, loaders[0], loaders[1], loaders[2], args.lr, y_test.shape, args.cpu, args.cuda_devices, model)
+    print("\nTraining Start")
+    save_dir = os.path.join('result/finetune/generation_' + args.name)
+    os.makedirs(save_dir, exist_ok=True)
+    filename = os.path.join(save_dir, 'model.ckpt')
+    print("   save model at {}".format(filename))
+    rank0 = int(os.environ.get('RANK', 0)) == 0
+    best_acc, bad_cnt = 0, 0
+    log = open(os.path.join(save_dir, 'log'), 'a') if rank0 else None
+    if log:
+        log.write("Loading pre-trained model from " + best_mdl.split('/')[-1] + '\n')
+    for epoch in range(args.epochs):
+        res = {part: getattr(trainer, part)() for part in ('train', 'valid', 'test')}
+        (train_loss, train_acc, train_fb, train_f), (valid_loss, valid_acc, valid_fb, valid_f) = res['train'], res['valid']
+        test_loss, test_acc, test_fb, test_f, _ = res['test']
+        avg_acc = sum(a * n for a, n in zip(valid_acc, pianobart.n_tokens)) / sum(pianobart.n_tokens)
+        is_best = avg_acc > best_acc
+        best_acc = max(avg_acc, best_acc)
+        bad_cnt = 0 if is_best else bad_cnt + 1
+        print('epoch: {}/{} | Train Loss: {} | Train acc: {} | Train FAD: {} | Train FAD (BAR): {} | Valid Loss: {} | Valid acc: {} | Valid FAD: {} | '
+              'Valid FAD(BAR): {} | Test loss: {} | Test acc: {} | Test FAD: {} | Test FAD(BAR): {}'.format(
+                  epoch + 1, args.epochs, train_loss, train_acc, train_f, train_fb, valid_loss, valid_acc, valid_f, valid_fb, test_loss, test_acc,
+                  test_f, test_fb))
+        if log:
+            trainer.save_checkpoint(epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename)
+            log.write('Epoch {}: train_loss={}, valid_loss={}, test_loss={}, train_acc={}, valid_acc={}, test_acc={}, train_fad={}, valid_fad={}, '
+                      'test_fad={}, train_fad(bar)={}, valid_fad(bar)={}, test_fad(bar)={}\n'.format(
+                          epoch + 1, train_loss, valid_loss, test_loss, train_acc, valid_acc, test_acc, train_f, valid_f, test_f, train_fb, valid_fb, test_fb))
+            log.flush()
+        if bad_cnt > 30:
+            print('valid acc not improving for 3 epochs')
+            break
+    if log:
+        log.close()
+    return trainer
+
+
+if __name__ == '__main__':
+    finetune_generation()

@@ -293,7 +293,9 @@ class PianoBartLM(nn.Module):
         if input_ids_encoder.shape[0] != 1:
             print("ERROR")
             exit(-1)
-        return eng.generate(input_ids_encoder, encoder_attention_mask, self.sample_row)
+        out = eng.generate(input_ids_encoder, encoder_attention_mask, self.sample_row)
+        # model.py:33-36: the result lives on `cuda:device_num`, or on the CPU for device_num == -1
+        return out.cpu() if device_num == -1 else out.to(torch.device('cuda', device_num))
 
     # model.py:68-78 -- temperatures / nucleus thresholds per head
     SAMPLE_T = [1.2, 1.2, 5, 1, 2, 5, 5, 1.2]

@@ -10,7 +10,14 @@ optimizer_step), and ONE device->host copy of 24 floats per step for the log lin
 
 Multi-GPU: launch one process per GPU (torch.distributed.run); `--cuda_devices` keeps its meaning of
 "which device(s)" for a single process, but more than one id is rejected with a pointer to torchrun,
-because nn.DataParallel (pretrain.py:63-65) is exactly what this engine replaces.
+because nn.DataParallel (pretrain.py:63-65) is exactly what this engine replaces. nn.DataParallel scatters
+ONE batch of `--batch_size` samples over the GPUs; here every rank draws its `batch_size / world` share of
+the same global batch: the shuffle + 85/15 split is drawn on rank 0 and broadcast, each epoch's order is a
+permutation seeded identically on all ranks, rank r takes every world-th sample of it (DistributedSampler),
+and the corruption / dropout streams are keyed by the rank so that no two ranks draw the same decisions.
+
+Input: the `.npy` files stay memory-mapped (pianobart_amd/data.py); concatenate, shuffle and split act on an
+index, and a batch reaches the device as int16 rows (16 bytes per token) -- what the kernels read.
 """
 import argparse
 import os
@@ -24,6 +31,7 @@ import torch
 
 from . import ops
 from ._lib import PBError
+from .data import MidiDataset, OctupleShards
 from .model import BartConfig, PianoBart, PianoBartLM
 
 
@@ -53,36 +61,74 @@ def get_args_pretrain(argv=None):
     return parser.parse_args(argv)
 
 
+def _dist_env():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def _dist_init(device=None):
+    """One process per GPU: join the job's process group (RCCL on the HIP device; gloo when there is none, i.e. the CPU tests of
+    the input pipeline)."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        if device is not None and device.type == 'cuda':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group('gloo')
+    return dist
+
+
+def _broadcast_from_rank0(arr):
+    """An int64 array decided on rank 0 (shuffled index, epoch seed) becomes every rank's."""
+    rank, world = _dist_env()
+    if world == 1:
+        return arr
+    dist = _dist_init()
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(dev)
+    dist.broadcast(t, 0)
+    return t.cpu().numpy()
+
+
 def load_data_pretrain(datasets, mode, root='Data/output_pretrain'):
-    """pretrain.py:548-576: <root>/<ds>/<ds>_{train,test,valid}_split.npy -> vstack, shuffle, 85/15 split."""
+    """pretrain.py:548-576: <root>/<ds>/<ds>_{train,test,valid}_split.npy -> one pool, shuffled (global np.random, unseeded like
+    the reference; under torchrun rank 0's draw is broadcast), 85 % / 15 % split. The files stay memory-mapped: the two returned
+    objects are index views (data.OctupleShards) with the array protocol the reference's callers use (len, shape, [i])."""
     if mode != "pretrain":
         return None
-    to_concat = []
+    arrays = []
     for dataset in datasets:
-        parts = [np.load(os.path.join(root, dataset, dataset + '_%s_split.npy' % s), allow_pickle=True) for s in ('train', 'test', 'valid')]
-        data = np.concatenate(parts, axis=0)
-        print(f'   {dataset}: {data.shape}')
-        to_concat.append(data)
-    training_data = np.vstack(to_concat)
-    print('   > all training data:', training_data.shape)
-    index = np.arange(len(training_data))
+        parts = OctupleShards.from_files([os.path.join(root, dataset, dataset + '_%s_split.npy' % s) for s in ('train', 'test', 'valid')])
+        print(f'   {dataset}: {parts.shape}')
+        arrays += parts.arrays
+    pool = OctupleShards(arrays)
+    print('   > all training data:', pool.shape)
+    index = np.arange(len(pool))
     np.random.shuffle(index)
-    training_data = training_data[index]
-    split = int(len(training_data) * 0.85)
-    return training_data[:split], training_data[split:]
+    index = _broadcast_from_rank0(index)
+    split = int(len(pool) * 0.85)
+    return pool.subset(index[:split]), pool.subset(index[split:])
 
 
-class MidiDataset(torch.utils.data.Dataset):
-    """dataset.py:4-16."""
-
-    def __init__(self, X):
-        self.data = X
-
-    def __len__(self):
-        return len(self.data)
-
-    def __getitem__(self, index):
-        return torch.tensor(self.data[index])
+def make_loaders(X_train, X_val, batch_size, num_workers, seed=None):
+    """main.py:28-35. One process: the reference's two DataLoaders. Under torchrun `batch_size` stays the GLOBAL batch (what
+    nn.DataParallel scatters, pretrain.py:63-65): each rank loads batch_size / world samples per step through a
+    DistributedSampler whose per-epoch permutation is seeded identically on every rank (seed drawn on rank 0)."""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    rank, world = _dist_env()
+    if world == 1:
+        return (DataLoader(MidiDataset(X=X_train), batch_size=batch_size, num_workers=num_workers, shuffle=True),
+                DataLoader(MidiDataset(X=X_val), batch_size=batch_size, num_workers=num_workers))
+    if batch_size % world:
+        raise PBError('--batch_size %d is the global batch and must be a multiple of the %d ranks' % (batch_size, world))
+    if seed is None:
+        seed = int(_broadcast_from_rank0(np.array([np.random.randint(0, 2 ** 31 - 1)]))[0])
+    loaders = []
+    for X, shuffle in ((X_train, True), (X_val, False)):
+        ds = MidiDataset(X=X)
+        sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed)
+        loaders.append(DataLoader(ds, batch_size=batch_size // world, num_workers=num_workers, sampler=sampler))
+    return tuple(loaders)
 
 
 class Pretrainer:
@@ -117,18 +163,23 @@ class Pretrainer:
         self.quiet = False
         self.world = int(os.environ.get('WORLD_SIZE', 1))
         self.reducer = None
+        self.rank = int(os.environ.get('RANK', 0))
         if self.world > 1:
-            import torch.distributed as dist
             from .parallel import GradReducer
-            if not dist.is_initialized():
-                dist.init_process_group('nccl', device_id=self.device)
+            _dist_init(self.device)
             self.reducer = GradReducer(self.engine, self.world)
         self._w = np.array([len(pianobart.e2w[k]) for k in pianobart.e2w], dtype=np.float64)   # e2w dict order (pretrain.py:185-189)
-        self._step_seed = 0x9E3779B97F4A7C15
+        # corruption stream keyed by the rank: ranks must not draw the same positions (the dropout stream is keyed in Engine)
+        self._step_seed = (0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * self.rank) & 0xFFFFFFFFFFFFFFFF
+        self._epoch = 0
 
     # ---- reference API ------------------------------------------------------------------------------
     def train(self):
         self.model.train()
+        sampler = getattr(self.train_data, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):                     # DistributedSampler: a new, rank-consistent permutation every epoch
+            sampler.set_epoch(self._epoch)
+        self._epoch += 1
         return self.iteration(self.train_data, self.max_seq_len)
 
     def valid(self):
@@ -170,7 +221,7 @@ class Pretrainer:
     def prepare_batch(self, ori_seq_batch):
         """pretrain.py:125-153 on the device: corrupted encoder ids, shift-right decoder ids, loss mask, attention masks."""
         ori = ori_seq_batch.to(self.device, non_blocking=True)
-        tgt16 = ops.ids_to_i16(ori.long() if ori.dtype != torch.int64 else ori)
+        tgt16 = ori.contiguous() if ori.dtype == torch.int16 else ops.ids_to_i16(ori.long() if ori.dtype != torch.int64 else ori)
         B, S = tgt16.shape[:2]
         enc16, loss_mask, _ = self._corrupt(tgt16)
         dec16 = torch.empty_like(tgt16)
@@ -207,68 +258,80 @@ class Pretrainer:
         return round(total_losses / n, 3), [round(float(x) / n, 3) for x in total_acc]
 
 
-def pretrain(argv=None):
-    """main.py:17-100."""
-    import pickle
-    from torch.utils.data import DataLoader
-    args = get_args_pretrain(argv)
-    print("Loading Dictionary")
-    if args.dict_file.endswith('.json'):
+def _load_vocab(dict_file):
+    if dict_file.endswith('.json'):
         import json
-        e2w = json.load(open(args.dict_file))['e2w']
-        w2e = {k: {v: w for w, v in d.items()} for k, d in e2w.items()}
-    else:
-        with open(args.dict_file, 'rb') as f:
-            e2w, w2e = pickle.load(f)
+        e2w = json.load(open(dict_file))['e2w']
+        return e2w, {k: {v: w for w, v in d.items()} for k, d in e2w.items()}
+    import pickle
+    with open(dict_file, 'rb') as f:
+        return pickle.load(f)
+
+
+class _RunLog:
+    """result/pretrain/<name>/{model.ckpt, model_best.ckpt, log}: written by rank 0 only; line formats of main.py:84-99."""
+
+    def __init__(self, name, rank0):
+        self.dir = 'result/pretrain/' + name
+        self.filename = os.path.join(self.dir, 'model.ckpt')
+        self.rank0 = rank0
+        os.makedirs(self.dir, exist_ok=True)
+
+    def write(self, text):
+        if self.rank0:
+            with open(os.path.join(self.dir, 'log'), 'a') as outfile:
+                outfile.write(text)
+
+
+def pretrain(argv=None):
+    """The pre-training driver (reference: main.py:17-100): same flags, prints, checkpoint and log artefacts; the loop itself is
+    organised around the device step (one process per GPU, rank 0 owns the artefacts)."""
+    args = get_args_pretrain(argv)
+    rank, world = _dist_env()
+    if world > 1:                                              # join the job before anything is drawn: rank 0's shuffle is everyone's
+        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+        torch.cuda.set_device(dev)
+        _dist_init(dev)
+    print("Loading Dictionary")
+    e2w, w2e = _load_vocab(args.dict_file)
     print("\nLoading Dataset", args.datasets)
     X_train, X_val = load_data_pretrain(datasets=args.datasets, mode="pretrain", root=args.data_root)
-    train_loader = DataLoader(MidiDataset(X=X_train), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=True)
+    train_loader, valid_loader = make_loaders(X_train, X_val, args.batch_size, args.num_workers)
     print("   len of train_loader", len(train_loader))
-    valid_loader = DataLoader(MidiDataset(X=X_val), batch_size=args.batch_size, num_workers=args.num_workers)
     print("   len of valid_loader", len(valid_loader))
     print("\nBuilding BART model")
-    configuration = BartConfig(max_position_embeddings=args.max_seq_len, d_model=args.hs, encoder_layers=args.layers,
-                               encoder_ffn_dim=args.ffn_dims, encoder_attention_heads=args.heads, decoder_layers=args.layers,
-                               decoder_ffn_dim=args.ffn_dims, decoder_attention_heads=args.heads)
-    pianobart = PianoBart(bartConfig=configuration, e2w=e2w, w2e=w2e, precision=args.precision)
+    shape = dict(max_position_embeddings=args.max_seq_len, d_model=args.hs)
+    for side in ('encoder', 'decoder'):                        # main.py:39-47: one size for both stacks
+        shape.update({side + '_layers': args.layers, side + '_ffn_dim': args.ffn_dims, side + '_attention_heads': args.heads})
+    pianobart = PianoBart(bartConfig=BartConfig(**shape), e2w=e2w, w2e=w2e, precision=args.precision)
     print("\nCreating BART Trainer")
     trainer = Pretrainer(pianobart, train_loader, valid_loader, args.lr, args.batch_size, args.max_seq_len, args.mask_percent,
                          args.cpu, args.cuda_devices)
     trainer.quiet = args.quiet
     print("\nTraining Start")
-    save_dir = 'result/pretrain/' + args.name
-    os.makedirs(save_dir, exist_ok=True)
-    filename = os.path.join(save_dir, 'model.ckpt')
-    print("   save model at {}".format(filename))
-    best_acc, best_epoch, bad_cnt = 0, 0, 0
+    run = _RunLog(args.name, rank == 0)
+    print("   save model at {}".format(run.filename))
+    best_acc, stale = 0, 0
     start_t = time.time()
-    rank0 = int(os.environ.get('RANK', 0)) == 0
     for epoch in range(args.epochs):
-        if bad_cnt >= 30:
+        if stale >= 30:
             print('valid acc not improving for 30 epochs')
             break
         train_loss, train_acc = trainer.train()
         valid_loss, valid_acc = trainer.valid()
-        weighted_score = [x * y for (x, y) in zip(valid_acc, pianobart.n_tokens)]
-        avg_acc = sum(weighted_score) / sum(pianobart.n_tokens)
+        avg_acc = float(np.dot(valid_acc, pianobart.n_tokens)) / sum(pianobart.n_tokens)       # n_tokens-weighted accuracy (main.py:72-74)
         is_best = avg_acc > best_acc
         best_acc = max(avg_acc, best_acc)
-        if is_best:
-            bad_cnt, best_epoch = 0, epoch
-        else:
-            bad_cnt += 1
+        stale = 0 if is_best else stale + 1
         print('epoch: {}/{} | Train Loss: {} | Train acc: {} | Valid Loss: {} | Valid acc: {}'.format(
             epoch + 1, args.epochs, train_loss, train_acc, valid_loss, valid_acc))
-        if rank0:
-            trainer.save_checkpoint(epoch, best_acc, valid_acc, valid_loss, train_loss, is_best, filename)
-            with open(os.path.join(save_dir, 'log'), 'a') as outfile:
-                outfile.write('Epoch {}: train_loss={}, train_acc={}, valid_loss={}, valid_acc={}\n'.format(
-                    epoch + 1, train_loss, train_acc, valid_loss, valid_acc))
+        if run.rank0:
+            trainer.save_checkpoint(epoch, best_acc, valid_acc, valid_loss, train_loss, is_best, run.filename)
+        run.write('Epoch {}: train_loss={}, train_acc={}, valid_loss={}, valid_acc={}\n'.format(epoch + 1, train_loss, train_acc, valid_loss, valid_acc))
     end_t = time.time()
-    print(f'Time cost in pretrain of PianoBart is {end_t - start_t}, start_t = {start_t}, end_t = {end_t}')
-    if rank0:
-        with open(os.path.join(save_dir, 'log'), 'a') as outfile:
-            outfile.write(f'Time cost in pretrain of PianoBart is {end_t - start_t}, start_t = {start_t}, end_t = {end_t}')
+    closing = f'Time cost in pretrain of PianoBart is {end_t - start_t}, start_t = {start_t}, end_t = {end_t}'
+    print(closing)
+    run.write(closing)
     return trainer
 
 

@@ -203,7 +203,7 @@ def test_flash_attention_at_bench_shape(ops, causal, tail):
     eb = max(float((db[i].double() - 0.25 - cs[i * d:(i + 1) * d]).abs().max() / cs.abs().max()) for i in range(3))
     print('flash S=1024 B*H=384 causal=%s %s: out abs %.2e  lse abs %.2e  dqkv rel %.2e  dbias rel %.2e' % (causal, tail, eo, el, eg, eb))
     assert not torch.isnan(out).any() and not torch.isnan(dqkv).any()
-    assert eo < 3e-2 and el < 2e-2 and eg < 3e-2 and eb < 2e-2
+    assert eo < 4e-2 and el < 3e-2 and eg < 2e-2 and eb < 1e-2
 
 
 # ------------------------------------------------------------------------------------------------ (iii) / (iv) whole step
@@ -268,7 +268,7 @@ def test_bf16_step_matches_fp32_step_cfg2_shape(ops):
     Philox masks in both precisions): loss, global gradient norm and every parameter tensor's gradient, bf16 vs exact f32. Then the
     bf16 step again on one stream: bit-identical to the two-stream schedule at this size."""
     from pianobart_amd import engine as E
-    ebf, mbf, batch = _compare_steps(ops, 1024, 768, 12, 3072, 12, 8, tol_loss=1e-2, tol_gn=5e-2, tol_slot=0.2)
+    ebf, mbf, batch = _compare_steps(ops, 1024, 768, 12, 3072, 12, 8, tol_loss=1e-3, tol_gn=2e-2, tol_slot=0.1)
     if ebf._side_stream() is not None:
         two = ebf.G32.clone()
         saved = E._WGRAD_STREAM
@@ -305,7 +305,7 @@ def test_bf16_step_at_full_bench_batch_is_finite_and_consistent(ops):
 
 def test_bf16_step_matches_fp32_step_cfg5_shape(ops):
     """configs[4] shape: 24L / 1024 / ffn 4096 / 16 heads, S = 2048, B = 1 (d = 1024 row kernels, head_dim 64 at S = 2048)."""
-    _compare_steps(ops, 2048, 1024, 24, 4096, 16, 1, tol_loss=2e-2, tol_gn=1e-1, tol_slot=0.3)
+    _compare_steps(ops, 2048, 1024, 24, 4096, 16, 1, tol_loss=2e-3, tol_gn=2e-2, tol_slot=0.15)
 
 
 def test_g10_cfg2_shape_spot_check_bf16():
@@ -334,5 +334,5 @@ def test_g10_cfg2_shape_spot_check_bf16():
     clear = z['top2_gap'] > 5e-2 * float(z['logit_absmax'])
     print('cfg2 bf16 logits rel = %.3e; argmax agreement %.4f overall, %.4f of the %.1f %% with a top-2 gap > 5%% of max|logit|'
           % (rel, agree, float((arg[clear] == ref[clear]).mean()), 100 * clear.mean()))
-    assert rel < 6e-2
-    assert agree > 0.97 and np.array_equal(arg[clear], ref[clear])
+    assert rel < 4e-2
+    assert agree > 0.995 and np.array_equal(arg[clear], ref[clear])

@@ -295,7 +295,8 @@ def test_flash_attention_fwd_bwd(ops, hd, causal, S, generic):
     p = torch.where(vis.any(-1, keepdim=True), torch.softmax(s, -1), torch.zeros_like(s))
     p = torch.nan_to_num(p, nan=0.0)
     ref = (p @ v).permute(0, 2, 1, 3).reshape(B, S, d)
-    assert float((out.double() - ref).abs().max()) < 3e-2
+    # the forward prescales Q by scale * log2(e) in bf16 (one more rounding of the scores, as the backward kernels always did)
+    assert float((out.double() - ref).abs().max()) < 4e-2
     has = vis.any(-1)
     ref_lse = torch.logsumexp(s, -1)
     assert float((lse.double() - ref_lse)[has].abs().max()) < 2e-2
