@@ -98,8 +98,11 @@ __device__ __forceinline__ void write_partials(f32x4 (&acc)[NACC][NIT], float* _
     }
 }
 
+// Register budget by row length: up to d = 768 (NIT <= 3) 128 VGPRs = 16 waves per CU (two 8-wave workgroups, tuned for cfg 2); a d = 1024 /
+// 2048 row (NIT 4 / 8: cfg 5, the reference's CLI default) keeps 4 / 8 float4 of xhat, g, mask and three accumulators per lane and
+// gets the 256-register budget of one workgroup per CU instead of spilling to scratch.
 template <typename T, typename TR, int NIT>
-__global__ __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ res,
+__global__ __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu(NIT <= 3 ? 4 : 2, NIT <= 3 ? 4 : 2))) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ res,
         const T* __restrict__ a, const float* __restrict__ w, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
         TR* __restrict__ dres, T* __restrict__ da, float* __restrict__ partials, int rows, int d, int accum_dres,
         uint64_t seed, uint32_t site, float p) {
@@ -403,12 +406,17 @@ extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, 
     return 0;
 }
 
-// ---- deferred reductions (see finalize_batch_kernel). State is per host thread: a backward pass is issued by one thread.
+// ---- deferred reductions (see finalize_batch_kernel). The open window (arena cursor, descriptor list) is per host thread: a backward
+// pass is issued by one thread. The device table itself belongs to the caller and may be shared between threads (autograd's device
+// thread and the main thread use the same workspace) or be re-allocated at the same address, so nothing is remembered about its
+// contents: every flush uploads its descriptors (~10 KB) with a stream-ordered copy from a small ring of pinned staging slots.
 struct DeferState {
     bool active = false;
     float* arena = nullptr; size_t cap = 0, used = 0;       // device floats handed out as partial-sum storage
     FinDesc* table = nullptr; int table_cap = 0, n = 0, maxd = 0;
-    std::vector<FinDesc> host, uploaded;                   // this pass / what the device table currently holds
+    std::vector<FinDesc> host;                             // descriptors of this pass
+    static constexpr int NSLOT = 4;
+    FinDesc* pin[NSLOT] = {}; size_t pin_cap[NSLOT] = {}; hipEvent_t ev[NSLOT] = {}; int next = 0;
 };
 static thread_local DeferState g_defer;
 
@@ -436,7 +444,6 @@ static bool defer_push(const float* partials, int nblk, int nacc, int d, float* 
 extern "C" int pb_defer_begin(float* arena, int64_t arena_floats, void* table, int32_t table_entries) {
     DeferState& S = g_defer;
     PB_REQUIRE(arena && table && arena_floats > 0 && table_entries > 0 && (uintptr_t)arena % 16 == 0, "pb_defer_begin: bad arena / table");
-    if (S.table != (FinDesc*)table) S.uploaded.clear();
     S.active = true; S.arena = arena; S.cap = (size_t)arena_floats; S.used = 0;
     S.table = (FinDesc*)table; S.table_cap = table_entries; S.n = 0; S.maxd = 0;
     S.host.clear();
@@ -451,16 +458,22 @@ extern "C" int pb_defer_flush(void* stream_) {
     S.active = false;
     if (S.n == 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
-    // the table of a training loop is the same every step: upload only when it changed (synchronously -- it is rare, and the
-    // host vector must not be rewritten under an in-flight copy)
-    if (S.uploaded.size() != S.host.size() || memcmp(S.uploaded.data(), S.host.data(), S.host.size() * sizeof(FinDesc)) != 0) {
-        if (hipStreamSynchronize(stream) != hipSuccess ||
-            hipMemcpy(S.table, S.host.data(), S.host.size() * sizeof(FinDesc), hipMemcpyHostToDevice) != hipSuccess) {
-            pb_set_error("pb_defer_flush: descriptor upload failed");
-            return -1;
-        }
-        S.uploaded = S.host;
+    // stage the descriptors in a pinned slot (waiting, once in NSLOT flushes at most, for the copy that last used it) and copy
+    // them to the caller's table in stream order: no host synchronisation, nothing cached across calls
+    const int slot = S.next;
+    S.next = (S.next + 1) % DeferState::NSLOT;
+    const size_t bytes = S.host.size() * sizeof(FinDesc);
+    if (S.ev[slot]) PB_CHECK_HIP(hipEventSynchronize(S.ev[slot]));
+    else PB_CHECK_HIP(hipEventCreateWithFlags(&S.ev[slot], hipEventDisableTiming));
+    if (S.pin_cap[slot] < bytes) {
+        if (S.pin[slot]) PB_CHECK_HIP(hipHostFree(S.pin[slot]));
+        S.pin[slot] = nullptr; S.pin_cap[slot] = 0;
+        PB_CHECK_HIP(hipHostMalloc((void**)&S.pin[slot], bytes, hipHostMallocDefault));
+        S.pin_cap[slot] = bytes;
     }
+    memcpy(S.pin[slot], S.host.data(), bytes);
+    PB_CHECK_HIP(hipMemcpyAsync(S.table, S.pin[slot], bytes, hipMemcpyHostToDevice, stream));
+    PB_CHECK_HIP(hipEventRecord(S.ev[slot], stream));
     hipLaunchKernelGGL(finalize_batch_kernel, dim3((S.maxd + 31) / 32, 3, S.n), dim3(8 * FIN_GROUPS), 0, stream, S.table);
     PB_LAUNCH_CHECK();
     return 0;

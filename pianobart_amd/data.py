@@ -42,7 +42,7 @@ def _row_i16(a, i):
         if not np.array_equal(r16, row):
             raise ValueError('Octuple id outside the int16 range')
         row = r16
-    return torch.from_numpy(np.ascontiguousarray(row))
+    return torch.from_numpy(np.array(row, dtype=np.int16))          # a private, writable copy of the 16 KB row (the map is read-only)
 
 
 class OctupleShards(torch.utils.data.Dataset):

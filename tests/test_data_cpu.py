@@ -1,0 +1,110 @@
+"""CPU: the input side of the pre-train path (reference: pretrain.py:548-576, dataset.py:4-16, main.py:28-35) --
+memory-mapped shards behind one index, and the data-parallel sharding of the harness at world size 2 over gloo: rank 0's shuffle
+and split are everyone's, an epoch's ranks see disjoint samples that cover the set, epochs differ, per-rank random streams differ."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.golden_util import synth_octuple_batch
+
+
+def _write(root, n=23, S=32, int16_sibling=False):
+    seqs = synth_octuple_batch(n, S, seed=5)[5].numpy().astype(np.int64)
+    cut = [0, 9, 23]
+    for k, ds in enumerate(('syn', 'syn2')):
+        os.makedirs(os.path.join(root, ds), exist_ok=True)
+        part = seqs[cut[k]:cut[k + 1]]
+        a, b = len(part) // 2, len(part) // 2 + 2
+        for name, pp in (('train', part[:a]), ('test', part[a:b]), ('valid', part[b:])):
+            np.save(os.path.join(root, ds, '%s_%s_split.npy' % (ds, name)), pp)
+    return seqs
+
+
+def test_shards_index_views_and_int16_rows(tmp_path):
+    from pianobart_amd.data import MidiDataset, OctupleShards, convert_to_int16
+    from pianobart_amd.pretrain import load_data_pretrain, make_loaders
+    root = str(tmp_path)
+    seqs = _write(root)
+    # an int16 sibling shard is picked up in place of the int64 file and gives the same rows
+    src = os.path.join(root, 'syn', 'syn_train_split.npy')
+    assert convert_to_int16(src, src[:-4] + '.i16.npy') == (4, 32, 8)
+    np.random.seed(0)
+    tr, va = load_data_pretrain(['syn', 'syn2'], 'pretrain', root)
+    assert isinstance(tr, OctupleShards) and len(tr) == int(23 * 0.85) and len(va) == 23 - len(tr) and tr.shape == (len(tr), 32, 8)
+    rows = [tr[i] for i in range(len(tr))] + [va[i] for i in range(len(va))]
+    assert all(r.dtype == torch.int16 and tuple(r.shape) == (32, 8) for r in rows)
+    key = lambda a: tuple(np.asarray(a).reshape(-1).tolist())
+    assert sorted(map(key, rows)) == sorted(map(key, seqs))                     # a permutation of the pool, nothing lost or doubled
+    assert any(isinstance(a, np.memmap) for a in tr.arrays)                      # the files stay where they are
+    tl, vl = make_loaders(tr, va, 4, 0)
+    b = next(iter(tl))
+    assert b.dtype == torch.int16 and tuple(b.shape) == (4, 32, 8) and len(tl) == -(-len(tr) // 4) and len(vl) == 1
+    assert torch.equal(MidiDataset(src)[1], torch.from_numpy(seqs[1].astype(np.int16)))
+    with pytest.raises(ValueError):
+        bad = np.zeros((1, 2, 8), dtype=np.int64); bad[0, 0, 0] = 70000
+        MidiDataset(bad)[0]
+
+
+def _worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pianobart_amd.pretrain import load_data_pretrain, make_loaders
+        np.random.seed(100 + rank)                                  # ranks start from DIFFERENT random states, like separate processes do
+        tr, va = load_data_pretrain(['syn', 'syn2'], 'pretrain', root)
+        tl, vl = make_loaders(tr, va, 4, 0)
+        key = lambda a: tuple(np.asarray(a).reshape(-1).tolist())
+        epochs = []
+        for ep in range(2):
+            tl.sampler.set_epoch(ep)
+            epochs.append([key(x) for b in tl for x in b])
+        q.put((rank, tr.index.tolist(), va.index.tolist(), epochs, [key(x) for b in vl for x in b], tl.batch_size))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_split_and_sharding_gloo(tmp_path):
+    root = str(tmp_path)
+    seqs = _write(root)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, tr0, va0, ep0, v0, bs0), (_, tr1, va1, ep1, v1, bs1) = res
+    assert tr0 == tr1 and va0 == va1 and sorted(tr0 + va0) == list(range(23))        # ONE split: rank 0's draw
+    assert bs0 == bs1 == 2                                                             # --batch_size 4 is the global batch
+    key = lambda a: tuple(np.asarray(a).reshape(-1).tolist())
+    train_rows = {key(seqs[i]) for i in tr0}
+    for e in range(2):
+        a, b = ep0[e], ep1[e]
+        assert len(a) == len(b) == -(-len(tr0) // 2)
+        assert set(a) | set(b) == train_rows                                           # the two ranks cover the epoch ...
+        assert len(set(a) & set(b)) <= 1                                               # ... without sharing samples (one wrap-around pad)
+    assert ep0[0] != ep0[1]                                                            # a new permutation every epoch
+    assert set(v0) | set(v1) == {key(seqs[i]) for i in va0}
+
+
+def test_per_rank_random_streams_differ(monkeypatch):
+    """Dropout (Engine._seed) and corruption (Pretrainer._step_seed) streams are keyed by RANK."""
+    from pianobart_amd.engine import Engine
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab
+    e2w, w2e = load_vocab()
+    cfg = BartConfig(max_position_embeddings=16, d_model=32, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=64, decoder_ffn_dim=64,
+                     encoder_attention_heads=2, decoder_attention_heads=2)
+    seeds = []
+    for r in ('0', '1', '7'):
+        monkeypatch.setenv('RANK', r)
+        m = PianoBartLM(PianoBart(cfg, e2w, w2e))
+        seeds.append(Engine(m.pianobart, m.mask_lm, 'bf16')._seed)
+    assert len(set(seeds)) == 3 and seeds[0] == 0x5EED1234

@@ -163,3 +163,101 @@ def test_weight_regulariser_matches_oracle(tag):
     before = eng.G32.clone()
     assert abs(float(tr.l2_penalty(False)) - pen_all) < 1e-5 * pen_all
     assert torch.equal(before, eng.G32)
+
+
+def _write_finetune_sets(root, prefix, seq, gen=False):
+    X = synth_octuple_batch(8, S, seed=3)[5].numpy().astype(np.int64)
+    rng = np.random.default_rng(0)
+    for part, sl in (('train', slice(0, 4)), ('valid', slice(4, 6)), ('test', slice(6, 8))):
+        np.save(os.path.join(root, '%s_%s.npy' % (prefix, part)), X[sl])
+        y = X[sl] if gen else (rng.integers(0, 8, size=(sl.stop - sl.start,)) if seq else rng.integers(0, 4, size=(sl.stop - sl.start, S)))
+        np.save(os.path.join(root, '%s_%s_ans.npy' % (prefix, part)), y)
+
+
+@pytest.mark.gpu
+def test_finetune_driver_writes_one_log_line_per_epoch(tmp_path):
+    """finetune() (main.py:103-215) end to end on a tiny synthetic composer set: the log holds the header line and ONE line per
+    epoch (real newlines), checkpoints carry the reference's keys."""
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a HIP device')
+    import pickle
+    from pianobart_amd.finetune import finetune
+    root = str(tmp_path / 'data')
+    os.makedirs(root)
+    _write_finetune_sets(root, 'Pianist8', True)
+    pickle.dump((E2W, W2E), open(tmp_path / 'dict.pkl', 'wb'))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        finetune(['--task', 'composer', '--dataset', 'Pianist8', '--dataroot', root, '--dict_file', str(tmp_path / 'dict.pkl'), '--name', 't',
+                  '--num_workers', '0', '--batch_size', '2', '--max_seq_len', str(S), '--hs', str(D), '--layers', '1', '--ffn_dims', '128',
+                  '--heads', '4', '--epochs', '2', '--nopretrain', '--cuda_devices', '0', '--precision', 'fp32'])
+        log = open('result/finetune/composer_t/log').read()
+        ck = torch.load('result/finetune/composer_t/model.ckpt', weights_only=False)
+    finally:
+        os.chdir(cwd)
+    lines = log.split('\n')
+    assert '\\n' not in log and lines[0].startswith('Loading pre-trained model from') and lines[-1] == ''
+    assert len(lines) == 4 and all(l.startswith('Epoch %d: train_loss=' % (i + 1)) for i, l in enumerate(lines[1:3]))
+    assert set(ck.keys()) == {'epoch', 'state_dict', 'valid_acc', 'valid_loss', 'train_loss', 'train_acc', 'optimizer'}
+
+
+@pytest.mark.gpu
+def test_generation_driver_end_to_end(tmp_path, capsys):
+    """finetune_generation() (main.py:214-321): args, data files, per-epoch train/valid/test, log + checkpoint; the FAD metrics that
+    need the absent `shapesimilarity` package are reported as n/a / None, never as numbers."""
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a HIP device')
+    from pianobart_amd.finetune_generation import finetune_generation, get_args_generation
+    a = get_args_generation([])
+    assert (a.datasets, a.lr, a.epochs, a.batch_size, a.hs, a.layers, a.eval) == ('maestro', 2e-6, 500, 8, 1024, 8, False)
+    root = str(tmp_path / 'data')
+    os.makedirs(root)
+    _write_finetune_sets(root, 'maestro', False, gen=True)
+    vocab = os.path.join(os.path.dirname(GOLD), '..', 'pianobart_amd', 'data', 'octuple_vocab.json')
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        tr = finetune_generation(['--datasets', 'maestro', '--dataroot', root, '--dict_file', os.path.abspath(vocab), '--name', 'g', '--num_workers', '0',
+                                  '--batch_size', '2', '--max_seq_len', str(S), '--hs', str(D), '--layers', '1', '--ffn_dims', '128', '--heads', '4',
+                                  '--epochs', '2', '--nopretrain', '--lr', '1e-3', '--cuda_devices', '0', '--precision', 'fp32'])
+        out = capsys.readouterr().out
+        log = open('result/finetune/generation_g/log').read().split('\n')
+        ck = torch.load('result/finetune/generation_g/model.ckpt', weights_only=False)
+    finally:
+        os.chdir(cwd)
+    assert len(log) == 4 and log[1].startswith('Epoch 1: train_loss=') and 'train_fad=None' in log[1]
+    assert 'FAD(BAR) Similarity: n/a' in out and 'FAD Similarity 0.0' not in out
+    assert set(ck.keys()) == {'epoch', 'state_dict', 'valid_acc', 'valid_loss', 'train_loss', 'train_acc', 'optimizer'}
+    assert any(k.startswith('mask_lm.proj.') for k in ck['state_dict']) and any(k.startswith('pianobart.') for k in ck['state_dict'])
+    assert tr.test()[2:4] == (None, None)
+
+
+@pytest.mark.gpu
+def test_head_adamw_leaves_parameters_without_gradient_alone():
+    """transformers.AdamW: `if p.grad is None: continue` -- no update, no decay, no step count; BART's dead `shared` table is not
+    re-homed into the head optimizer's flat buffers at all."""
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a HIP device')
+    from oracle import pianobart_oracle as O
+    from pianobart_amd.finetune import HeadAdamW
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n, generator=g).cuda()) for n in (10, 7, 33, 4)]
+    dead = torch.nn.Parameter(torch.randn(5, generator=g).cuda())
+    opt = HeadAdamW(ps + [dead], lr=1e-2, never=[dead])
+    assert len(opt.params) == 4 and opt.P.numel() == 12 + 8 + 36 + 4
+    ref = [p.detach().cpu().clone() for p in ps]
+    m = [torch.zeros_like(r) for r in ref]; v = [torch.zeros_like(r) for r in ref]
+    steps = [0, 0, 0, 0]
+    for it in range(3):
+        live = [0, 1, 2, 3] if it != 1 else [0, 2]                       # step 2: parameters 1 and 3 receive no gradient
+        for i, p in enumerate(ps):
+            p.grad = torch.randn(p.shape, generator=g).cuda() if i in live else None
+        opt.step()
+        for i in live:
+            steps[i] += 1
+            O.hf_adamw_step([ref[i]], [ps[i].grad.cpu()], [m[i]], [v[i]], step=steps[i], lr=1e-2)
+    assert opt.steps == steps == [3, 2, 3, 2]
+    for p, r in zip(ps, ref):
+        assert _rel(p.detach(), r) < 1e-6
+    assert dead.data_ptr() < opt.P.data_ptr() or dead.data_ptr() >= opt.P.data_ptr() + 4 * opt.P.numel()

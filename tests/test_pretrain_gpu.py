@@ -130,3 +130,32 @@ def test_generation_trainer_step_matches_reference_formula():
     l0 = tr.train()[0]
     l1 = tr.train()[0]
     assert l1 < l0
+
+
+def test_mmap_int16_shard_feeds_the_same_batch_as_the_int64_path(tmp_path):
+    """a memory-mapped int16 shard -> DataLoader -> Pretrainer.prepare_batch gives bit-identical device tensors to the
+    reference-format int64 array path (same corruption seed), and the ids reach the device as int16 without a conversion kernel."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from torch.utils.data import DataLoader
+    from pianobart_amd.data import MidiDataset, convert_to_int16
+    from pianobart_amd.model import BartConfig, PianoBart
+    from pianobart_amd.pretrain import Pretrainer
+    seqs = synth_octuple_batch(6, 64, seed=12)[5].numpy().astype(np.int64)
+    np.save(tmp_path / 'a.npy', seqs)
+    convert_to_int16(str(tmp_path / 'a.npy'), str(tmp_path / 'b.npy'))
+    kw = dict(max_position_embeddings=64, d_model=64, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=128,
+              decoder_ffn_dim=128, encoder_attention_heads=4, decoder_attention_heads=4)
+    tr = Pretrainer(PianoBart(BartConfig(**kw), E2W, W2E, precision='fp32'), None, None, 2e-5, 6, 64, 0.15, False, [0])
+    b16 = next(iter(DataLoader(MidiDataset(str(tmp_path / 'b.npy')), batch_size=6)))
+    assert b16.dtype == torch.int16
+    import random
+    seed0 = tr._step_seed
+    random.seed(3)
+    got = tr.prepare_batch(b16)
+    tr._step_seed = seed0
+    random.seed(3)
+    want = tr.prepare_batch(torch.from_numpy(seqs))                              # the reference's int64 rows
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    assert torch.equal(got[2].cpu().long(), torch.from_numpy(seqs))              # targets = the sequences themselves
