@@ -301,7 +301,7 @@ if __name__ == '__main__':
     fns = dict(vocab=g_vocab, g1=g1_forward, g4=g4_grads, g6=g6_gen_mask, g7=g7_sampling, g8=g8_generate,
                g9=g9_state_dict, g10=g10_cfg2_spot)
     for w in which:
-        if w in ('g11', 'g12'):
+        if w in ('g11', 'g12', 'g13'):
             continue
         print('==', w)
         fns[w]()
@@ -413,3 +413,62 @@ def g11_pretrain_artifacts():
 
 if __name__ == '__main__' and 'g11' in sys.argv[1:]:
     g11_pretrain_artifacts()
+
+
+def g13_octuple_midi():
+    """G13: MIDI_to_encoding / encoding_to_MIDI / padding of the REAL reference (Data/data_generation/convert.py) on
+    a synthetic song. The reference imports the third-party `miditoolkit` (absent here) only for its plain data containers and the
+    file parser; the converters themselves touch nothing but attributes, so the containers are stood in for by attribute bags
+    (data holders, no logic) and the file parser is not used. The vectors: the song (notes, time-signature and tempo changes), the
+    reference's encoding of it, its padded forms, and the reference's decoding of that encoding back into notes / changes."""
+    class Bag:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    mt = types.ModuleType('miditoolkit')
+    mt.midi = types.ModuleType('miditoolkit.midi'); mt.midi.parser = types.ModuleType('miditoolkit.midi.parser')
+    mt.containers = types.ModuleType('miditoolkit.containers')
+    mt.midi.parser.MidiFile = lambda *a, **k: Bag(ticks_per_beat=480, instruments=[], time_signature_changes=[], tempo_changes=[])
+    mt.containers.Instrument = lambda program, is_drum, name: Bag(program=program, is_drum=is_drum, name=name, notes=[])
+    mt.containers.Note = lambda start, end, pitch, velocity: Bag(start=start, end=end, pitch=pitch, velocity=velocity)
+    mt.containers.TimeSignature = lambda numerator, denominator, time: Bag(numerator=numerator, denominator=denominator, time=time)
+    mt.containers.TempoChange = lambda tempo, time: Bag(tempo=tempo, time=time)
+    for name, mod in (('miditoolkit', mt), ('miditoolkit.midi', mt.midi), ('miditoolkit.midi.parser', mt.midi.parser), ('miditoolkit.containers', mt.containers)):
+        sys.modules[name] = mod
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_convert', os.path.join(REF, 'Data', 'data_generation', 'convert.py'))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    rng = np.random.default_rng(13)
+    tpb = 384
+    insts = [Bag(program=0, is_drum=False, name='PIANO', notes=[]), Bag(program=40, is_drum=False, name='x', notes=[]), Bag(program=0, is_drum=True, name='d', notes=[])]
+    t = 0
+    for _ in range(400):
+        t += int(rng.integers(0, tpb))
+        k = int(rng.choice(3, p=[0.6, 0.3, 0.1]))
+        insts[k].notes.append(Bag(start=t, end=t + int(rng.integers(1, 6 * tpb)), pitch=int(rng.integers(21, 108)), velocity=int(rng.integers(1, 128))))
+    song = Bag(ticks_per_beat=tpb, instruments=insts,
+               time_signature_changes=[Bag(numerator=4, denominator=4, time=0), Bag(numerator=3, denominator=4, time=16 * tpb), Bag(numerator=6, denominator=8, time=40 * tpb),
+                                       Bag(numerator=12, denominator=4, time=70 * tpb)],
+               tempo_changes=[Bag(tempo=96.0, time=0), Bag(tempo=133.7, time=30 * tpb), Bag(tempo=300.0, time=60 * tpb), Bag(tempo=10.0, time=80 * tpb)])
+    enc = conv.MIDI_to_encoding(song, task='pretrain')
+    notes = np.array([[n.start, n.end, n.pitch, n.velocity, i.program, int(i.is_drum)] for i in insts for n in i.notes], dtype=np.int64)
+    melodic = [e for e in enc if e[2] <= 128 and e[3] <= 255]                 # rows encoding_to_MIDI can place (the reference codes drums past the vocabulary)
+    back = conv.encoding_to_MIDI(melodic)
+    back_notes = np.array(sorted([n.start, n.end, n.pitch, n.velocity, i.program, int(i.is_drum)] for i in back.instruments for n in i.notes), dtype=np.int64)
+    save('g13_octuple_midi.npz', ticks_per_beat=tpb, notes=notes,
+         ts=np.array([[c.time, c.numerator, c.denominator] for c in song.time_signature_changes], dtype=np.int64),
+         tp=np.array([[c.time, c.tempo] for c in song.tempo_changes], dtype=np.float64),
+         encoding=np.array(enc, dtype=np.int64),
+         padded_1024=np.array(conv.padding('x', list(enc[:300]), 1024), dtype=np.int64),
+         padded_cut_head=np.array(conv.padding('x', list(enc), 256, last=False), dtype=np.int64),
+         padded_cut_tail=np.array(conv.padding('x', list(enc), 256, last=True), dtype=np.int64),
+         melodic=np.array(melodic, dtype=np.int64), back_notes=back_notes,
+         back_ts=np.array([[c.time, c.numerator, c.denominator] for c in back.time_signature_changes], dtype=np.int64),
+         back_tp=np.array([[c.time, c.tempo] for c in back.tempo_changes], dtype=np.float64),
+         tables=np.array([len(conv.ts_list), len(conv.dur_enc), len(conv.dur_dec), conv.t2e((6, 8)), conv.d2e(1000), conv.e2d(77), conv.b2e(133.7)], dtype=np.int64))
+    print('g13: %d notes -> %d rows (%d placeable), decoded %d notes, %d ts / %d tempo changes' % (len(notes), len(enc), len(melodic), len(back_notes),
+                                                                                             len(back.time_signature_changes), len(back.tempo_changes)))
+
+
+if __name__ == '__main__' and 'g13' in sys.argv[1:]:
+    g13_octuple_midi()
