@@ -233,6 +233,7 @@ int pb_gemv(const void* W, const void* x, const float* bias, void* y, int32_t N,
 int pb_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const float* key_mask, int32_t H, int32_t Sk,
                    int32_t hd, int64_t k_ss, int64_t v_ss, float scale, int32_t dtype, void* stream);
 #define PB_DECODE_MAX_LAYERS 48
+#define PB_DECODE_MAX_SPLITS 16
 typedef struct pb_decode_layer {
     const void* wqkv; const float* bqkv; const void* wo; const float* bo; const float* ln1_w; const float* ln1_b;
     const void* wq_c; const float* bq_c; const void* wo_c; const float* bo_c; const float* lnc_w; const float* lnc_b;
@@ -247,6 +248,8 @@ typedef struct pb_decode_plan {
     const float* ptab; const float* lin_b; const float* pos; const float* lne_w; const float* lne_b; const float* enc_mask;
     void* x; void* y1; void* yc; void* y2; void* q; void* ctx; void* a; void* g;   /* scratch rows: d (g: ffn) elements of dtype */
     float* stat;              /* 8 floats */
+    float* attn_part;         /* H * PB_DECODE_MAX_SPLITS * (d / H + 2) floats: per-(head, key split) {max, sum, output} of the single-query
+                                 attention, merged by the out-projection GEMV; NULL = one workgroup per head writing ctx (the round-1 form) */
     float* logits;            /* (vocab) f32 */
     const void* head_w; const float* head_b;
     pb_decode_layer layers[PB_DECODE_MAX_LAYERS];

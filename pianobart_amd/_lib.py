@@ -40,7 +40,7 @@ class DecodePlan(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('dtype', 'd', 'H', 'ffn', 'S', 'S_enc', 'n_layers', 'vocab')] + \
                [('tab_off', ctypes.c_int32 * 9), ('_pad', ctypes.c_int32)] + \
                [(n, ctypes.c_void_p) for n in ('tok16', 'ptab', 'lin_b', 'pos', 'lne_w', 'lne_b', 'enc_mask', 'x', 'y1', 'yc', 'y2', 'q', 'ctx', 'a', 'g',
-                                               'stat', 'logits', 'head_w', 'head_b')] + \
+                                               'stat', 'attn_part', 'logits', 'head_w', 'head_b')] + \
                [('layers', DecodeLayer * 48)]
 
 

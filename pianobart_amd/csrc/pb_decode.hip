@@ -4,7 +4,10 @@
 // ~203 MB of bf16 decoder weights per token at cfg 2) or a tiny row op, so the kernels are:
 //   * gemv_kernel    y = act(W x + b): 2 output rows per workgroup, K split over its 4 waves, 16-byte weight loads straight
 //                    to VGPRs (no LDS: the operand is streamed once and not shared, cdna_hip_programming.md "GEMV" row);
-//   * attn_decode    single-query attention, one 16-wave workgroup per head, coalesced row-chunk loads of the cached K/V;
+//   * attn_decode    single-query attention, one 16-wave workgroup per head, coalesced row-chunk loads of the cached K/V
+//                    (the stand-alone pb_attn_decode op); inside pb_decode_step the keys of a head are split over up to 16
+//                    workgroups (attn_split_kernel) whose partial {max, sum, output} records the out-projection GEMV merges
+//                    in its prologue -- no merge launch, no inter-workgroup hand-off;
 //   * pb_decode_step a native host function that issues the 8*ND + 2 launches of one token (embed -> ND x [q|k|v (+LN2 of the
 //                    layer below), self-attn, out, q_c (+LN1), cross-attn, out_c, fc1+GELU (+LNc), fc2] -> heads (+LN2))
 //                    without Python between; the post-LNs ride in the prologue of the GEMV that consumes them.
@@ -27,11 +30,17 @@ __device__ __forceinline__ float block_sum4(float v, float* red, int lane, int w
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// With `part` set the input vector is the attention context that attn_split_kernel left as per-key-split partials
+// part[h][s] = {m, l, o[hd]} (f32): every workgroup merges the splits of the heads its K range touches on the fly
+// (ctx = sum_s o_s e^(m_s - M) / sum_s l_s e^(m_s - M), rounded to T like the stored context of the one-kernel form), so the
+// split needs neither a merge launch nor any inter-workgroup hand-off inside the attention kernel.
+struct MergeIn { const float* part; int nsplit, hd, stride; };       // stride = floats per (head, split) record
+
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, const T* __restrict__ x, const float* __restrict__ bias,
                                                    TO* __restrict__ y, TO* __restrict__ y2, int n_split, int N, int K, int gelu,
                                                    const T* __restrict__ res, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, T* __restrict__ ln_out, float eps) {
+                                                   const float* __restrict__ beta, T* __restrict__ ln_out, float eps, const MergeIn mg) {
     constexpr int EPV = 16 / sizeof(T);
     __shared__ float red[4][2];
     __shared__ float red1[4];
@@ -66,7 +75,28 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, cons
         T xv[EPV], u0[EPV], u1[EPV];
         *reinterpret_cast<uint4*>(u0) = *reinterpret_cast<const uint4*>(w0 + c);
         *reinterpret_cast<uint4*>(u1) = *reinterpret_cast<const uint4*>(w1 + c);
-        *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + c);
+        if (mg.part) {
+            const int h = c / mg.hd, off = c % mg.hd;                      // EPV columns of one head (hd is a multiple of EPV)
+            const float* rec = mg.part + (size_t)h * mg.nsplit * mg.stride;
+            float M = -INFINITY;
+            for (int sp = 0; sp < mg.nsplit; ++sp) M = fmaxf(M, rec[(size_t)sp * mg.stride]);
+            float L = 0.f, o[EPV];
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) o[j] = 0.f;
+            if (M != -INFINITY)
+                for (int sp = 0; sp < mg.nsplit; ++sp) {
+                    const float* r = rec + (size_t)sp * mg.stride;
+                    const float wgt = __expf(r[0] - M);                   // a split without a visible key has m = -inf: weight 0
+                    L = fmaf(r[1], wgt, L);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) o[j] = fmaf(r[2 + off + j], wgt, o[j]);
+                }
+            const float inv = L > 0.f ? 1.0f / L : 0.f;                    // nothing visible -> zero row (oracle header)
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) xv[j] = from_f<T>(o[j] * inv);
+        } else {
+            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + c);
+        }
         if (res) {
             T rv[EPV];
             *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res + c);
@@ -206,12 +236,116 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const T* __r
     }
 }
 
+
+// ---------------------------------------------------------------- single-query attention, keys split over workgroups
+// The one-workgroup-per-head form above keeps 12 of 256 CUs busy at cfg 2 (10.7 us per call, 24 calls per token = 40 % of the
+// decode step's GPU time). Here a (head, key-split) pair is one 4-wave workgroup: it computes the scores of its <= `chunk` keys,
+// their local maximum m, l = sum e^(s - m) and o = sum e^(s - m) v (unnormalised) and stores {m, l, o[hd]} as f32; the consumer
+// GEMV merges the splits in its prologue (gemv_kernel / MergeIn). Same row-chunk ownership of the cached K / V rows as above.
+constexpr int AS_WAVES = 4;
+template <typename T, int CPR, int CR = CPR>
+__global__ __launch_bounds__(AS_WAVES * 64) void attn_split_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                                   float* __restrict__ part, const float* __restrict__ key_mask, int Sk, int chunk,
+                                                                   long k_ss, long v_ss, float scale) {
+    constexpr int EPV = 16 / sizeof(T), HD = CR * EPV, KPW = 64 / CPR, STEP = AS_WAVES * KPW, UR = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);            // [chunk] scores -> probabilities
+    float* red = sc + ((chunk + 3) & ~3);                  // [AS_WAVES] reductions, then [AS_WAVES][HD] partial outputs
+    const int h = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
+    const int j0 = sp * chunk, j1 = min(Sk, j0 + chunk);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, sub = lane % CPR, grp = lane / CPR;
+    const bool live = CR == CPR || sub < CR;
+    float qv[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) qv[e] = 0.f;
+    if (live) {
+        T qq[EPV];
+        *reinterpret_cast<uint4*>(qq) = *reinterpret_cast<const uint4*>(q + h * HD + sub * EPV);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) qv[e] = to_f(qq[e]) * scale;
+    }
+    float mx = -INFINITY;
+    for (int jb = j0 + wave * KPW; jb < j1; jb += UR * STEP) {
+        uint4 kraw[UR];
+#pragma unroll
+        for (int r = 0; r < UR; ++r) {
+            const int j = jb + r * STEP + grp;
+            kraw[r] = uint4{0u, 0u, 0u, 0u};
+            if (j < j1 && live) kraw[r] = *reinterpret_cast<const uint4*>(kc + (long)j * k_ss + h * HD + sub * EPV);
+        }
+#pragma unroll
+        for (int r = 0; r < UR; ++r) {
+            const int j = jb + r * STEP + grp;
+            float a = 0.f;
+            if (j < j1) {
+                const T* kv = reinterpret_cast<const T*>(&kraw[r]);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) a = fmaf(to_f(kv[e]), qv[e], a);
+            }
+#pragma unroll
+            for (int o = 1; o < CPR; o <<= 1) a += __shfl_xor(a, o, 64);
+            if (j < j1) {
+                const float sv = (!key_mask || key_mask[j] != 0.f) ? a : -INFINITY;
+                if (sub == 0) sc[j - j0] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    if (mx != -INFINITY)
+        for (int j = t; j < j1 - j0; j += AS_WAVES * 64) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    float acc[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
+    if (mx != -INFINITY)
+        for (int jb = j0 + wave * KPW; jb < j1; jb += UR * STEP) {
+            uint4 vraw[UR];
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int j = jb + r * STEP + grp;
+                vraw[r] = uint4{0u, 0u, 0u, 0u};
+                if (j < j1 && live) vraw[r] = *reinterpret_cast<const uint4*>(vc + (long)j * v_ss + h * HD + sub * EPV);
+            }
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int j = jb + r * STEP + grp;
+                if (j < j1) {
+                    const T* vv = reinterpret_cast<const T*>(&vraw[r]);
+                    const float pj = sc[j - j0];
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) acc[e] = fmaf(pj, to_f(vv[e]), acc[e]);
+                }
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e)
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (grp == 0 && live)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) red[wave * HD + sub * EPV + e] = acc[e];
+    __syncthreads();
+    float* rec = part + ((size_t)h * nsplit + sp) * (HD + 2);
+    if (t == 0) { rec[0] = mx; rec[1] = sum; }
+    if (t < HD) rec[2 + t] = (red[t] + red[HD + t]) + (red[2 * HD + t] + red[3 * HD + t]);
+}
+
 }  // namespace
 
 struct LnIn { const void* res; const float* gamma; const float* beta; void* out; };
 
 static int gemv_launch(const void* W, const void* x, const float* bias, void* y, void* y2, int n_split, int N, int K, int dtype, int y_f32,
-                       int gelu, hipStream_t stream, LnIn ln = LnIn{nullptr, nullptr, nullptr, nullptr}) {
+                       int gelu, hipStream_t stream, LnIn ln = LnIn{nullptr, nullptr, nullptr, nullptr}, MergeIn mg = MergeIn{nullptr, 0, 0, 0}) {
     const int epv = dtype == PB_BF16 ? 8 : 4;
     PB_REQUIRE(N > 0 && K > 0 && K % epv == 0, "pb_gemv: K=%d must be a multiple of %d", K, epv);
     PB_REQUIRE(((uintptr_t)W % 16 == 0) && ((uintptr_t)x % 16 == 0), "pb_gemv: operands must be 16-byte aligned");
@@ -219,12 +353,12 @@ static int gemv_launch(const void* W, const void* x, const float* bias, void* y,
     const float eps = 1e-5f;
     if (dtype == PB_BF16) {
         if (y_f32) hipLaunchKernelGGL((gemv_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)W, (const bf16_t*)x, bias, (float*)y, (float*)y2, n_split, N, K, gelu,
-                                      (const bf16_t*)ln.res, ln.gamma, ln.beta, (bf16_t*)ln.out, eps);
+                                      (const bf16_t*)ln.res, ln.gamma, ln.beta, (bf16_t*)ln.out, eps, mg);
         else hipLaunchKernelGGL((gemv_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)W, (const bf16_t*)x, bias, (bf16_t*)y, (bf16_t*)y2, n_split, N, K, gelu,
-                                (const bf16_t*)ln.res, ln.gamma, ln.beta, (bf16_t*)ln.out, eps);
+                                (const bf16_t*)ln.res, ln.gamma, ln.beta, (bf16_t*)ln.out, eps, mg);
     } else {
         hipLaunchKernelGGL((gemv_kernel<float, float>), grid, block, 0, stream, (const float*)W, (const float*)x, bias, (float*)y, (float*)y2, n_split, N, K, gelu,
-                           (const float*)ln.res, ln.gamma, ln.beta, (float*)ln.out, eps);
+                           (const float*)ln.res, ln.gamma, ln.beta, (float*)ln.out, eps, mg);
     }
     PB_LAUNCH_CHECK();
     return 0;
@@ -267,6 +401,36 @@ extern "C" int pb_attn_decode(const void* q, const void* k_cache, const void* v_
     return 0;
 }
 
+// key-split single-query attention into `part` (H * nsplit records of hd + 2 floats); returns the number of splits used
+template <typename T, int CPR, int CR = CPR>
+static void attn_split_launch(const void* q, const void* kc, const void* vc, float* part, const float* key_mask, int H, int Sk, int chunk, int nsplit,
+                              long k_ss, long v_ss, float scale, hipStream_t stream) {
+    constexpr int HD = CR * (16 / (int)sizeof(T));
+    const size_t lds = (size_t)(((chunk + 3) & ~3) + AS_WAVES * HD) * sizeof(float);
+    hipLaunchKernelGGL((attn_split_kernel<T, CPR, CR>), dim3(H, nsplit), dim3(AS_WAVES * 64), lds, stream, (const T*)q, (const T*)kc, (const T*)vc, part,
+                       key_mask, Sk, chunk, k_ss, v_ss, scale);
+}
+static int attn_split(const void* q, const void* kc, const void* vc, float* part, const float* key_mask, int H, int Sk, int hd, long k_ss, long v_ss,
+                      float scale, int dtype, hipStream_t stream, int& nsplit) {
+    // <= PB_DECODE_MAX_SPLITS splits of >= 64 keys: H * nsplit workgroups cover the chip at cfg 2 from 512 keys on
+    int chunk = (Sk + PB_DECODE_MAX_SPLITS - 1) / PB_DECODE_MAX_SPLITS;
+    chunk = chunk < 64 ? 64 : (chunk + 15) & ~15;
+    nsplit = (Sk + chunk - 1) / chunk;
+    if (dtype == PB_BF16) {
+        if (hd == 32) attn_split_launch<bf16_t, 4>(q, kc, vc, part, key_mask, H, Sk, chunk, nsplit, k_ss, v_ss, scale, stream);
+        else if (hd == 64) attn_split_launch<bf16_t, 8>(q, kc, vc, part, key_mask, H, Sk, chunk, nsplit, k_ss, v_ss, scale, stream);
+        else if (hd == 96) attn_split_launch<bf16_t, 16, 12>(q, kc, vc, part, key_mask, H, Sk, chunk, nsplit, k_ss, v_ss, scale, stream);
+        else attn_split_launch<bf16_t, 16>(q, kc, vc, part, key_mask, H, Sk, chunk, nsplit, k_ss, v_ss, scale, stream);
+    } else {
+        if (hd == 32) attn_split_launch<float, 8>(q, kc, vc, part, key_mask, H, Sk, chunk, nsplit, k_ss, v_ss, scale, stream);
+        else if (hd == 64) attn_split_launch<float, 16>(q, kc, vc, part, key_mask, H, Sk, chunk, nsplit, k_ss, v_ss, scale, stream);
+        else if (hd == 96) attn_split_launch<float, 32, 24>(q, kc, vc, part, key_mask, H, Sk, chunk, nsplit, k_ss, v_ss, scale, stream);
+        else attn_split_launch<float, 32>(q, kc, vc, part, key_mask, H, Sk, chunk, nsplit, k_ss, v_ss, scale, stream);
+    }
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- one decoder token, natively sequenced
 extern "C" int pb_decode_step(const pb_decode_plan* p, int32_t i, void* stream) {
     PB_REQUIRE(p && p->n_layers > 0 && p->n_layers <= PB_DECODE_MAX_LAYERS, "pb_decode_step: bad plan");
@@ -288,13 +452,24 @@ extern "C" int pb_decode_step(const pb_decode_plan* p, int32_t i, void* stream) 
         // q | k|v in one launch; k|v land in row i of the self-attention cache. Input: h (layer 0) or LN2 of the layer below.
         if (gemv_launch(L.wqkv, ln.res ? (const void*)p->a : (const void*)h, L.bqkv, p->q, kvs + (size_t)i * 2 * d * esz, d, 3 * d, d, dt, 0, 0, st, ln)) return -1;
         if (ln.res) h = alt;
-        if (pb_attn_decode(p->q, kvs, kvs + (size_t)d * esz, p->ctx, nullptr, H, i + 1, hd, 2 * d, 2 * d, scale, dt, stream)) return -1;
-        if (pb_gemv(L.wo, p->ctx, L.bo, p->a, d, d, dt, 0, 0, stream)) return -1;
+        int ns = 0;
+        if (p->attn_part) {                                // keys split over workgroups, merged in the out-projection's prologue
+            if (attn_split(p->q, kvs, kvs + (size_t)d * esz, p->attn_part, nullptr, H, i + 1, hd, 2 * d, 2 * d, scale, dt, st, ns)) return -1;
+            if (gemv_launch(L.wo, p->ctx, L.bo, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, MergeIn{p->attn_part, ns, hd, hd + 2})) return -1;
+        } else {
+            if (pb_attn_decode(p->q, kvs, kvs + (size_t)d * esz, p->ctx, nullptr, H, i + 1, hd, 2 * d, 2 * d, scale, dt, stream)) return -1;
+            if (pb_gemv(L.wo, p->ctx, L.bo, p->a, d, d, dt, 0, 0, stream)) return -1;
+        }
         // cross attention against the cached encoder K/V; the q projection applies LN1(h + a) -> y1
         ln = LnIn{h, L.ln1_w, L.ln1_b, p->y1};
         if (gemv_launch(L.wq_c, p->a, L.bq_c, p->q, nullptr, d, d, d, dt, 0, 0, st, ln)) return -1;
-        if (pb_attn_decode(p->q, L.kv_cross, (const char*)L.kv_cross + (size_t)d * esz, p->ctx, p->enc_mask, H, p->S_enc, hd, 2 * d, 2 * d, scale, dt, stream)) return -1;
-        if (pb_gemv(L.wo_c, p->ctx, L.bo_c, p->a, d, d, dt, 0, 0, stream)) return -1;
+        if (p->attn_part) {
+            if (attn_split(p->q, L.kv_cross, (const char*)L.kv_cross + (size_t)d * esz, p->attn_part, p->enc_mask, H, p->S_enc, hd, 2 * d, 2 * d, scale, dt, st, ns)) return -1;
+            if (gemv_launch(L.wo_c, p->ctx, L.bo_c, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, MergeIn{p->attn_part, ns, hd, hd + 2})) return -1;
+        } else {
+            if (pb_attn_decode(p->q, L.kv_cross, (const char*)L.kv_cross + (size_t)d * esz, p->ctx, p->enc_mask, H, p->S_enc, hd, 2 * d, 2 * d, scale, dt, stream)) return -1;
+            if (pb_gemv(L.wo_c, p->ctx, L.bo_c, p->a, d, d, dt, 0, 0, stream)) return -1;
+        }
         // FFN; fc1 applies LNc(y1 + a) -> yc
         ln = LnIn{p->y1, L.lnc_w, L.lnc_b, p->yc};
         if (gemv_launch(L.w1, p->a, L.b1, p->g, nullptr, f, f, d, dt, 0, 1, st, ln)) return -1;

@@ -23,6 +23,7 @@ from ._lib import LIB, PB_BF16, PB_F32, PBError
 _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second HIP stream, bits: 1 = weight-gradient GEMMs, 2 = cross-attention K/V projections, 4 = backward GEMMs as ordinary grids (0: everything on one stream, for A/B)
 _WG_TARGET = int(os.environ.get('PB_WG_TARGET', '192' if _WGRAD_STREAM & 1 else '256'))            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
 _NO_DEFER = bool(int(os.environ.get('PB_NO_DEFER', '0')))                  # developer aid: reduce every bias / LayerNorm gradient right behind its producer (A/B)
+_DECODE_SPLIT = bool(int(os.environ.get('PB_DECODE_SPLIT', '1')))              # developer aid: 0 = single-query attention with one workgroup per head (A/B)
 _NO_FUSED_BIAS = bool(int(os.environ.get('PB_NO_FUSED_BIAS', '0')))     # developer aid: A/B the bias gradients fused into the GEMM / attention epilogues
 
 LN_EPS = 1e-5
@@ -812,6 +813,8 @@ class Engine:
             for n, t in rows.items():
                 setattr(plan, n, P(t))
             plan.stat, plan.logits, plan.head_w, plan.head_b = P(stat), P(logits), P(self.w['head.w']), P(wf['head.b'])
+            attn_part = torch.empty(self.H * 16 * (self.hd + 2), dtype=torch.float32, device=dev)      # PB_DECODE_MAX_SPLITS records per head
+            plan.attn_part = P(attn_part) if _DECODE_SPLIT else None
             for l in range(self.ND):
                 pf, L = 'dec.%d.' % l, plan.layers[l]
                 L.wqkv, L.bqkv, L.wo, L.bo = P(self.w[pf + 'wqkv']), P(wf[pf + 'bqkv']), P(self.w[pf + 'wo']), P(wf[pf + 'bo'])

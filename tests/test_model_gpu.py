@@ -403,3 +403,50 @@ def test_backward_after_an_intervening_forward_fails_loudly():
         m.train()
     with pytest.raises(PBError):
         loss.backward()
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16', 4e-2)])
+def test_decode_at_cfg2_size_matches_teacher_forced_full_pass(precision, tol):
+    """BASELINE configs[3] shape: 12L / 768 / 12 heads, S = 1024, B = 1. 96 decode steps of the KV-cached native path (self-attention
+    keys split over workgroups from 65 keys on, cross-attention over ~700 encoder keys in 11 splits, merged in the out-projection
+    GEMV) against ONE teacher-forced full decoder pass over the same tokens (the training kernels): the logits row of every step,
+    and -- exact-f32 instantiation -- its argmax ids."""
+    _need_gpu()
+    m = _lm(1024, 768, 12, 3072, 12, 41, precision).eval()
+    with torch.no_grad():
+        for i, p0 in enumerate([256, 128, 129, 256, 128, 32, 254, 49]):
+            m.mask_lm.proj[i].bias[p0:] = -30.0                   # specials unsamplable: the loop runs as long as we feed it
+    m = m.cuda()
+    enc = synth_octuple_batch(1, 1024, seed=19, min_len=700)[5].cuda()
+    emask = (enc[:, :, 0] != 256).float()
+    assert 600 < int(emask.sum()) <= 1024
+    N = 96
+    forced = synth_octuple_batch(1, N, seed=23, min_len=N)[5][0]
+    forced[-1] = forced[-2]                                       # no EOS row inside the forced prefix
+    rows = []
+
+    def feed(row):
+        rows.append(row.clone())
+        return forced[len(rows) - 1].clone() if len(rows) <= N else torch.tensor([256, 128, 129, 256, 128, 32, 254, 49])
+
+    eng = m._get_engine()
+    out = eng.generate(enc, emask, feed)
+    assert len(rows) == N + 1 and torch.equal(out[0, :N].cpu(), forced)
+    # teacher-forced: decoder input = SOS + forced[:-1]... one full pass gives the logits of every position at once
+    dec = torch.tensor([256, 128, 129, 256, 128, 32, 254, 49]).repeat(1, 1024, 1)
+    dec[0, 0] = torch.tensor([258, 130, 131, 258, 130, 34, 256, 51])
+    dec[0, 1:N + 1] = forced
+    dmask = torch.zeros(1, 1024); dmask[0, :N + 1] = 1
+    with torch.no_grad():
+        full = torch.cat(m(enc, dec.cuda(), emask, dmask.cuda()), dim=-1)[0].float().cpu()
+    worst = 0.0
+    for i in range(N + 1):
+        keep = full[i] > -20
+        worst = max(worst, float((rows[i][keep] - full[i][keep]).abs().max() / full[i][keep].abs().max()))
+    print('decode 12L/768 S=1024 (%s): worst logits rel over %d steps = %.2e' % (precision, N + 1, worst))
+    assert worst < tol
+    if precision == 'fp32':
+        offs = np.cumsum([0, 262, 134, 135, 262, 134, 38, 260, 55])
+        a = torch.stack([torch.stack([r[offs[k]:offs[k + 1]].argmax() for k in range(8)]) for r in rows])
+        b = torch.stack([torch.stack([full[i][offs[k]:offs[k + 1]].argmax() for k in range(8)]) for i in range(N + 1)])
+        assert float((a == b).float().mean()) > 0.995
