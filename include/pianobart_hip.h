@@ -248,7 +248,7 @@ typedef struct pb_decode_plan {
     const float* ptab; const float* lin_b; const float* pos; const float* lne_w; const float* lne_b; const float* enc_mask;
     void* x; void* y1; void* yc; void* y2; void* q; void* ctx; void* a; void* g;   /* scratch rows: d (g: ffn) elements of dtype */
     float* stat;              /* 8 floats */
-    float* attn_part;         /* H * PB_DECODE_MAX_SPLITS * (d / H + 2) floats: per-(head, key split) {max, sum, output} of the single-query
+    float* attn_part;         /* H * PB_DECODE_MAX_SPLITS * (d / H + 4) floats, 16-byte aligned: per-(head, key split) {max, sum, output} of the single-query
                                  attention, merged by the out-projection GEMV; NULL = one workgroup per head writing ctx (the round-1 form) */
     float* logits;            /* (vocab) f32 */
     const void* head_w; const float* head_b;

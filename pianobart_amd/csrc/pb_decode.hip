@@ -31,12 +31,19 @@ __device__ __forceinline__ float block_sum4(float v, float* red, int lane, int w
 }
 
 // With `part` set the input vector is the attention context that attn_split_kernel left as per-key-split partials
-// part[h][s] = {m, l, o[hd]} (f32): every workgroup merges the splits of the heads its K range touches on the fly
+// part[h][s] = {m, l, -, -, o[hd]} (f32): every workgroup merges the splits of the heads its K range touches on the fly
 // (ctx = sum_s o_s e^(m_s - M) / sum_s l_s e^(m_s - M), rounded to T like the stored context of the one-kernel form), so the
 // split needs neither a merge launch nor any inter-workgroup hand-off inside the attention kernel.
 struct MergeIn { const float* part; int nsplit, hd, stride; };       // stride = floats per (head, split) record
 
-template <typename T, typename TO>
+// NCH = chunks of EPV elements a thread owns along K (K <= NCH * 256 * EPV). Everything a thread will ever read -- its weight chunks
+// of both rows, x, the residual, gamma / beta, the split records' maxima -- is requested up front, so the kernel is ONE memory round
+// trip deep (plus the two block reductions of the LayerNorm statistics): at batch 1 these kernels are latency, not bandwidth.
+template <typename T> struct VecOf;
+template <> struct VecOf<bf16_t> { typedef bf16x8 type; };
+template <> struct VecOf<float> { typedef f32x4 type; };
+
+template <typename T, typename TO, int NCH, bool MERGE>
 __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, const T* __restrict__ x, const float* __restrict__ bias,
                                                    TO* __restrict__ y, TO* __restrict__ y2, int n_split, int N, int K, int gelu,
                                                    const T* __restrict__ res, const float* __restrict__ gamma,
@@ -47,66 +54,99 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 2;
     const bool two = n0 + 1 < N;
-    float mean = 0.f, rstd = 1.f;
-    if (res) {
-        float s = 0.f;
-        for (int c = threadIdx.x * EPV; c < K; c += 256 * EPV) {
-            T xv[EPV], rv[EPV];
-            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + c);
-            *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res + c);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) s += to_f(rv[j]) + to_f(xv[j]);
-        }
-        mean = block_sum4(s, red1, lane, wave) / (float)K;
-        float q = 0.f;
-        for (int c = threadIdx.x * EPV; c < K; c += 256 * EPV) {
-            T xv[EPV], rv[EPV];
-            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + c);
-            *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res + c);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) { const float z = to_f(rv[j]) + to_f(xv[j]) - mean; q = fmaf(z, z, q); }
-        }
-        rstd = rsqrtf(block_sum4(q, red1, lane, wave) / (float)K + eps);
-    }
-    float a0 = 0.f, a1 = 0.f;
     const T* w0 = W + (long)n0 * K;
     const T* w1 = W + (long)(two ? n0 + 1 : n0) * K;
-    for (int c = threadIdx.x * EPV; c < K; c += 256 * EPV) {
-        T xv[EPV], u0[EPV], u1[EPV];
-        *reinterpret_cast<uint4*>(u0) = *reinterpret_cast<const uint4*>(w0 + c);
-        *reinterpret_cast<uint4*>(u1) = *reinterpret_cast<const uint4*>(w1 + c);
-        if (mg.part) {
+    typedef typename VecOf<T>::type V;                                     // EPV elements = 16 bytes, kept as a register vector (no address taken)
+    const V zero4 = V{};
+    V u0[NCH], u1[NCH], xr[NCH], rr[NCH];
+    f32x4 gm[NCH][EPV / 4], bt[NCH][EPV / 4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (threadIdx.x + 256 * i) * EPV;
+        const bool in = c < K;
+        u0[i] = in ? *reinterpret_cast<const V*>(w0 + c) : zero4;
+        u1[i] = in ? *reinterpret_cast<const V*>(w1 + c) : zero4;
+        xr[i] = (in && !MERGE) ? *reinterpret_cast<const V*>(x + c) : zero4;
+        rr[i] = (in && res) ? *reinterpret_cast<const V*>(res + c) : zero4;
+#pragma unroll
+        for (int v4 = 0; v4 < EPV / 4; ++v4) {
+            gm[i][v4] = (in && res) ? *reinterpret_cast<const f32x4*>(gamma + c + 4 * v4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bt[i][v4] = (in && res) ? *reinterpret_cast<const f32x4*>(beta + c + 4 * v4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    float xf[NCH][EPV];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (threadIdx.x + 256 * i) * EPV;
+        if (MERGE && c < K) {
             const int h = c / mg.hd, off = c % mg.hd;                      // EPV columns of one head (hd is a multiple of EPV)
             const float* rec = mg.part + (size_t)h * mg.nsplit * mg.stride;
+            // all loads of the <= PB_DECODE_MAX_SPLITS records are issued before the first use: one L2 round trip, not one per split
+            float ms[PB_DECODE_MAX_SPLITS], ls[PB_DECODE_MAX_SPLITS];
+            f32x4 oa[PB_DECODE_MAX_SPLITS][EPV / 4];
+#pragma unroll
+            for (int sp = 0; sp < PB_DECODE_MAX_SPLITS; ++sp) {
+                const float* r = rec + (size_t)(sp < mg.nsplit ? sp : 0) * mg.stride;
+                ms[sp] = sp < mg.nsplit ? r[0] : -INFINITY;
+                ls[sp] = r[1];
+#pragma unroll
+                for (int v4 = 0; v4 < EPV / 4; ++v4) oa[sp][v4] = *reinterpret_cast<const f32x4*>(r + 4 + off + 4 * v4);
+            }
             float M = -INFINITY;
-            for (int sp = 0; sp < mg.nsplit; ++sp) M = fmaxf(M, rec[(size_t)sp * mg.stride]);
+#pragma unroll
+            for (int sp = 0; sp < PB_DECODE_MAX_SPLITS; ++sp) M = fmaxf(M, ms[sp]);
             float L = 0.f, o[EPV];
 #pragma unroll
             for (int j = 0; j < EPV; ++j) o[j] = 0.f;
-            if (M != -INFINITY)
-                for (int sp = 0; sp < mg.nsplit; ++sp) {
-                    const float* r = rec + (size_t)sp * mg.stride;
-                    const float wgt = __expf(r[0] - M);                   // a split without a visible key has m = -inf: weight 0
-                    L = fmaf(r[1], wgt, L);
 #pragma unroll
-                    for (int j = 0; j < EPV; ++j) o[j] = fmaf(r[2 + off + j], wgt, o[j]);
-                }
+            for (int sp = 0; sp < PB_DECODE_MAX_SPLITS; ++sp) {
+                const float wgt = (M == -INFINITY || ms[sp] == -INFINITY) ? 0.f : __expf(ms[sp] - M);   // no visible key in the split (or at all): weight 0
+                L = fmaf(ls[sp], wgt, L);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) o[j] = fmaf(oa[sp][j >> 2][j & 3], wgt, o[j]);
+            }
             const float inv = L > 0.f ? 1.0f / L : 0.f;                    // nothing visible -> zero row (oracle header)
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) xv[j] = from_f<T>(o[j] * inv);
+            for (int j = 0; j < EPV; ++j) xf[i][j] = to_f(from_f<T>(o[j] * inv));     // rounded to T like the stored context of the one-kernel form
         } else {
-            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + c);
-        }
-        if (res) {
-            T rv[EPV];
-            *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res + c);
 #pragma unroll
-            for (int j = 0; j < EPV; ++j)      // rounded to T exactly like the stored LayerNorm output the unfused path would read back
-                xv[j] = from_f<T>((to_f(rv[j]) + to_f(xv[j]) - mean) * rstd * gamma[c + j] + beta[c + j]);
-            if (blockIdx.x == 0) *reinterpret_cast<uint4*>(ln_out + c) = *reinterpret_cast<const uint4*>(xv);
+            for (int j = 0; j < EPV; ++j) xf[i][j] = to_f(xr[i][j]);
         }
+    }
+    if (res) {
+        // x' = LayerNorm(res + x) * gamma + beta, two-pass statistics from the registers
+        float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) { const float xf = to_f(xv[j]); a0 = fmaf(to_f(u0[j]), xf, a0); a1 = fmaf(to_f(u1[j]), xf, a1); }
+        for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) { xf[i][j] += to_f(rr[i][j]); s += xf[i][j]; }       // lanes beyond K hold zeros
+        }
+        const float mean = block_sum4(s, red1, lane, wave) / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const bool in = (threadIdx.x + 256 * i) * EPV < K;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) { const float z = xf[i][j] - mean; q = in ? fmaf(z, z, q) : q; }
+        }
+        const float rstd = rsqrtf(block_sum4(q, red1, lane, wave) / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (threadIdx.x + 256 * i) * EPV;
+            V xo;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {       // rounded to T exactly like the stored LayerNorm output the unfused path would read back
+                xo[j] = from_f<T>((xf[i][j] - mean) * rstd * gm[i][j >> 2][j & 3] + bt[i][j >> 2][j & 3]);
+                xf[i][j] = to_f(xo[j]);
+            }
+            if (blockIdx.x == 0 && c < K) *reinterpret_cast<V*>(ln_out + c) = xo;
+        }
+    }
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { a0 = fmaf(to_f(u0[i][j]), xf[i][j], a0); a1 = fmaf(to_f(u1[i][j]), xf[i][j], a1); }    // weights beyond K are zeros
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1);
     if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; }
@@ -240,7 +280,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const T* __r
 // ---------------------------------------------------------------- single-query attention, keys split over workgroups
 // The one-workgroup-per-head form above keeps 12 of 256 CUs busy at cfg 2 (10.7 us per call, 24 calls per token = 40 % of the
 // decode step's GPU time). Here a (head, key-split) pair is one 4-wave workgroup: it computes the scores of its <= `chunk` keys,
-// their local maximum m, l = sum e^(s - m) and o = sum e^(s - m) v (unnormalised) and stores {m, l, o[hd]} as f32; the consumer
+// their local maximum m, l = sum e^(s - m) and o = sum e^(s - m) v (unnormalised) and stores {m, l, -, -, o[hd]} as f32; the consumer
 // GEMV merges the splits in its prologue (gemv_kernel / MergeIn). Same row-chunk ownership of the cached K / V rows as above.
 constexpr int AS_WAVES = 4;
 template <typename T, int CPR, int CR = CPR>
@@ -265,13 +305,23 @@ __global__ __launch_bounds__(AS_WAVES * 64) void attn_split_kernel(const T* __re
         for (int e = 0; e < EPV; ++e) qv[e] = to_f(qq[e]) * scale;
     }
     float mx = -INFINITY;
-    for (int jb = j0 + wave * KPW; jb < j1; jb += UR * STEP) {
+    const int jfirst = j0 + wave * KPW;
+    uint4 vpre[UR];                                        // V rows of the first (usually the only) block, requested together with its K rows
+    for (int jb = jfirst; jb < j1; jb += UR * STEP) {
         uint4 kraw[UR];
 #pragma unroll
         for (int r = 0; r < UR; ++r) {
             const int j = jb + r * STEP + grp;
             kraw[r] = uint4{0u, 0u, 0u, 0u};
             if (j < j1 && live) kraw[r] = *reinterpret_cast<const uint4*>(kc + (long)j * k_ss + h * HD + sub * EPV);
+        }
+        if (jb == jfirst) {
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int j = jb + r * STEP + grp;
+                vpre[r] = uint4{0u, 0u, 0u, 0u};
+                if (j < j1 && live) vpre[r] = *reinterpret_cast<const uint4*>(vc + (long)j * v_ss + h * HD + sub * EPV);
+            }
         }
 #pragma unroll
         for (int r = 0; r < UR; ++r) {
@@ -308,13 +358,16 @@ __global__ __launch_bounds__(AS_WAVES * 64) void attn_split_kernel(const T* __re
 #pragma unroll
     for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
     if (mx != -INFINITY)
-        for (int jb = j0 + wave * KPW; jb < j1; jb += UR * STEP) {
+        for (int jb = jfirst; jb < j1; jb += UR * STEP) {
             uint4 vraw[UR];
 #pragma unroll
             for (int r = 0; r < UR; ++r) {
                 const int j = jb + r * STEP + grp;
-                vraw[r] = uint4{0u, 0u, 0u, 0u};
-                if (j < j1 && live) vraw[r] = *reinterpret_cast<const uint4*>(vc + (long)j * v_ss + h * HD + sub * EPV);
+                vraw[r] = vpre[r];
+                if (jb != jfirst) {
+                    vraw[r] = uint4{0u, 0u, 0u, 0u};
+                    if (j < j1 && live) vraw[r] = *reinterpret_cast<const uint4*>(vc + (long)j * v_ss + h * HD + sub * EPV);
+                }
             }
 #pragma unroll
             for (int r = 0; r < UR; ++r) {
@@ -335,9 +388,9 @@ __global__ __launch_bounds__(AS_WAVES * 64) void attn_split_kernel(const T* __re
 #pragma unroll
         for (int e = 0; e < EPV; ++e) red[wave * HD + sub * EPV + e] = acc[e];
     __syncthreads();
-    float* rec = part + ((size_t)h * nsplit + sp) * (HD + 2);
+    float* rec = part + ((size_t)h * nsplit + sp) * (HD + 4);          // {m, l, -, -, o[HD]}: o starts 16-byte aligned
     if (t == 0) { rec[0] = mx; rec[1] = sum; }
-    if (t < HD) rec[2 + t] = (red[t] + red[HD + t]) + (red[2 * HD + t] + red[3 * HD + t]);
+    if (t < HD) rec[4 + t] = (red[t] + red[HD + t]) + (red[2 * HD + t] + red[3 * HD + t]);
 }
 
 }  // namespace
@@ -351,15 +404,25 @@ static int gemv_launch(const void* W, const void* x, const float* bias, void* y,
     PB_REQUIRE(((uintptr_t)W % 16 == 0) && ((uintptr_t)x % 16 == 0), "pb_gemv: operands must be 16-byte aligned");
     dim3 grid((N + 1) / 2), block(256);
     const float eps = 1e-5f;
+    const int nch = (K + 256 * epv - 1) / (256 * epv);
+    PB_REQUIRE(nch <= 4, "pb_gemv: K=%d exceeds %d", K, 4 * 256 * epv);
+#define PB_GEMV_GO(TT, TO, NCH_, MG_)                                                                                                      \
+    hipLaunchKernelGGL((gemv_kernel<TT, TO, NCH_, MG_>), grid, block, 0, stream, (const TT*)W, (const TT*)x, bias, (TO*)y, (TO*)y2, n_split, N, K, \
+                       gelu, (const TT*)ln.res, ln.gamma, ln.beta, (TT*)ln.out, eps, mg)
+#define PB_GEMV_NCH(TT, TO)                                                                                   \
+    do {                                                                                                      \
+        if (mg.part) { PB_REQUIRE(nch <= 1, "pb_gemv: the split-merge prologue needs K <= %d", 256 * epv); PB_GEMV_GO(TT, TO, 1, true); } \
+        else if (nch <= 1) PB_GEMV_GO(TT, TO, 1, false);                                                      \
+        else if (nch == 2) PB_GEMV_GO(TT, TO, 2, false);                                                      \
+        else PB_GEMV_GO(TT, TO, 4, false);                                                                    \
+    } while (0)
     if (dtype == PB_BF16) {
-        if (y_f32) hipLaunchKernelGGL((gemv_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)W, (const bf16_t*)x, bias, (float*)y, (float*)y2, n_split, N, K, gelu,
-                                      (const bf16_t*)ln.res, ln.gamma, ln.beta, (bf16_t*)ln.out, eps, mg);
-        else hipLaunchKernelGGL((gemv_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)W, (const bf16_t*)x, bias, (bf16_t*)y, (bf16_t*)y2, n_split, N, K, gelu,
-                                (const bf16_t*)ln.res, ln.gamma, ln.beta, (bf16_t*)ln.out, eps, mg);
+        if (y_f32) PB_GEMV_NCH(bf16_t, float); else PB_GEMV_NCH(bf16_t, bf16_t);
     } else {
-        hipLaunchKernelGGL((gemv_kernel<float, float>), grid, block, 0, stream, (const float*)W, (const float*)x, bias, (float*)y, (float*)y2, n_split, N, K, gelu,
-                           (const float*)ln.res, ln.gamma, ln.beta, (float*)ln.out, eps, mg);
+        PB_GEMV_NCH(float, float);
     }
+#undef PB_GEMV_NCH
+#undef PB_GEMV_GO
     PB_LAUNCH_CHECK();
     return 0;
 }
@@ -401,7 +464,7 @@ extern "C" int pb_attn_decode(const void* q, const void* k_cache, const void* v_
     return 0;
 }
 
-// key-split single-query attention into `part` (H * nsplit records of hd + 2 floats); returns the number of splits used
+// key-split single-query attention into `part` (H * nsplit records of hd + 4 floats); returns the number of splits used
 template <typename T, int CPR, int CR = CPR>
 static void attn_split_launch(const void* q, const void* kc, const void* vc, float* part, const float* key_mask, int H, int Sk, int chunk, int nsplit,
                               long k_ss, long v_ss, float scale, hipStream_t stream) {
@@ -455,7 +518,7 @@ extern "C" int pb_decode_step(const pb_decode_plan* p, int32_t i, void* stream) 
         int ns = 0;
         if (p->attn_part) {                                // keys split over workgroups, merged in the out-projection's prologue
             if (attn_split(p->q, kvs, kvs + (size_t)d * esz, p->attn_part, nullptr, H, i + 1, hd, 2 * d, 2 * d, scale, dt, st, ns)) return -1;
-            if (gemv_launch(L.wo, p->ctx, L.bo, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, MergeIn{p->attn_part, ns, hd, hd + 2})) return -1;
+            if (gemv_launch(L.wo, p->ctx, L.bo, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, MergeIn{p->attn_part, ns, hd, hd + 4})) return -1;
         } else {
             if (pb_attn_decode(p->q, kvs, kvs + (size_t)d * esz, p->ctx, nullptr, H, i + 1, hd, 2 * d, 2 * d, scale, dt, stream)) return -1;
             if (pb_gemv(L.wo, p->ctx, L.bo, p->a, d, d, dt, 0, 0, stream)) return -1;
@@ -465,7 +528,7 @@ extern "C" int pb_decode_step(const pb_decode_plan* p, int32_t i, void* stream) 
         if (gemv_launch(L.wq_c, p->a, L.bq_c, p->q, nullptr, d, d, d, dt, 0, 0, st, ln)) return -1;
         if (p->attn_part) {
             if (attn_split(p->q, L.kv_cross, (const char*)L.kv_cross + (size_t)d * esz, p->attn_part, p->enc_mask, H, p->S_enc, hd, 2 * d, 2 * d, scale, dt, st, ns)) return -1;
-            if (gemv_launch(L.wo_c, p->ctx, L.bo_c, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, MergeIn{p->attn_part, ns, hd, hd + 2})) return -1;
+            if (gemv_launch(L.wo_c, p->ctx, L.bo_c, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, MergeIn{p->attn_part, ns, hd, hd + 4})) return -1;
         } else {
             if (pb_attn_decode(p->q, L.kv_cross, (const char*)L.kv_cross + (size_t)d * esz, p->ctx, p->enc_mask, H, p->S_enc, hd, 2 * d, 2 * d, scale, dt, stream)) return -1;
             if (pb_gemv(L.wo_c, p->ctx, L.bo_c, p->a, d, d, dt, 0, 0, stream)) return -1;

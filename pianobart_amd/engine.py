@@ -813,7 +813,7 @@ class Engine:
             for n, t in rows.items():
                 setattr(plan, n, P(t))
             plan.stat, plan.logits, plan.head_w, plan.head_b = P(stat), P(logits), P(self.w['head.w']), P(wf['head.b'])
-            attn_part = torch.empty(self.H * 16 * (self.hd + 2), dtype=torch.float32, device=dev)      # PB_DECODE_MAX_SPLITS records per head
+            attn_part = torch.empty(self.H * 16 * (self.hd + 4), dtype=torch.float32, device=dev)      # PB_DECODE_MAX_SPLITS records per head
             plan.attn_part = P(attn_part) if _DECODE_SPLIT else None
             for l in range(self.ND):
                 pf, L = 'dec.%d.' % l, plan.layers[l]
