@@ -246,67 +246,66 @@ class FinetuneTrainer:
             shutil.copyfile(filename, filename.split('.')[0] + '_best.ckpt')
 
 
-def finetune(argv=None):
-    """main.py:103-215."""
-    import pickle
-    import random
+def _finetune_loaders(args):
+    """The three DataLoaders of main.py:126-141 (train shuffled) + the shape of the test labels."""
     from torch.utils.data import DataLoader
+    X_train, X_val, X_test, y_train, y_val, y_test = load_data_finetune(args.dataset, args.task, args.dataroot)
+    loaders = [DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=shuffle)
+               for X, y, shuffle in ((X_train, y_train, True), (X_val, y_val, False), (X_test, y_test, False))]
+    for tag, ld in zip(('train', 'valid', 'valid'), loaders):                  # the reference prints "valid_loader" twice
+        print('   len of %s_loader' % tag, len(ld))
+    return loaders, y_test.shape
+
+
+def finetune(argv=None):
+    """The classification fine-tune driver (reference: main.py:103-215): seeds 2023, the reference's flags, prints, checkpoint keys
+    and log lines; best model = highest validation accuracy (ties count), stop after 4 epochs without one."""
+    import random
     from .model import BartConfig, PianoBart
-    seed = 2023
-    torch.manual_seed(seed)
-    np.random.seed(seed)
-    random.seed(seed)
+    from .pretrain import _load_vocab
+    for seed_fn in (torch.manual_seed, np.random.seed, random.seed):
+        seed_fn(2023)
     args = get_args_finetune(argv)
     print('Loading Dictionary')
-    with open(args.dict_file, 'rb') as f:
-        e2w, w2e = pickle.load(f)
+    e2w, w2e = _load_vocab(args.dict_file)
     print('\nLoading Dataset')
-    seq_class = args.task in ('composer', 'emotion')
-    X_train, X_val, X_test, y_train, y_val, y_test = load_data_finetune(args.dataset, args.task, args.dataroot)
-    mk = lambda X, y, sh: DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=sh)
-    train_loader, valid_loader, test_loader = mk(X_train, y_train, True), mk(X_val, y_val, False), mk(X_test, y_test, False)
-    print('   len of train_loader', len(train_loader))
-    print('   len of valid_loader', len(valid_loader))
-    print('   len of valid_loader', len(test_loader))
+    (train_loader, valid_loader, test_loader), test_shape = _finetune_loaders(args)
     print('\nBuilding BART model')
-    configuration = BartConfig(max_position_embeddings=args.max_seq_len, d_model=args.hs, encoder_layers=args.layers, encoder_ffn_dim=args.ffn_dims,
-                               encoder_attention_heads=args.heads, decoder_layers=args.layers, decoder_ffn_dim=args.ffn_dims,
-                               decoder_attention_heads=args.heads)
-    pianobart = PianoBart(bartConfig=configuration, e2w=e2w, w2e=w2e, precision=args.precision)
-    best_mdl = ''
-    if not args.nopretrain:
-        best_mdl = args.ckpt
+    shape = dict(max_position_embeddings=args.max_seq_len, d_model=args.hs)
+    for side in ('encoder', 'decoder'):
+        shape.update({side + '_layers': args.layers, side + '_ffn_dim': args.ffn_dims, side + '_attention_heads': args.heads})
+    pianobart = PianoBart(bartConfig=BartConfig(**shape), e2w=e2w, w2e=w2e, precision=args.precision)
+    best_mdl = '' if args.nopretrain else args.ckpt
+    if best_mdl:
         print('   Loading pre-trained model from', best_mdl.split('/')[-1])
-        pianobart.load_state_dict(torch.load(best_mdl, map_location='cpu')['state_dict'])
+        pianobart.load_state_dict(torch.load(best_mdl, map_location='cpu', weights_only=False)['state_dict'])
     print('\nCreating Finetune Trainer')
-    trainer = FinetuneTrainer(pianobart, train_loader, valid_loader, test_loader, args.lr, args.class_num, args.hs, y_test.shape, args.cpu,
-                              args.cuda_devices[:1], None, seq_class, args.error_correction, args.weight)
+    trainer = FinetuneTrainer(pianobart, train_loader, valid_loader, test_loader, args.lr, args.class_num, args.hs, test_shape, args.cpu,
+                              args.cuda_devices[:1], None, args.task in ('composer', 'emotion'), args.error_correction, args.weight)
     print('\nTraining Start')
     save_dir = os.path.join('result/finetune/', args.task + '_' + args.name)
     os.makedirs(save_dir, exist_ok=True)
     filename = os.path.join(save_dir, 'model.ckpt')
     print('   save model at {}'.format(filename))
-    best_acc, best_epoch, bad_cnt = 0, 0, 0
-    with open(os.path.join(save_dir, 'log'), 'a') as outfile:
-        outfile.write('Loading pre-trained model from ' + best_mdl.split('/')[-1] + '\n')
+    best_acc, stale = 0, 0
+    with open(os.path.join(save_dir, 'log'), 'a') as log:
+        log.write('Loading pre-trained model from ' + best_mdl.split('/')[-1] + '\n')
         for epoch in range(args.epochs):
-            train_loss, train_acc = trainer.train()
-            valid_loss, valid_acc = trainer.valid()
+            (train_loss, train_acc), (valid_loss, valid_acc) = trainer.train(), trainer.valid()
             test_loss, test_acc, _ = trainer.test()
             is_best = valid_acc >= best_acc
             best_acc = max(valid_acc, best_acc)
-            if is_best:
-                bad_cnt, best_epoch = 0, epoch
-            else:
-                bad_cnt += 1
+            stale = 0 if is_best else stale + 1
             print('epoch: {}/{} | Train Loss: {} | Train acc: {} | Valid Loss: {} | Valid acc: {} | Test loss: {} | Test acc: {}'.format(
                 epoch + 1, args.epochs, train_loss, train_acc, valid_loss, valid_acc, test_loss, test_acc))
             trainer.save_checkpoint(epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename)
-            outfile.write('Epoch {}: train_loss={}, valid_loss={}, test_loss={}, train_acc={}, valid_acc={}, test_acc={}\n'.format(
+            log.write('Epoch {}: train_loss={}, valid_loss={}, test_loss={}, train_acc={}, valid_acc={}, test_acc={}\n'.format(
                 epoch + 1, train_loss, valid_loss, test_loss, train_acc, valid_acc, test_acc))
-            if bad_cnt > 3:
+            log.flush()
+            if stale > 3:
                 print('valid acc not improving for 3 epochs')
                 break
+    return trainer
 
 
 if __name__ == '__main__':

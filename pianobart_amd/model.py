@@ -119,7 +119,11 @@ class Embeddings(nn.Module):
         self.d_model = d_model
 
     def forward(self, x):
-        raise PBError('Embeddings.forward is fused into the Octuple gather-sum HIP kernel; call PianoBart instead')
+        """lut(x) * sqrt(d_model) (PianoBart.py:15-16) for direct callers: a HIP row gather + scale, differentiable in `lut`. Inside
+        PianoBart.forward the eight embeddings never run on their own: they are folded into the projected Octuple table."""
+        from . import heads
+        e = heads.gather_rows(self.lut.weight, x)
+        return heads.mul(e, torch.full_like(e, math.sqrt(self.d_model)))
 
 
 def _check_cfg(cfg):
@@ -218,7 +222,11 @@ class MLM(nn.Module):
         self.e2w = e2w
 
     def forward(self, y):
-        raise PBError('MLM.forward is fused into PianoBartLM.forward (one d x 1280 HIP GEMM)')
+        """model.py:119-126 for direct callers: y = pianobart(...) output (anything with .last_hidden_state) or a (B,S,d) tensor ->
+        list of 8 (B,S,n_i) f32 logits through the exact-f32 HIP GEMM. PianoBartLM.forward runs the 8 heads as ONE fused GEMM instead."""
+        from . import heads
+        h = y.last_hidden_state if hasattr(y, 'last_hidden_state') else y
+        return [heads.linear(h, self.proj[i].weight, self.proj[i].bias) for i, _ in enumerate(self.e2w)]
 
 
 # -- nucleus sampling: host-side numpy exactly like the reference, so the RNG stream matches ----------

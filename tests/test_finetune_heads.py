@@ -261,3 +261,34 @@ def test_head_adamw_leaves_parameters_without_gradient_alone():
     for p, r in zip(ps, ref):
         assert _rel(p.detach(), r) < 1e-6
     assert dead.data_ptr() < opt.P.data_ptr() or dead.data_ptr() >= opt.P.data_ptr() + 4 * opt.P.numel()
+
+
+@pytest.mark.gpu
+def test_embeddings_and_mlm_forward_for_direct_callers():
+    """Embeddings.forward (PianoBart.py:15-16) and MLM.forward (model.py:119-126) are fused away inside PianoBart / PianoBartLM but
+    stay callable on their own, with gradients, and agree with the oracle; MLM on the backbone's hidden state reproduces the fused
+    8-head GEMM of PianoBartLM.forward."""
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a HIP device')
+    from oracle import pianobart_oracle as O
+    from pianobart_amd import model as M
+    m = M.PianoBartLM(M.PianoBart(M.BartConfig(**KW), E2W, W2E, precision='fp32'))
+    randomize_params(m, 5)
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(**KW), E2W, W2E))
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda().eval(); o = o.eval()
+    ids = torch.randint(0, 134, (2, 7))
+    e = m.pianobart.word_emb[1](ids.cuda())
+    eo = o.pianobart.word_emb[1](ids)
+    assert _rel(e.detach(), eo.detach()) < 1e-6
+    e.sum().backward()
+    eo.sum().backward()
+    assert _rel(m.pianobart.word_emb[1].lut.weight.grad, o.pianobart.word_emb[1].lut.weight.grad) < 1e-6
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(2, S, seed=4)
+    with torch.no_grad():
+        fused = m(enc.cuda(), dec.cuda(), emask.cuda(), dmask.cuda())
+        y = m.pianobart(enc.cuda(), dec.cuda(), emask.cuda(), dmask.cuda())
+        sep = m.mask_lm(y)
+        ref = o(enc, dec, emask, dmask)
+    for a, b, r in zip(sep, fused, ref):
+        assert a.shape == b.shape and _rel(a, b) < 1e-5 and _rel(a, r) < 1e-4
