@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, cons
     const T* w1 = W + (long)(two ? n0 + 1 : n0) * K;
     typedef typename VecOf<T>::type V;                                     // EPV elements = 16 bytes, kept as a register vector (no address taken)
     const V zero4 = V{};
+    const float bias_v = (threadIdx.x < 2 && (threadIdx.x == 0 || two) && bias) ? bias[n0 + threadIdx.x] : 0.f;   // requested with everything else
     V u0[NCH], u1[NCH], xr[NCH], rr[NCH];
     f32x4 gm[NCH][EPV / 4], bt[NCH][EPV / 4];
 #pragma unroll
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ W, cons
     __syncthreads();
     if (threadIdx.x < 2 && (threadIdx.x == 0 || two)) {
         const int n = n0 + threadIdx.x;
-        float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] + (bias ? bias[n] : 0.f);
+        float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] + bias_v;
         if (gelu) v = gelu_f(v);
         if (n < n_split) y[n] = from_f<TO>(v); else y2[n - n_split] = from_f<TO>(v);
     }
