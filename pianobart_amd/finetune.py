@@ -103,13 +103,22 @@ class HeadAdamW:
         self.steps = [0] * len(self.params)                                # per-parameter step counts, as in the HF optimizer state
         self.lr, self.wd, self.betas, self.eps, self.t = lr, weight_decay, betas, eps, 0
 
-    def step(self):
+    def gather_grads(self):
+        """Copy every parameter's .grad into the flat gradient buffer (what a data-parallel caller all-reduces before step)."""
+        for p, (o, n) in zip(self.params, self.views):
+            if p.grad is not None:
+                self.G[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            else:
+                self.G[o:o + n].zero_()
+
+    def step(self, gathered=False):
         self.t += 1
         runs = []                                                          # (offset, length, step): neighbours with a gradient and equal step count
         for i, (p, (o, n)) in enumerate(zip(self.params, self.views)):
             if p.grad is None:
                 continue
-            self.G[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            if not gathered:
+                self.G[o:o + p.numel()].copy_(p.grad.reshape(-1))
             self.steps[i] += 1
             if runs and runs[-1][0] + runs[-1][1] == o and runs[-1][2] == self.steps[i]:
                 runs[-1] = (runs[-1][0], runs[-1][1] + n, self.steps[i])
@@ -126,12 +135,14 @@ class HeadAdamW:
 
 class FinetuneTrainer:
     def __init__(self, pianobart, train_dataloader, valid_dataloader, test_dataloader, lr, class_num, hs, testset_shape, cpu,
-                 cuda_devices=None, model=None, SeqClass=False, error=False, weight=None):
+                 cuda_devices=None, model=None, SeqClass=False, error=False, weight=None, data_parallel=None):
         if cpu or not torch.cuda.is_available():
             raise PBError('pianobart_amd has no CPU execution path')
         if cuda_devices is not None and len(cuda_devices) > 1:
             raise PBError('nn.DataParallel is replaced by one process per GPU (torch.distributed.run)')
-        self.device = torch.device('cuda', cuda_devices[0] if cuda_devices else 0)
+        dev_id = int(os.environ['LOCAL_RANK']) if 'LOCAL_RANK' in os.environ else (cuda_devices[0] if cuda_devices else 0)
+        self.device = torch.device('cuda', dev_id)
+        torch.cuda.set_device(self.device)
         print('   device:', self.device)
         self.pianobart, self.SeqClass, self.class_num = pianobart, SeqClass, class_num
         if model is not None:
@@ -148,6 +159,17 @@ class FinetuneTrainer:
         self.head_optim = HeadAdamW([p for p in self.model.parameters() if id(p) not in in_engine], lr=lr, weight_decay=0.01,
                                     never=[pianobart.bart.shared.weight])      # never read, never a gradient (SURVEY a-3)
         self.lr = lr
+        # one process per GPU (torch.distributed.run): every rank steps its own mini-batch, gradients are AVERAGED over the ranks -- the
+        # backbone's through the engine's bucket exchange (summed, then scaled by 1 / world in the optimizer step), the head parameters'
+        # with one all-reduce of the head optimizer's flat gradient buffer. data_parallel=True installs this at world size 1 (tests).
+        self.world = int(os.environ.get('WORLD_SIZE', 1))
+        self.reducer = None
+        if self.world > 1 or data_parallel:
+            import torch.distributed as dist
+            from .parallel import GradReducer
+            if not dist.is_initialized():
+                dist.init_process_group('nccl', device_id=self.device)
+            self.reducer = GradReducer(self.engine, self.world)
         self.testset_shape = testset_shape if not error else testset_shape[:-1]
         self.error = error
         self.weight = weight
@@ -165,10 +187,16 @@ class FinetuneTrainer:
             if not p.is_cuda or p.dtype != torch.float32 or not p.data.is_contiguous():
                 raise PBError('l2_penalty: parameters must be contiguous f32 HIP tensors')
             g = None
+            i = self._engine_slot.get(id(p))
             if with_grad:
-                i = self._engine_slot.get(id(p))
                 g = self.engine.grad_views[i] if i is not None else p.grad
-            ops.l2_penalty(p.data, g, self.weight, self._l2_scratch, self._l2_acc)
+            # data parallel: the backbone's flat gradient holds the SUM over ranks and is scaled by 1 / world in the optimizer step,
+            # so the (rank-independent) penalty gradient enters it world times; the reported value is not affected
+            if with_grad and i is not None and self.world > 1:
+                ops.l2_penalty(p.data, None, self.weight, self._l2_scratch, self._l2_acc)
+                ops.l2_penalty(p.data, g, self.weight * self.world, self._l2_scratch, None)
+            else:
+                ops.l2_penalty(p.data, g, self.weight, self._l2_scratch, self._l2_acc)
         return self._l2_acc
 
     def compute_loss(self, predict, target, loss_mask, seq):
@@ -224,16 +252,23 @@ class FinetuneTrainer:
                     total_acc += float(torch.sum((y == output).float()))
                     total_cnt += y.shape[0]
                 loss = self.compute_loss(y_hat, y, attn, seq)
-                total_loss += float(loss)
+                total_loss += float(loss.detach())
                 if mode == 0:
                     self.model.zero_grad()
                     self.head_optim.zero_grad()
                     loss.backward()
+                    if self.reducer:
+                        self.reducer.all_reduce_grads()                      # the backbone buckets have been exchanged (summed) before anything else touches them
                 if self.weight is not None:                                  # the regulariser is part of the reported loss in every mode
                     total_loss += float(self.l2_penalty(mode == 0))
                 if mode == 0:
-                    self.engine.optimizer_step(lr=self.lr, max_norm=float('inf'))          # no clipping in fine-tune (finetune.py:227)
-                    self.head_optim.step()
+                    if self.reducer:
+                        import torch.distributed as dist
+                        self.head_optim.gather_grads()
+                        dist.all_reduce(self.head_optim.G)
+                        self.head_optim.G.mul_(1.0 / self.world)
+                    self.engine.optimizer_step(lr=self.lr, max_norm=float('inf'), gscale=1.0 / self.world)   # no clipping in fine-tune (finetune.py:227)
+                    self.head_optim.step(gathered=self.reducer is not None)
         res = (round(total_loss / len(training_data), 4), round(total_acc / total_cnt, 4))
         return res + (all_output,) if mode == 2 else res
 
