@@ -34,6 +34,16 @@ def train_flops_per_token(S, d, N, f, V=1280):
     return 3 * 2 * macs / S
 
 
+def train_flops_live_rows(Te, Td, pairs, d, N, f, V=1280):
+    """train_flops_per_token's graph restricted to the rows the step keeps (dead-row compaction): Te encoder-side and Td
+    decoder-side rows, pairs = (query, key) pairs covered by the encoder self-, decoder self- (causal) and cross-attention
+    (each pair costs 2 d MACs forward: QK^T and PV over all heads). With Te = Td = B S and pairs = (B S^2, B S^2 / 2, B S^2)
+    this is train_flops_per_token x B S."""
+    macs = (Te + Td) * 2048 * d + N * Te * (4 * d * d + 2 * d * f) + N * Td * (6 * d * d + 2 * d * f) + N * Te * 2 * d * d \
+        + N * 2 * d * (pairs[0] + pairs[1] + pairs[2]) + Td * d * V
+    return 3 * 2 * macs
+
+
 def synth_batch(B, S, seed, device):
     sys.path.insert(0, os.path.join(ROOT))
     from tests.golden_util import synth_octuple_batch
@@ -97,17 +107,24 @@ def cpu_baseline(cfgkw, S, timeout=170):
         return {"value": None, "unit": "tokens/s", "cores": None, "kind": "port", "sample": "oracle train step did not finish within %d s on this host" % timeout}
 
 
-def pmc_traffic(M, N, K):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_gemm_fc1_pmc.json,
-    FETCH_SIZE x2 + WRITE_SIZE, collected offline: counters cannot be read from inside this process). None if the shape differs."""
-    for name in ('r02_gemm_fc1_pmc.json', 'r01_gemm_fc1_pmc.json'):
+def pmc_traffic(Ms, N, K):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r0x_gemm_fc1_pmc*.json,
+    FETCH_SIZE x2 + WRITE_SIZE, collected offline: counters cannot be read from inside this process), averaged over the row counts
+    the step launches it with (packed step: the encoder-side and the decoder-side count). None unless every shape has a record."""
+    import glob
+    recs = []
+    for name in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_gemm_fc1_pmc*.json')), reverse=True):
         try:
-            j = json.load(open(os.path.join(ROOT, 'profiles', name)))
-            if 'M=%d N=%d K=%d' % (M, N, K) in j['kernel']:     # same kernel, same shape, same tile as the live timing
-                return j['hbm_bytes_per_launch'], 'profiles/' + name
+            recs.append((os.path.basename(name), json.load(open(name))))
         except Exception:
             pass
-    return None, None
+    vals, srcs = [], []
+    for M in Ms:
+        hit = [(n, j) for n, j in recs if 'M=%d N=%d K=%d' % (M, N, K) in j.get('kernel', '')]     # same kernel, same shape, same tile as the live timing
+        if not hit:
+            return None, None
+        vals.append(hit[0][1]['hbm_bytes_per_launch']); srcs.append('profiles/' + hit[0][0])
+    return sum(vals) / len(vals), ', '.join(sorted(set(srcs)))
 
 
 class StepProbe:
@@ -118,10 +135,11 @@ class StepProbe:
               'embed_ln_fwd': 'rows', 'embed_ln_bwd': 'rows', 'colsum': 'rows', 'batch_sum': 'rows', 'onehot_build': 'rows', 'dropout': 'rows',
               'ce_fwd_bwd': 'loss', 'mask_count': 'loss', 'loss_coef': 'loss', 'grad_sqnorm': 'optimizer', 'clip_coef': 'optimizer',
               'adamw_step': 'optimizer', 'fill_f32': 'optimizer', 'cast_f32_to_bf16': 'optimizer', 'defer_flush': 'rows', 'key_extent': 'rows',
-              'softmax_fwd': 'attention', 'softmax_bwd': 'attention'}
+              'softmax_fwd': 'attention', 'softmax_bwd': 'attention', 'flash_fwd_packed': 'attention', 'flash_bwd_packed': 'attention',
+              'rowmap_count': 'rows', 'rowmap_build': 'rows', 'gather_rows16': 'rows', 'pos_grad_packed': 'rows'}
 
-    def __init__(self, ops):
-        self.ops, self.saved, self.log = ops, {}, []
+    def __init__(self, ops, pairs=None):
+        self.ops, self.saved, self.log, self.pairs = ops, {}, [], pairs          # pairs: Engine.last_pairs (packed attention work)
 
     def _label(self, name, a, kw):
         if name == 'gemm':
@@ -137,6 +155,13 @@ class StepProbe:
             causal = a[off + 6]
             fl = 4.0 * B * H * Sq * Sk * hd * (0.5 if causal else 1.0) * (1.0 if name == 'flash_fwd' else 2.5)
             return '%s B%d H%d S%dx%d hd%d%s' % (name, B, H, Sq, Sk, hd, ' causal' if causal else ''), fl
+        if name in ('flash_fwd_packed', 'flash_bwd_packed'):
+            off = 5 if name == 'flash_fwd_packed' else 10
+            rows, B, H, hd = a[off:off + 4]
+            causal = a[off + 5]
+            pairs = self.pairs[{'enc': 0, 'dec': 1, 'cross': 2}[rows.kind]]
+            fl = 4.0 * H * hd * pairs * (1.0 if name == 'flash_fwd_packed' else 2.5)
+            return '%s B%d H%d packed rows (%s, max %dx%d) hd%d' % (name, B, H, rows.kind, rows.Sq_max, rows.Sk_max, hd), fl
         return name, 0.0
 
     def __enter__(self):
@@ -302,9 +327,12 @@ def main():
     tokens = B * S * world * args.steps
     value = tokens / dt
     fpt = train_flops_per_token(S, args.hs, args.layers, args.ffn)
-    step_tflops_per_gpu = fpt * B * S / (ms_per_step * 1e-3) / 1e12
+    ref_tflops_per_gpu = fpt * B * S / (ms_per_step * 1e-3) / 1e12               # the reference graph: every padded row credited
     peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3
     T = B * S
+    Te, Td, _ = eng.last_rows
+    live_flops = train_flops_live_rows(Te, Td, eng.last_pairs, args.hs, args.layers, args.ffn)
+    step_tflops_per_gpu = live_flops / (ms_per_step * 1e-3) / 1e12              # the rows and (query, key) pairs the step computes
 
     # ---- roofline of the dominant kernel AS LAUNCHED BY THE STEP (fc1: NT T x ffn x d + bias + GELU + derivative out), and the
     # per-family shares, from HIP events on the launch stream (one-stream schedule; after the timed region, rank 0 at N=1 only)
@@ -317,15 +345,17 @@ def main():
         try:
             step(); torch.cuda.synchronize()
             nprobe = 3
-            with StepProbe(ops) as probe:
+            with StepProbe(ops, eng.last_pairs) as probe:
                 probe.mark()
                 for _ in range(nprobe):
                     step()
                 torch.cuda.synchronize()
                 families, table, shapes = probe.summary(nprobe, peak)
-            key = [k for k in shapes if k.startswith('gemm NT %dx%dx%d+bias+gelu' % (T, args.ffn, args.hs))]
-            if key:
-                fc1_ms, fc1_n = shapes[key[0]][0] / shapes[key[0]][2], shapes[key[0]][2] / nprobe
+            key = [k for k in shapes if any(k.startswith('gemm NT %dx%dx%d+bias+gelu' % (m_, args.ffn, args.hs)) for m_ in {Te, Td})]
+            if key:                                                   # fc1 of the encoder (M = Te) and decoder (M = Td) layers
+                n_ = sum(shapes[k][2] for k in key)
+                fc1_ms, fc1_n = sum(shapes[k][0] for k in key) / n_, n_ / nprobe
+                fc1_flops = sum(shapes[k][1] for k in key) / n_
         finally:
             E._WGRAD_STREAM = saved
     # the same kernel alone, back to back on random operands with its real epilogue (flatters: warm Infinity Cache, no neighbours)
@@ -343,10 +373,10 @@ def main():
     e1.record(); torch.cuda.synchronize()
     iso_ms = e0.elapsed_time(e1) / nrep
     gemm_ms = fc1_ms if fc1_ms else iso_ms
-    gemm_tflops = 2.0 * T * args.ffn * args.hs / (gemm_ms * 1e-3) / 1e12
+    gemm_tflops = (fc1_flops if fc1_ms else 2.0 * T * args.ffn * args.hs) / (gemm_ms * 1e-3) / 1e12
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic(T, args.ffn, args.hs)
+        traffic, traffic_src = pmc_traffic(sorted({Te, Td}), args.ffn, args.hs)
         s = sums.double().cpu()
         w8 = torch.tensor([262, 134, 262, 134, 38, 135, 55, 260], dtype=torch.double)
         loss = float(((s[0:8] / s[8:16]) * w8).sum() / w8.sum())
@@ -357,16 +387,23 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "tokens_per_s_per_gpu": value / world,
             "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / peak,
+            "reference_graph_tflops_per_gpu": ref_tflops_per_gpu,
+            "rows": {"encoder_side": Te, "decoder_side": Td, "padded": T,
+                     "note": "dead-row compaction: rows that are neither visible as attention keys nor carry a loss term are dropped from the "
+                             "step (results unchanged, tests/test_packed_gpu.py); `value` counts all B x S tokens of the batch, the unit the "
+                             "reference's own tokens/s is in; step_tflops_per_gpu / step_mfma_frac / roofline count only the rows and "
+                             "(query, key) pairs that are computed; PB_PACK_ROWS=0 runs the dense step"},
             "train_loss": loss,
             "config": {"workload": "pretrain step %dL/%dd/ffn%d/%dh S=%d B=%d/GPU dropout=%s (BASELINE configs[1])" %
                        (args.layers, args.hs, args.ffn, args.heads, S, B, cfgkw['dropout']),
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world,
                        "flops_per_token_train": fpt,
-                       "flops_note": "algorithmic FLOPs of the reference graph (SURVEY 8d): full S^2 attention (causal at 1/2) is credited although the "
-                                     "kernels skip 64-key tiles that lie wholly in a sample's PAD tail (<= ~1.5 % of the step)"},
+                       "flops_note": "flops_per_token_train: algorithmic FLOPs of the reference graph (SURVEY 8d), full S^2 attention (causal at "
+                                     "1/2), every padded row; step_tflops_per_gpu uses the same graph restricted to the rows / pairs the step computes"},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "gemm3_kernel<%s,NT> (256x256 ping-pong) fc1 M=%d N=%d K=%d + bias + GELU + derivative out" % (args.precision, T, args.ffn, args.hs),
+                         "kernel": "gemm3_kernel<%s,NT> (256x256 ping-pong) fc1 M=%s N=%d K=%d + bias + GELU + derivative out" %
+                                   (args.precision, T if Te == T else '%d (encoder layers) / %d (decoder layers)' % (Te, Td), args.ffn, args.hs),
                          "avg_launch_ms": gemm_ms,
                          "how": ("HIP events around each of the %.0f fc1 launches of a step, inside the step (one-stream schedule)" % fc1_n) if fc1_ms
                                 else "isolated back-to-back launches (probe disabled)",

@@ -20,7 +20,7 @@ extern "C" {
 #define PB_F32 0
 #define PB_BF16 1
 
-#define PB_ABI_VERSION 2
+#define PB_ABI_VERSION 3
 int pb_abi_version(void);
 const char* pb_last_error(void);
 
@@ -42,6 +42,10 @@ const char* pb_last_error(void);
                                     persistent one-per-CU grid: what to ask for when other kernels (RCCL) hold CUs        */
 #define PB_GEMM_NO_192 8192      /* A/B runs: never pick the 256x192 tile                                                */
 #define PB_GEMM_FORCE_192 16384  /* A/B runs: always pick the 256x192 tile when the 256-row kernel is used               */
+#define PB_GEMM_TAIL_SPLIT 32768 /* 256x256 kernel: the tiles of a partly filled last round of the grid may be cut into K ranges that
+                                    occupy the idle CUs (f32 partials, finished by a second small launch); a cost model decides.
+                                    Pays for a caller that runs one GEMM at a time (N = 768 at 26 624 rows: +13-17 %); the training
+                                    step fills those CUs from its second stream and does not ask for it                   */
 typedef struct pb_gemm_desc {
     const void* A; const void* B; void* C;
     const float* bias;            /* per-n, may be NULL */
@@ -78,6 +82,18 @@ int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float* P, const 
                     const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
                     float* partials /*workspace, pb_ln_partials_floats()*/, void* dz_out, int32_t T, int32_t S, int32_t d,
                     int32_t dtype, uint64_t seed, uint32_t site, float p_drop, void* stream);
+/* the same two on packed rows (pb_rowmap_build): row r is row row_ids[r] = b*S + s of the padded batch, i.e. it sits at sequence
+ * position row_ids[r] % S and draws the dropout bits of that row (a packed step drops exactly what the padded step drops);
+ * T need not be a multiple of S. With dz_out the position-table gradient comes from pb_pos_grad_packed. */
+int pb_embed_ln_fwd_packed(const int16_t* ids16, const int32_t* row_ids, const float* P, const int32_t* seg_off,
+                           const float* lin_bias, const float* pos, const float* ln_w, const float* ln_b, void* y,
+                           float* mean, float* rstd, int32_t T, int32_t S, int32_t d, int32_t dtype, float eps,
+                           uint64_t seed, uint32_t site, float p_drop, void* stream);
+int pb_embed_ln_bwd_packed(const void* dy, const int16_t* ids16, const int32_t* row_ids, const float* P,
+                           const int32_t* seg_off, const float* lin_bias, const float* pos, const float* ln_w,
+                           const float* mean, const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma,
+                           float* dbeta, float* partials, void* dz_out, int32_t T, int32_t S, int32_t d, int32_t dtype,
+                           uint64_t seed, uint32_t site, float p_drop, void* stream);
 /* onehot (T,V) bf16 with ones at columns seg_off[i] + ids16[t][i] */
 int pb_onehot_build(const int16_t* ids16, const int32_t* seg_off /*host 8*/, void* out, int64_t T, int32_t V, void* stream);
 /* out[i] += sum_b x[b*Sd + i], i < Sd */
@@ -89,11 +105,19 @@ int64_t pb_ln_partials_floats(int32_t d);
 int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, const float* ln_b, void* y,
                   float* mean, float* rstd, int32_t T, int32_t d, int32_t dtype, float eps,
                   uint64_t seed, uint32_t site, float p_drop, void* stream);
+/* on packed rows: row r draws the dropout bits of row row_ids[r] of the padded batch */
+int pb_add_ln_fwd_packed(const void* res, const void* a, const float* ln_w, const float* ln_b, void* y,
+                         float* mean, float* rstd, const int32_t* row_ids, int32_t T, int32_t d, int32_t dtype, float eps,
+                         uint64_t seed, uint32_t site, float p_drop, void* stream);
 /* dres gets dz (accumulated into if accum_dres), da gets dz*dropmask; dgamma/dbeta/dbias_a are ADDED to. */
 int pb_add_ln_bwd(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
                   const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
                   float* partials, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32, int32_t accum_dres,
                   uint64_t seed, uint32_t site, float p_drop, void* stream);
+int pb_add_ln_bwd_packed(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
+                         const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
+                         float* partials, const int32_t* row_ids, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32,
+                         int32_t accum_dres, uint64_t seed, uint32_t site, float p_drop, void* stream);
 
 /* ---- bias gradients: out[n] += sum_t dy[t][n] --------------------------------------------------*/
 /* partials: workspace of at least pb_colsum_partials_floats(N) floats */
@@ -133,6 +157,41 @@ int pb_flash_bwd(const void* q, const void* k, const void* v, const void* o, con
                      kernels' epilogue registers; dbias_ws: pb_flash_bias_ws_floats(B, H, Sq, Sk, hd) floats */,
                  void* stream);
 int64_t pb_flash_bias_ws_floats(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd);
+
+/* ---- K4 on packed rows (dead-row compaction, head_dim 64 / 96 / 128) -----------------------------
+ * The PAD tail the reference computes and then masks (PianoBart.py:60-75: attention_mask hides rows as keys only) is dropped: the
+ * rows of the batch lie back to back. Batch b's query rows are rows q_off[b] .. q_off[b] + q_len[b] - 1 of q / o / dout / dq
+ * (row stride *_ss, element (row, h, c) at ptr[row*ss + h*hd + c]), its key rows k_off[b] .. k_off[b] + k_len[b] - 1 of
+ * k / v / dk / dv; the first k_vis[b] key rows of the batch are the visible ones (the rest receive no gradient and are seen
+ * by no query). causal: key row j is visible to query row i of the same batch iff j <= i (row indices within the batch) and
+ * j < k_vis[b]. Sq_max / Sk_max: maxima of q_len / k_len (grid and LDS sizing); lse and delta are (B, H, Sq_max) f32.
+ * dbias_ws: pb_flash_bias_ws_floats(B, H, Sq_max, Sk_max, hd) floats. All five descriptors are device int32 (B). */
+int pb_flash_fwd_packed(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* q_off,
+                        const int32_t* q_len, const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis,
+                        int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss,
+                        int64_t v_ss, int64_t o_ss, float scale, int32_t causal, void* stream);
+int pb_flash_bwd_packed(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                        void* dq, void* dk, void* dv, float* delta, const int32_t* q_off, const int32_t* q_len,
+                        const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H,
+                        int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss,
+                        int64_t dq_ss, int64_t dk_ss, int64_t dv_ss, float scale, int32_t causal,
+                        float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* stream);
+
+/* ---- row maps for the packed step (pb_rowmap.hip) ------------------------------------------------
+ * pb_rowmap_count: counts (B,4) int32 = {encoder rows visible as keys (emask != 0), decoder rows visible as keys (dmask != 0),
+ *   decoder live rows (visible, or loss_mask (B,S,8) row != 0), 1 iff the visible decoder positions are exactly 0 .. L-1}.
+ * pb_rowmap_build: batch b's packed rows off[b] .. off[b] + len[b] - 1 = its positions with mask != 0 (ascending), then those
+ *   with a loss term (loss_mask may be NULL), then its first remaining (dead) positions up to len[b]; row_src[r] = b*S + s and
+ *   row_pos[r] = s for packed row r, inv (B*S) = packed row of (b, s) or -1. len[b] must cover the first two classes.
+ * pb_gather_rows16: dst row r = src row row_src[r] (row_bytes a multiple of 16).
+ * pb_pos_grad_packed: out (S,d) f32 += sum_b x[inv[b][s]] (the position-table gradient; replaces pb_batch_sum). */
+int pb_rowmap_count(const float* emask, const float* dmask, const float* loss_mask, int32_t* counts, int32_t B, int32_t S,
+                    void* stream);
+int pb_rowmap_build(const float* mask, const float* loss_mask, const int32_t* off, const int32_t* len, int32_t* row_src,
+                    int32_t* row_pos, int32_t* inv, int32_t B, int32_t S, void* stream);
+int pb_gather_rows16(const void* src, const int32_t* row_src, void* dst, int64_t n_rows, int32_t row_bytes, void* stream);
+int pb_pos_grad_packed(const void* x, const int32_t* inv, float* out, int32_t B, int32_t S, int32_t d, int32_t dtype,
+                       void* stream);
 
 /* ---- K9: fused 8-segment log-softmax + CE + argmax + masked accuracy (+ dlogits) ----------------
  * Replaces pretrain.py:112-118,163-189 (np.argmax x8, CrossEntropyLoss x8, masked means).

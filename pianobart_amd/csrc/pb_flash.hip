@@ -405,11 +405,12 @@ int check_common(const char* who, int hd, long a, long b2, long c2, long d2) {
 }  // namespace
 
 int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int* kmax, int B, int H, int Sq, int Sk, int hd,
-                   long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream);
+                   long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream,
+                   const int* const* vl = nullptr);
 int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, const float* key_mask,
                    const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, int hd, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
-                   int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream);
+                   int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream, const int* const* vl = nullptr);
 
 namespace {
 __global__ void key_extent_kernel(const float* __restrict__ key_mask, int* __restrict__ kmax, int Sk) {
@@ -490,4 +491,33 @@ extern "C" int pb_flash_bwd(const void* q, const void* k, const void* v, const v
     FA_DISPATCH(hd, hipLaunchKernelGGL((fa_bwd_dq_kernel<HD>), gq, dim3(FA_THREADS), 3 * 64 * HD * 2 + 256, stream, a));
     PB_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- packed rows ("varlen"): the batch rows of different lengths lie back to back; see include/pianobart_hip.h
+extern "C" int pb_flash_fwd_packed(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* q_off, const int32_t* q_len,
+                                   const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H, int32_t Sq_max,
+                                   int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss, float scale,
+                                   int32_t causal, void* stream_) {
+    if (check_common("pb_flash_fwd_packed", hd, q_ss, k_ss, v_ss, o_ss)) return -2;
+    PB_REQUIRE(hd == 64 || hd == 96 || hd == 128, "pb_flash_fwd_packed: head_dim %d (64 / 96 / 128 only)", hd);
+    PB_REQUIRE(q_off && q_len && k_off && k_len && k_vis, "pb_flash_fwd_packed: the five row descriptors are required");
+    if (B <= 0 || H <= 0 || Sq_max <= 0) return 0;
+    const int* vl[4] = {q_off, q_len, k_off, k_len};
+    return pb_flash64_fwd(q, k, v, o, lse, nullptr, k_vis, B, H, Sq_max, Sk_max, hd, 0, q_ss, 0, k_ss, 0, v_ss, 0, o_ss, scale, causal & 1,
+                          (hipStream_t)stream_, vl);
+}
+
+extern "C" int pb_flash_bwd_packed(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                                   void* dk, void* dv, float* delta, const int32_t* q_off, const int32_t* q_len, const int32_t* k_off,
+                                   const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd,
+                                   int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss, int64_t dq_ss, int64_t dk_ss, int64_t dv_ss,
+                                   float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* stream_) {
+    if (check_common("pb_flash_bwd_packed", hd, q_ss, k_ss, v_ss, o_ss)) return -2;
+    PB_REQUIRE(hd == 64 || hd == 96 || hd == 128, "pb_flash_bwd_packed: head_dim %d (64 / 96 / 128 only)", hd);
+    PB_REQUIRE(q_off && q_len && k_off && k_len && k_vis, "pb_flash_bwd_packed: the five row descriptors are required");
+    PB_REQUIRE(dq_ss % 4 == 0, "pb_flash_bwd_packed: bad strides");
+    if (B <= 0 || H <= 0 || Sq_max <= 0) return 0;
+    const int* vl[4] = {q_off, q_len, k_off, k_len};
+    return pb_flash64_bwd(q, k, v, o, dout, lse, delta, nullptr, k_vis, dq, dk, dv, B, H, Sq_max, Sk_max, hd, 0, q_ss, 0, k_ss, 0, v_ss, 0, o_ss,
+                          0, dq_ss, 0, dk_ss, 0, dv_ss, scale, causal & 1, dbias_q, dbias_k, dbias_v, dbias_ws, (hipStream_t)stream_, vl);
 }

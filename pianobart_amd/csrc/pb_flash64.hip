@@ -26,7 +26,26 @@ struct Fa64Args {
     float scale; int causal;
     float* cs_q; float* cs_kv;        // bias-gradient partials (column sums of dQ | of dK, dV), or NULL
     const bf16_t* zeros;              // >= 16 bytes of zeros (source of the column chunks beyond head_dim in a partly filled image)
+    // packed rows ("varlen", pb_flash_*_packed): batch b's query rows are rows vl_q_off[b] .. + vl_q_len[b] - 1 of q / o / dout / dq (row
+    // stride *_ss; the batch strides are not used), its key rows vl_k_off[b] .. + vl_k_len[b] - 1 of k / v / dk / dv, of which the
+    // first kmax[b] are visible; Sq / Sk are the maxima over the batch (grid, LDS, and the row length of lse / delta). NULL: dense.
+    const int *vl_q_off, *vl_k_off, *vl_q_len, *vl_k_len;
 };
+
+// Packed rows: give the kernel body the view of ONE batch -- its own Sq / Sk and base pointers rebased so that the dense address
+// arithmetic (ptr + b * batch_stride + row * row_stride) lands on the batch's first packed row.
+__device__ __forceinline__ void varlen_localize(Fa64Args& p, int b) {
+    if (!p.vl_q_off) return;
+    const long qo = p.vl_q_off[b], ko = p.vl_k_off[b];
+    p.Sq = p.vl_q_len[b]; p.Sk = p.vl_k_len[b];
+    p.q += qo * p.q_ss - b * p.q_sb; p.k += ko * p.k_ss - b * p.k_sb; p.v += ko * p.v_ss - b * p.v_sb;
+    if (p.o) p.o += qo * p.o_ss - b * p.o_sb;
+    if (p.out) p.out += qo * p.o_ss - b * p.o_sb;
+    if (p.dout) p.dout += qo * p.o_ss - b * p.o_sb;
+    if (p.dq) p.dq += qo * p.dq_ss - b * p.dq_sb;
+    if (p.dk) p.dk += ko * p.dk_ss - b * p.dk_sb;
+    if (p.dv) p.dv += ko * p.dv_ss - b * p.dv_sb;
+}
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -193,15 +212,19 @@ __device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float c) {
 // is summed from the same bf16 p the PV product sees.
 constexpr float LAZY_THR = 8.0f;
 template <int HD>
-__global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
+__global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args pin) {
     constexpr int NB = (HD + 63) / 64, KS = HD / 32, DT = HD / 16, HDT = HD;
     using C = FaCfg<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
-    block_map((p.Sq + 127) / 128, p.H, p.B, rb, h, b);
+    block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b);
     const int q0 = rb * 128;
+    Fa64Args p = pin;
+    varlen_localize(p, b);
+    const int lse_ld = pin.Sq;                                            // row length of lse (B, H, Sq_max)
+    if (q0 >= p.Sq) return;                                               // packed rows: this batch has no such row block
     const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
     const bf16_t* K = p.k + b * p.k_sb + h * HDT;
     const bf16_t* V = p.v + b * p.v_sb + h * HDT;
@@ -214,7 +237,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
     unsigned* ldsFlag = reinterpret_cast<unsigned*>(ldsBias + ((p.Sk + 63) / 64) * 64);
     for (int tile = wave; tile < nt; tile += 4) {                        // one wave = one tile of keys
         const int key = tile * 64 + lane;
-        const bool vis = key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
+        const bool vis = key < (pin.vl_q_off ? kvis_end : p.Sk) && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
         ldsBias[key] = vis ? 0.f : -INFINITY;
         const bool allvis = __builtin_amdgcn_ballot_w64(vis) == ~0ull;
         if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
@@ -389,7 +412,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
                 bf16x4 r = {(bf16_t)(oacc[qt][dt][0] * inv), (bf16_t)(oacc[qt][dt][1] * inv), (bf16_t)(oacc[qt][dt][2] * inv), (bf16_t)(oacc[qt][dt][3] * inv)};
                 *reinterpret_cast<bf16x4*>(O + dt * 16 + g * 4) = r;
             }
-            if (g == 0) p.lse[((long)b * p.H + h) * p.Sq + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;   // m = the reference l was summed against
+            if (g == 0) p.lse[((long)b * p.H + h) * lse_ld + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;   // m = the reference l was summed against
         }
     }
 }
@@ -402,7 +425,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args p) {
 // applied once to dK. Only tiles on the causal diagonal compare. Pipeline as in the forward: DMA ring of {Q, dO}
 // tiles behind a counted vmcnt, raw barriers, transposed fragments by asm; -lse, -delta of the whole row sit in LDS.
 template <int HD>
-__global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
+__global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args pin) {
     constexpr int NB = (HD + 63) / 64, KS = HD / 32, DT = HD / 16, HDT = HD;
     using C = FaCfg<NB>;
     constexpr int KT = C::KT, BK_ = 64 * KT;
@@ -410,8 +433,19 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
-    block_map((p.Sk + BK_ - 1) / BK_, p.H, p.B, rb, h, b);
+    block_map((pin.Sk + BK_ - 1) / BK_, pin.H, pin.B, rb, h, b);
     const int k0 = rb * BK_;
+    Fa64Args p = pin;
+    varlen_localize(p, b);
+    const int lse_ld = pin.Sq;
+    if (k0 >= p.Sk) {                                                     // packed rows: no such key block in this batch; its bias-gradient partials are zeros
+        if (p.cs_kv && t < 2 * HDT) {
+            const int nkb0 = (pin.Sk + BK_ - 1) / BK_, dm = p.H * HDT;
+            float* row = p.cs_kv + (long)(b * nkb0 + rb) * 2 * dm + h * HDT;
+            row[t < HDT ? t : dm + t - HDT] = 0.f;
+        }
+        return;
+    }
     const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
     const bf16_t* K = p.k + b * p.k_sb + h * HDT;
     const bf16_t* V = p.v + b * p.v_sb + h * HDT;
@@ -424,7 +458,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
     float* ldsNL = reinterpret_cast<float*>(smem + C::NS * C::STB);       // -lse * log2(e) per query (-inf: row contributes nothing)
     float* ldsND = ldsNL + sqp;                                          // -delta per query
     for (int q = it0 * 64 + t; q < nt * 64; q += FT) {
-        const long li = ((long)b * p.H + h) * p.Sq + q;
+        const long li = ((long)b * p.H + h) * lse_ld + q;
         const float ls = q < p.Sq ? p.lse[li] : INFINITY;
         ldsNL[q] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
         ldsND[q] = q < p.Sq ? -p.delta[li] : 0.f;
@@ -559,7 +593,8 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
         for (int r = 0; r < 4; ++r) {
             const int key = k0 + wave * (16 * KT) + kt * 16 + g * 4 + r;
             if (key < p.Sk) {
-                const bool kvis = !p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f;    // a masked key receives no gradient
+                const bool kvis = pin.vl_q_off ? key < (p.kmax ? p.kmax[b] : p.Sk)                 // packed rows: the visible keys are a prefix
+                                               : (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);    // a masked key receives no gradient
                 bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HDT;
                 bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT;
 #pragma unroll
@@ -572,7 +607,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
             }
         }
     if (p.cs_kv) {      // bias gradients: column sums of the block's dK / dV rows -> partial row (b, key block), head h's columns
-        const int nkb = (p.Sk + BK_ - 1) / BK_, d_model = p.H * HDT;
+        const int nkb = (pin.Sk + BK_ - 1) / BK_, d_model = p.H * HDT;
         float* red = reinterpret_cast<float*>(smem);                      // [4 waves][2 HDT]: the tile ring is free after the last barrier
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -593,15 +628,22 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args p) {
 // and -delta are per-lane constants splatted into the initial accumulators, K / V tiles stream through the DMA ring, and a
 // tile that holds a masked key adds the 0 / -inf key bias before the exp2 (no select).
 template <int HD>
-__global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
+__global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args pin) {
     constexpr int NB = (HD + 63) / 64, KS = HD / 32, DT = HD / 16, HDT = HD;
     using C = FaCfg<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
-    block_map((p.Sq + 127) / 128, p.H, p.B, rb, h, b);
+    block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b);
     const int q0 = rb * 128;
+    Fa64Args p = pin;
+    varlen_localize(p, b);
+    const int lse_ld = pin.Sq;
+    if (q0 >= p.Sq) {                                                     // packed rows: no such row block in this batch; its bias-gradient partial is zero
+        if (p.cs_q && t < HDT) p.cs_q[(long)(b * ((pin.Sq + 127) / 128) + rb) * (p.H * HDT) + h * HDT + t] = 0.f;
+        return;
+    }
     const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
     const bf16_t* K = p.k + b * p.k_sb + h * HDT;
     const bf16_t* V = p.v + b * p.v_sb + h * HDT;
@@ -614,7 +656,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
     unsigned* ldsFlag = reinterpret_cast<unsigned*>(ldsBias + ((p.Sk + 63) / 64) * 64);
     for (int tile = wave; tile < nt; tile += 4) {
         const int key = tile * 64 + lane;
-        const bool vis = key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
+        const bool vis = key < (pin.vl_q_off ? kvis_end : p.Sk) && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
         ldsBias[key] = vis ? 0.f : -INFINITY;
         const bool allvis = __builtin_amdgcn_ballot_w64(vis) == ~0ull;
         if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
@@ -625,7 +667,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         myq[qt] = q0 + wave * 32 + qt * 16 + lr;
-        const long li = ((long)b * p.H + h) * p.Sq + myq[qt];
+        const long li = ((long)b * p.H + h) * lse_ld + myq[qt];
         const float ls = myq[qt] < p.Sq ? p.lse[li] : INFINITY;
         nl[qt] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
         // delta = rowsum(dO . O) of this lane's query, computed here (this kernel owns whole query rows and already holds dO) and
@@ -751,7 +793,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args p) {
             }
         }
     if (p.cs_q) {       // bias gradient of the q projection: the 16 lanes of a DPP row hold 16 queries of the same 4 columns
-        const int nqb = (p.Sq + 127) / 128, d_model = p.H * HDT;
+        const int nqb = (pin.Sq + 127) / 128, d_model = p.H * HDT;
         float* red = reinterpret_cast<float*>(smem);                      // [4 waves][HDT]
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -799,8 +841,10 @@ static int fa64_fwd_launch(const Fa64Args& a, hipStream_t stream) {
 }
 
 int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask, const int* kmax, int B, int H, int Sq, int Sk, int hd,
-                   long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream) {
+                   long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream,
+                   const int* const* vl) {
     Fa64Args a = {};
+    if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; }
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal;
@@ -828,8 +872,9 @@ static int fa64_bwd_launch(const Fa64Args& a, hipStream_t stream) {
 int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, const float* key_mask,
                    const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, int hd, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
-                   int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream) {
+                   int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream, const int* const* vl) {
     Fa64Args a = {};
+    if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; }
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dout = (const bf16_t*)dout;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;

@@ -37,6 +37,11 @@ struct Gemm2Args {
     int nb2; long sA1, sA2, sB1, sB2, sC1, sC2, sCz;
     float alpha; int flags; int tiles_m, tiles_n, nsplit;
     float* cs_ws;                         // column-sum partials (2 tiles_m rows of N floats) or NULL
+    // tail split (gemm3_kernel, nsplit == 1): work items 0 .. n_full - 1 are whole tiles; the tiles of the last, partly filled
+    // round of the persistent grid are cut into tail_split K ranges each, one work item per range, whose f32 partial tiles go
+    // to tail_slabs (item-major, 256 x BN floats each) and are summed, finished and stored by tail_finish_kernel.
+    int n_full, tail_split, tail_kc;
+    float* tail_slabs;
 };
 
 __device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
@@ -398,15 +403,26 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     // Persistent over the (split, tile) work list: workgroup b takes items b, b + grid, ... (grid = a multiple of 8, so an item's
     // XCD chunk in block_tile stays the workgroup's XCD). The first DMA pieces of the NEXT item are issued right after the last
     // barrier of the current one, i.e. before its epilogue: the ~2 us from first DMA to first MFMA hide under the store tail.
-    const int total = p.tiles_m * p.tiles_n * p.nsplit;
+    const int ntile = p.tiles_m * p.tiles_n * p.nsplit;
+    const int total = p.tail_split > 1 ? p.n_full + (ntile - p.n_full) * p.tail_split : ntile;
     int L = blockIdx.x;
-    int m0, n0, zs;
-    block_tile<256, BNT>(p, L, m0, n0, zs);
+    int m0, n0, zs, kbeg, nk;
+    auto item = [&](int l) {
+        if (!(p.tail_split > 1 && l >= p.n_full)) {
+            block_tile<256, BNT>(p, l, m0, n0, zs);
+            kbeg = zs * p.Kc;
+            nk = max(0, min(p.K, kbeg + p.Kc) - kbeg) / BK;
+        } else {
+            const int u = l - p.n_full, ks = u % p.tail_split;
+            block_tile<256, BNT>(p, p.n_full + u / p.tail_split, m0, n0, zs);
+            kbeg = ks * p.tail_kc;
+            nk = max(0, min(p.K, kbeg + p.tail_kc) - kbeg) / BK;
+        }
+    };
+    item(L);
     const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
-    int kbeg = zs * p.Kc;
-    int nk = max(0, min(p.K, kbeg + p.Kc) - kbeg) / BK;
 
     f32x4 acc[8][TNW];
 #pragma unroll
@@ -544,18 +560,29 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         const int em0 = m0, en0 = n0;
         const float* ebias = reinterpret_cast<const float*>(smem + 2 * SLOT + bslot * 1024) + wc * GSB;
         const long ecoff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
+        const int eL = L;
         L += gridDim.x;
         const bool more = L < total;
         if (more) {
-            block_tile<256, BNT>(p, L, m0, n0, zs);
-            kbeg = zs * p.Kc;
-            nk = max(0, min(p.K, kbeg + p.Kc) - kbeg) / BK;
+            item(L);
             G3_PROLOGUE();
         }
-        if (!(p.flags & 128)) epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias,
-                                                   p.cs_ws ? p.cs_ws + (long)((em0 >> 8) * 2 + wr) * p.N : nullptr);   // bit 7: profiling build without the epilogue
+        const bool etail = p.tail_split > 1 && eL >= p.n_full;       // the finished item was one K range of a tail tile
+        if (etail) {
+            // a tail item dumps its accumulators in register order (1 KiB per wave instruction); tail_finish_kernel knows the layout
+            float* dst = p.tail_slabs + (long)(eL - p.n_full) * (256 * BNT) + wave * (8 * TNW * 256) + lane * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) *reinterpret_cast<f32x4*>(dst + (i * TNW + j) * 256) = acc[i][j] * p.alpha;
+        } else if (!(p.flags & 128)) {                                 // bit 7: profiling build without the epilogue
+            epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias,
+                                  p.cs_ws ? p.cs_ws + (long)((em0 >> 8) * 2 + wr) * p.N : nullptr);
+        }
         if (!more) break;
-        {   // an interior tile without read-modify-write issues exactly 8 x 2 (x 2 for f32 C or the GELU pair) stores per wave
+        if (etail) {
+            pend = 8 * TNW == 32 ? 32 : 0;                            // 8 x TNW plain 16-byte stores per wave
+        } else {   // an interior tile without read-modify-write issues exactly 8 x 2 (x 2 for f32 C or the GELU pair) stores per wave
             const bool interior = em0 + 256 <= p.M && en0 + BNT <= p.N;
             const bool plain = !(p.flags & (PB_GEMM_ACCUM | PB_GEMM_MUL_GELU_GRAD | 128));
             pend = (interior && plain) ? (((p.flags & PB_GEMM_C_F32) || (p.flags & PB_GEMM_GELU)) ? 32 : 16) : 0;
@@ -585,6 +612,39 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
+// Sums the tail_split partial tiles of every tail tile and finishes them like epilogue_regs would have: alpha is already in the
+// partials; + bias, (+= C), store bf16 / f32. One workgroup per tail tile. The partials lie in the register order of gemm3_kernel
+// (wave, i, j, lane): float4 number q of a tile belongs to wave w = q / (8 TNW 64), row tile i, column tile j, lane l, i.e. to
+// C[wr*128 + i*16 + (l & 15)][wc*16*TNW + j*16 + (l >> 4)*4 .. +3] with wr = w >> 2, wc = w & 3.
+constexpr int TAIL_FIN_PARTS = 16;                                  // workgroups per tail tile (a tile is 64 K float4s)
+template <int TNW>
+__global__ __launch_bounds__(256) void tail_finish_kernel(const Gemm2Args p) {
+    constexpr int BNT = 64 * TNW, PER = 8 * 8 * TNW * 64;             // float4s per tile
+    const int t_ = blockIdx.x / TAIL_FIN_PARTS, part = blockIdx.x % TAIL_FIN_PARTS, tile = p.n_full + t_;
+    int m0, n0, zs;
+    block_tile<256, BNT>(p, tile, m0, n0, zs);
+    const float* slab = p.tail_slabs + (long)t_ * p.tail_split * (256 * BNT);
+    const bool accum = p.flags & PB_GEMM_ACCUM, c32 = p.flags & PB_GEMM_C_F32;
+    for (int q = part * (PER / TAIL_FIN_PARTS) + threadIdx.x; q < (part + 1) * (PER / TAIL_FIN_PARTS); q += 256) {
+        const int l = q & 63, ij = (q >> 6) % (8 * TNW), w = q / (64 * 8 * TNW);
+        const int row = m0 + (w >> 2) * 128 + (ij / TNW) * 16 + (l & 15), col = n0 + (w & 3) * (16 * TNW) + (ij % TNW) * 16 + (l >> 4) * 4;
+        if (row >= p.M || col >= p.N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + 4 * q);
+        for (int k = 1; k < p.tail_split; ++k) v += *reinterpret_cast<const f32x4*>(slab + (long)k * (256 * BNT) + 4 * q);
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+        const long ci = (long)row * p.ldc + col;
+        if (c32) {
+            float* C = reinterpret_cast<float*>(p.C) + ci;
+            if (accum) v += *reinterpret_cast<const f32x4*>(C);
+            *reinterpret_cast<f32x4*>(C) = v;
+        } else {
+            bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + ci;
+            if (accum) v += load4(C);
+            store4(C, v);
+        }
+    }
+}
+
 }  // namespace
 
 // CU count of the current device, rounded down to a multiple of 8 (one persistent workgroup per CU; a grid that is a multiple
@@ -600,6 +660,24 @@ static int pb_num_cus() {
 }
 
 // Called by pb_gemm (pb_gemm.hip) when the problem qualifies. Returns 1 if it declined, 0 on success, <0 on error.
+// Workspace of the tail split: one buffer per stream that ever ran one (the engine runs GEMMs on two streams at a time), sized for
+// a full round of 256 x 256 f32 partial tiles. Never freed (process lifetime, like the zero page of the attention kernels).
+#include <mutex>
+#include <vector>
+static float* tail_slabs_for(hipStream_t stream, size_t floats) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, hipStream_t>, std::pair<float*, size_t>>> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : pool)
+        if (e.first.first == dev && e.first.second == stream && e.second.second >= floats) return e.second.first;
+    if (pool.size() >= 16) return nullptr;
+    float* ptr = nullptr;
+    if (hipMalloc(&ptr, floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    pool.push_back({{dev, stream}, {ptr, floats}});
+    return ptr;
+}
 int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (d->dtype != PB_BF16) return 1;
@@ -617,7 +695,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096 | 8192 | 16384)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096 | 8192 | 16384 | 32768)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue");
         return -2;
     }
@@ -657,6 +735,36 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         hipLaunchKernelGGL(kfn, grid, dim3(WM_ * WN_ * 64), lds, stream, a);                                                \
     } while (0)
     bool cs_fused = false;
+    a.n_full = 0; a.tail_split = 1; a.tail_kc = 0; a.tail_slabs = nullptr;
+    if (big && (d->flags & PB_GEMM_TAIL_SPLIT) && !(d->flags & 2048) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 && !d->colsum_out &&
+        !(d->flags & (PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | 128))) {
+        // The persistent grid runs ceil(tiles / CUs) rounds; a last round that fills only part of the chip (N = 768: 312 tiles =
+        // 1.22 rounds at 26 624 rows, 384 = 1.5 at 32 768) costs a whole one. Cut those tiles' K range so that they occupy the CUs
+        // that would idle: the round then lasts 1 / split of a tile plus the trip of the f32 partials through the slabs.
+        const int ncu = pb_num_cus(), ntile = a.tiles_m * a.tiles_n, rem = ntile % ncu, nkt = d->K / BK;
+        if (rem > 0) {
+            // Cost model in units of one K step (64) of a 256 x 256 tile, ~1.6 us in the step (same-process A/B of the N = 768 shapes,
+            // tools/gemm_tail_ab.py): a split saves nkt - ceil(nkt / split) steps of the last round and costs the finishing launch
+            // (~5 us) plus the trip of rem x split f32 tiles (256 KiB each) out to the slabs and back at ~5 TB/s. Measured at
+            // 26 624 rows: K = 3072 154 -> 134 us, K = 2304 128 -> 107 us; K = 768 loses (46 -> 52 us) and so does a half-full round
+            // (32 768 rows, 138 -> 136 us): the model turns those down. Only on request (PB_GEMM_TAIL_SPLIT): in the training step the
+            // second stream's weight-gradient GEMMs already fill the CUs a short last round leaves idle, and the same-box A/B of the
+            // whole step showed no gain (62.4 vs 62.6 ms); a single-stream caller gets the 13-17 % of the table above.
+            const int smax = std::min(std::min(ncu / rem, nkt / 3), 8);
+            int best = 1; float best_net = 0.f;
+            for (int sp = 2; sp <= smax; ++sp) {
+                const int per = (nkt + sp - 1) / sp;
+                const float overhead = (5.f + 0.105f * rem * sp) / 1.6f;
+                const float net = (float)(nkt - per) - 1.3f * overhead;
+                if (net > best_net) { best = sp; best_net = net; }
+            }
+            if (best >= 2) {
+                const int per = (nkt + best - 1) / best;
+                float* slabs = tail_slabs_for(stream, (size_t)ncu * 256 * 256);
+                if (slabs) { a.n_full = ntile - rem; a.tail_split = (nkt + per - 1) / per; a.tail_kc = per * BK; a.tail_slabs = slabs; }
+            }
+        }
+    }
     if (big && !(d->flags & 2048)) {
         if (d->colsum_out && nsplit == 1 && nb1 * a.nb2 == 1) {
             float* slice = pb_defer_alloc((size_t)2 * a.tiles_m * d->N);          // deferred reduction: the partial rows must outlive this call
@@ -667,8 +775,10 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     do {                                                                                                                 \
         auto kfn = wide192 ? gemm3_kernel<AK, BK_, 3> : gemm3_kernel<AK, BK_, 4>;                                          \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
-        dim3 pgrid(std::min<unsigned>(grid.x, (d->flags & 4096) ? grid.x : (unsigned)pb_num_cus()), grid.y, 1);            \
+        const unsigned items = a.tail_split > 1 ? a.n_full + (grid.x - a.n_full) * a.tail_split : grid.x;                    \
+        dim3 pgrid(std::min<unsigned>(items, (d->flags & 4096) ? items : (unsigned)pb_num_cus()), grid.y, 1);               \
         hipLaunchKernelGGL(kfn, pgrid, dim3(512), 131072 + 2048, stream, a);                                              \
+        if (a.tail_split > 1) hipLaunchKernelGGL(tail_finish_kernel<4>, dim3((grid.x - a.n_full) * TAIL_FIN_PARTS), dim3(256), 0, stream, a); \
     } while (0)
         if (a_kc && b_kc) PB_G3_LAUNCH(true, true);
         else if (a_kc && !b_kc) PB_G3_LAUNCH(true, false);

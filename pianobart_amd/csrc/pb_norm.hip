@@ -47,10 +47,11 @@ __device__ __forceinline__ void ln_stats(const f32x4 (&z)[NIT], int lane, int d4
 template <typename T, int NIT>
 __global__ __launch_bounds__(LN_THREADS) void add_ln_fwd_kernel(const T* __restrict__ res, const T* __restrict__ a,
         const float* __restrict__ w, const float* __restrict__ b, T* __restrict__ y, float* __restrict__ mean_o,
-        float* __restrict__ rstd_o, int rows, int d, float eps, uint64_t seed, uint32_t site, float p) {
+        float* __restrict__ rstd_o, int rows, int d, float eps, uint64_t seed, uint32_t site, float p, const int* __restrict__ row_ids) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
     const DropCfg dc = make_drop(seed, site, p);
     for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
+        const long rid = row_ids ? row_ids[row] : row;              // packed rows draw the dropout bits of their row in the padded batch
         f32x4 z[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(LN_THREADS) void add_ln_fwd_kernel(const T* __restr
             if (c4 < d4) {
                 const f32x4 r = load4(res + row * d + 4 * c4);
                 const f32x4 x = load4(a + row * d + 4 * c4);
-                const f32x4 m = drop_mask4(dc, (uint32_t)(row * d4 + c4));
+                const f32x4 m = drop_mask4(dc, (uint32_t)(rid * d4 + c4));
                 z[it] = r + x * m;
             }
         }
@@ -105,7 +106,7 @@ template <typename T, typename TR, int NIT>
 __global__ __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu(NIT <= 3 ? 4 : 2, NIT <= 3 ? 4 : 2))) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ res,
         const T* __restrict__ a, const float* __restrict__ w, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
         TR* __restrict__ dres, T* __restrict__ da, float* __restrict__ partials, int rows, int d, int accum_dres,
-        uint64_t seed, uint32_t site, float p) {
+        uint64_t seed, uint32_t site, float p, const int* __restrict__ row_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds = reinterpret_cast<float*>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu(NIT 
         for (int it = 0; it < NIT; ++it) acc[k][it] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
         const float mean = mean_i[row], rstd = rstd_i[row];
+        const long rid = row_ids ? row_ids[row] : row;
         f32x4 xh[NIT], g[NIT], msk[NIT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu(NIT 
             if (c4 < d4) {
                 const f32x4 r = load4(res + row * d + 4 * c4);
                 const f32x4 x = load4(a + row * d + 4 * c4);
-                msk[it] = drop_mask4(dc, (uint32_t)(row * d4 + c4));
+                msk[it] = drop_mask4(dc, (uint32_t)(rid * d4 + c4));
                 xh[it] = (r + x * msk[it] - mean) * rstd;
                 const f32x4 dyv = load4(dy + row * d + 4 * c4);
                 g[it] = dyv * load4(w + 4 * c4);
@@ -222,14 +224,14 @@ struct SegOff { int off[8]; };
 template <int NIT>
 __device__ __forceinline__ void embed_row(f32x4 (&z)[NIT], const int16_t* __restrict__ ids16, const float* __restrict__ P,
                                           const SegOff& so, const float* __restrict__ lin_bias, const float* __restrict__ pos,
-                                          long row, int S, int d, int lane) {
+                                          long row, int S, int d, int lane, const int* __restrict__ row_ids) {
     const int d4 = d >> 2;
     // one 16-byte load of the 8 int16 ids of this token, broadcast over the wave
     const uint4 raw = *reinterpret_cast<const uint4*>(ids16 + row * 8);
     int id[8];
     id[0] = (int)(raw.x & 0xffff); id[1] = (int)(raw.x >> 16); id[2] = (int)(raw.y & 0xffff); id[3] = (int)(raw.y >> 16);
     id[4] = (int)(raw.z & 0xffff); id[5] = (int)(raw.z >> 16); id[6] = (int)(raw.w & 0xffff); id[7] = (int)(raw.w >> 16);
-    const int s = (int)(row % S);
+    const int s = (int)((row_ids ? (long)row_ids[row] : row) % S);      // packed rows carry their row number in the padded batch
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c4 = lane + 64 * it;
@@ -246,12 +248,12 @@ template <typename T, int NIT>
 __global__ __launch_bounds__(LN_THREADS) void embed_ln_fwd_kernel(const int16_t* __restrict__ ids16, const float* __restrict__ P,
         const SegOff so, const float* __restrict__ lin_bias, const float* __restrict__ pos, const float* __restrict__ w,
         const float* __restrict__ b, T* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
-        int rows, int S, int d, float eps, uint64_t seed, uint32_t site, float p) {
+        int rows, int S, int d, float eps, uint64_t seed, uint32_t site, float p, const int* __restrict__ row_ids) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
     const DropCfg dc = make_drop(seed, site, p);
     for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
         f32x4 z[NIT];
-        embed_row<NIT>(z, ids16, P, so, lin_bias, pos, row, S, d, lane);
+        embed_row<NIT>(z, ids16, P, so, lin_bias, pos, row, S, d, lane, row_ids);
         float mean, rstd;
         ln_stats<NIT>(z, lane, d4, d, eps, mean, rstd);
 #pragma unroll
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_fwd_kernel(const int16_t*
             const int c4 = lane + 64 * it;
             if (c4 < d4) {
                 const f32x4 g = load4(w + 4 * c4), be = load4(b + 4 * c4);
-                const f32x4 m = drop_mask4(dc, (uint32_t)(row * d4 + c4));     // dropout AFTER the LN here
+                const f32x4 m = drop_mask4(dc, (uint32_t)((row_ids ? (long)row_ids[row] : row) * d4 + c4));     // dropout AFTER the LN here
                 store4(y + row * d + 4 * c4, ((z[it] - mean) * rstd * g + be) * m);
             }
         }
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(const T* __res
         const float* __restrict__ P, const SegOff so, const float* __restrict__ lin_bias, const float* __restrict__ pos,
         const float* __restrict__ w, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
         float* __restrict__ dP, float* __restrict__ dpos, float* __restrict__ partials, T* __restrict__ dz_out,
-        int rows, int S, int d, uint64_t seed, uint32_t site, float p) {
+        int rows, int S, int d, uint64_t seed, uint32_t site, float p, const int* __restrict__ row_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds = reinterpret_cast<float*>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
@@ -288,14 +290,14 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(const T* __res
     for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
         const float mean = mean_i[row], rstd = rstd_i[row];
         f32x4 z[NIT], g[NIT];
-        embed_row<NIT>(z, ids16, P, so, lin_bias, pos, row, S, d, lane);
+        embed_row<NIT>(z, ids16, P, so, lin_bias, pos, row, S, d, lane, row_ids);
         float s1 = 0.f, s2 = 0.f, nz = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c4 = lane + 64 * it;
             if (c4 < d4) {
                 z[it] = (z[it] - mean) * rstd;                                   // xhat
-                const f32x4 m = drop_mask4(dc, (uint32_t)(row * d4 + c4));
+                const f32x4 m = drop_mask4(dc, (uint32_t)((row_ids ? (long)row_ids[row] : row) * d4 + c4));
                 const f32x4 dyv = load4(dy + row * d + 4 * c4) * m;
                 g[it] = dyv * load4(w + 4 * c4);
                 acc[0][it] += dyv * z[it];
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(const T* __res
         int id[8];
         id[0] = (int)(raw.x & 0xffff); id[1] = (int)(raw.x >> 16); id[2] = (int)(raw.y & 0xffff); id[3] = (int)(raw.y >> 16);
         id[4] = (int)(raw.z & 0xffff); id[5] = (int)(raw.z >> 16); id[6] = (int)(raw.w & 0xffff); id[7] = (int)(raw.w >> 16);
-        const int s = (int)(row % S);
+        const int s = (int)((row_ids ? (long)row_ids[row] : row) % S);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c4 = lane + 64 * it;
@@ -388,9 +390,9 @@ static int nit_for(int d) { const int n = (d / 4 + 63) / 64; return n <= 4 ? n :
 
 extern "C" int64_t pb_ln_partials_floats(int32_t d) { return (int64_t)LN_MAX_BLOCKS * 3 * d; }
 
-extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, const float* ln_b, void* y, float* mean,
-                             float* rstd, int32_t T, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
-                             float p_drop, void* stream_) {
+static int add_ln_fwd_impl(const void* res, const void* a, const float* ln_w, const float* ln_b, void* y, float* mean,
+                           float* rstd, int32_t T, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
+                           float p_drop, void* stream_, const int32_t* row_ids) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_ln_dims("pb_add_ln_fwd", T, d)) return -2;
     if (T == 0) return 0;
@@ -398,12 +400,23 @@ extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, 
     PB_LN_DISPATCH(nit_for(d),
         if (dtype == PB_BF16)
             hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, (const bf16_t*)res,
-                               (const bf16_t*)a, ln_w, ln_b, (bf16_t*)y, mean, rstd, T, d, eps, seed, site, p_drop);
+                               (const bf16_t*)a, ln_w, ln_b, (bf16_t*)y, mean, rstd, T, d, eps, seed, site, p_drop, row_ids);
         else
             hipLaunchKernelGGL((add_ln_fwd_kernel<float, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, (const float*)res,
-                               (const float*)a, ln_w, ln_b, (float*)y, mean, rstd, T, d, eps, seed, site, p_drop));
+                               (const float*)a, ln_w, ln_b, (float*)y, mean, rstd, T, d, eps, seed, site, p_drop, row_ids));
     PB_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int pb_add_ln_fwd(const void* res, const void* a, const float* ln_w, const float* ln_b, void* y, float* mean,
+                             float* rstd, int32_t T, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
+                             float p_drop, void* stream_) {
+    return add_ln_fwd_impl(res, a, ln_w, ln_b, y, mean, rstd, T, d, dtype, eps, seed, site, p_drop, stream_, nullptr);
+}
+extern "C" int pb_add_ln_fwd_packed(const void* res, const void* a, const float* ln_w, const float* ln_b, void* y, float* mean,
+                                    float* rstd, const int32_t* row_ids, int32_t T, int32_t d, int32_t dtype, float eps, uint64_t seed,
+                                    uint32_t site, float p_drop, void* stream_) {
+    PB_REQUIRE(row_ids != nullptr, "pb_add_ln_fwd_packed: row_ids is required");
+    return add_ln_fwd_impl(res, a, ln_w, ln_b, y, mean, rstd, T, d, dtype, eps, seed, site, p_drop, stream_, row_ids);
 }
 
 // ---- deferred reductions (see finalize_batch_kernel). The open window (arena cursor, descriptor list) is per host thread: a backward
@@ -495,10 +508,10 @@ int pb_finalize_rows(const float* partials, int nblk, int d, float* out, void* s
     return launch_finalize(partials, nblk, nacc, d, out, out1, nullptr, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int pb_add_ln_bwd(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
-                             const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
-                             float* partials, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32, int32_t accum_dres,
-                             uint64_t seed, uint32_t site, float p_drop, void* stream_) {
+static int add_ln_bwd_impl(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
+                           const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
+                           float* partials, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32, int32_t accum_dres,
+                           uint64_t seed, uint32_t site, float p_drop, void* stream_, const int32_t* row_ids) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_ln_dims("pb_add_ln_bwd", T, d)) return -2;
     if (T == 0) return 0;
@@ -510,27 +523,42 @@ extern "C" int pb_add_ln_bwd(const void* dy, const void* res, const void* a, con
             if (dres_f32)
                 hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, float, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream,
                                    (const bf16_t*)dy, (const bf16_t*)res, (const bf16_t*)a, ln_w, mean, rstd, (float*)dres,
-                                   (bf16_t*)da, partials, T, d, accum_dres, seed, site, p_drop);
+                                   (bf16_t*)da, partials, T, d, accum_dres, seed, site, p_drop, row_ids);
             else
                 hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream,
                                    (const bf16_t*)dy, (const bf16_t*)res, (const bf16_t*)a, ln_w, mean, rstd, (bf16_t*)dres,
-                                   (bf16_t*)da, partials, T, d, accum_dres, seed, site, p_drop);
+                                   (bf16_t*)da, partials, T, d, accum_dres, seed, site, p_drop, row_ids);
         } else {
             hipLaunchKernelGGL((add_ln_bwd_kernel<float, float, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream,
                                (const float*)dy, (const float*)res, (const float*)a, ln_w, mean, rstd, (float*)dres,
-                               (float*)da, partials, T, d, accum_dres, seed, site, p_drop);
+                               (float*)da, partials, T, d, accum_dres, seed, site, p_drop, row_ids);
         });
     PB_LAUNCH_CHECK();
     return launch_finalize(partials, grid, 3, d, dgamma, dbeta, dbias_a, nullptr, stream);
 }
+extern "C" int pb_add_ln_bwd(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
+                             const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
+                             float* partials, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32, int32_t accum_dres,
+                             uint64_t seed, uint32_t site, float p_drop, void* stream_) {
+    return add_ln_bwd_impl(dy, res, a, ln_w, mean, rstd, dres, da, dgamma, dbeta, dbias_a, partials, T, d, dtype, dres_f32, accum_dres, seed, site,
+                           p_drop, stream_, nullptr);
+}
+extern "C" int pb_add_ln_bwd_packed(const void* dy, const void* res, const void* a, const float* ln_w, const float* mean,
+                                    const float* rstd, void* dres, void* da, float* dgamma, float* dbeta, float* dbias_a,
+                                    float* partials, const int32_t* row_ids, int32_t T, int32_t d, int32_t dtype, int32_t dres_f32,
+                                    int32_t accum_dres, uint64_t seed, uint32_t site, float p_drop, void* stream_) {
+    PB_REQUIRE(row_ids != nullptr, "pb_add_ln_bwd_packed: row_ids is required");
+    return add_ln_bwd_impl(dy, res, a, ln_w, mean, rstd, dres, da, dgamma, dbeta, dbias_a, partials, T, d, dtype, dres_f32, accum_dres, seed, site,
+                           p_drop, stream_, row_ids);
+}
 
-extern "C" int pb_embed_ln_fwd(const int16_t* ids16, const float* P, const int32_t* seg_off, const float* lin_bias,
-                               const float* pos, const float* ln_w, const float* ln_b, void* y, float* mean, float* rstd,
-                               int32_t T, int32_t S, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
-                               float p_drop, void* stream_) {
+static int embed_ln_fwd_impl(const int16_t* ids16, const float* P, const int32_t* seg_off, const float* lin_bias,
+                             const float* pos, const float* ln_w, const float* ln_b, void* y, float* mean, float* rstd,
+                             int32_t T, int32_t S, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
+                             float p_drop, void* stream_, const int32_t* row_ids) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_ln_dims("pb_embed_ln_fwd", T, d)) return -2;
-    PB_REQUIRE(S > 0 && T % S == 0, "pb_embed_ln_fwd: T=%d not a multiple of S=%d", T, S);
+    PB_REQUIRE(S > 0 && (row_ids || T % S == 0), "pb_embed_ln_fwd: T=%d not a multiple of S=%d", T, S);
     if (T == 0) return 0;
     SegOff so;
     for (int i = 0; i < 8; ++i) so.off[i] = seg_off[i];
@@ -538,22 +566,35 @@ extern "C" int pb_embed_ln_fwd(const int16_t* ids16, const float* P, const int32
     PB_LN_DISPATCH(nit_for(d),
         if (dtype == PB_BF16)
             hipLaunchKernelGGL((embed_ln_fwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, ids16, P, so, lin_bias,
-                               pos, ln_w, ln_b, (bf16_t*)y, mean, rstd, T, S, d, eps, seed, site, p_drop);
+                               pos, ln_w, ln_b, (bf16_t*)y, mean, rstd, T, S, d, eps, seed, site, p_drop, row_ids);
         else
             hipLaunchKernelGGL((embed_ln_fwd_kernel<float, NIT>), dim3(grid), dim3(LN_THREADS), 0, stream, ids16, P, so, lin_bias,
-                               pos, ln_w, ln_b, (float*)y, mean, rstd, T, S, d, eps, seed, site, p_drop));
+                               pos, ln_w, ln_b, (float*)y, mean, rstd, T, S, d, eps, seed, site, p_drop, row_ids));
     PB_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int pb_embed_ln_fwd(const int16_t* ids16, const float* P, const int32_t* seg_off, const float* lin_bias,
+                               const float* pos, const float* ln_w, const float* ln_b, void* y, float* mean, float* rstd,
+                               int32_t T, int32_t S, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
+                               float p_drop, void* stream_) {
+    return embed_ln_fwd_impl(ids16, P, seg_off, lin_bias, pos, ln_w, ln_b, y, mean, rstd, T, S, d, dtype, eps, seed, site, p_drop, stream_, nullptr);
+}
+extern "C" int pb_embed_ln_fwd_packed(const int16_t* ids16, const int32_t* row_ids, const float* P, const int32_t* seg_off, const float* lin_bias,
+                                      const float* pos, const float* ln_w, const float* ln_b, void* y, float* mean, float* rstd,
+                                      int32_t T, int32_t S, int32_t d, int32_t dtype, float eps, uint64_t seed, uint32_t site,
+                                      float p_drop, void* stream_) {
+    PB_REQUIRE(row_ids != nullptr, "pb_embed_ln_fwd_packed: row_ids is required");
+    return embed_ln_fwd_impl(ids16, P, seg_off, lin_bias, pos, ln_w, ln_b, y, mean, rstd, T, S, d, dtype, eps, seed, site, p_drop, stream_, row_ids);
+}
 
-extern "C" int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float* P, const int32_t* seg_off,
-                               const float* lin_bias, const float* pos, const float* ln_w, const float* mean,
-                               const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
-                               float* partials, void* dz_out, int32_t T, int32_t S, int32_t d, int32_t dtype, uint64_t seed,
-                               uint32_t site, float p_drop, void* stream_) {
+static int embed_ln_bwd_impl(const void* dy, const int16_t* ids16, const float* P, const int32_t* seg_off,
+                             const float* lin_bias, const float* pos, const float* ln_w, const float* mean,
+                             const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
+                             float* partials, void* dz_out, int32_t T, int32_t S, int32_t d, int32_t dtype, uint64_t seed,
+                             uint32_t site, float p_drop, void* stream_, const int32_t* row_ids) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_ln_dims("pb_embed_ln_bwd", T, d)) return -2;
-    PB_REQUIRE(S > 0 && T % S == 0, "pb_embed_ln_bwd: T=%d not a multiple of S=%d", T, S);
+    PB_REQUIRE(S > 0 && (row_ids || T % S == 0), "pb_embed_ln_bwd: T=%d not a multiple of S=%d", T, S);
     if (T == 0) return 0;
     SegOff so;
     for (int i = 0; i < 8; ++i) so.off[i] = seg_off[i];
@@ -562,12 +603,29 @@ extern "C" int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float
     PB_LN_DISPATCH(nit_for(d),
         if (dtype == PB_BF16)
             hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream, (const bf16_t*)dy,
-                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, (bf16_t*)dz_out, T, S, d, seed, site, p_drop);
+                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, (bf16_t*)dz_out, T, S, d, seed, site, p_drop, row_ids);
         else
             hipLaunchKernelGGL((embed_ln_bwd_kernel<float, NIT>), dim3(grid), dim3(LN_THREADS), lds, stream, (const float*)dy,
-                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, (float*)dz_out, T, S, d, seed, site, p_drop));
+                               ids16, P, so, lin_bias, pos, ln_w, mean, rstd, dP, dpos, partials, (float*)dz_out, T, S, d, seed, site, p_drop, row_ids));
     PB_LAUNCH_CHECK();
     return launch_finalize(partials, grid, 3, d, dgamma, dbeta, dbias, nullptr, stream);
+}
+extern "C" int pb_embed_ln_bwd(const void* dy, const int16_t* ids16, const float* P, const int32_t* seg_off,
+                               const float* lin_bias, const float* pos, const float* ln_w, const float* mean,
+                               const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
+                               float* partials, void* dz_out, int32_t T, int32_t S, int32_t d, int32_t dtype, uint64_t seed,
+                               uint32_t site, float p_drop, void* stream_) {
+    return embed_ln_bwd_impl(dy, ids16, P, seg_off, lin_bias, pos, ln_w, mean, rstd, dP, dpos, dbias, dgamma, dbeta, partials, dz_out, T, S, d,
+                             dtype, seed, site, p_drop, stream_, nullptr);
+}
+extern "C" int pb_embed_ln_bwd_packed(const void* dy, const int16_t* ids16, const int32_t* row_ids, const float* P, const int32_t* seg_off,
+                                      const float* lin_bias, const float* pos, const float* ln_w, const float* mean,
+                                      const float* rstd, float* dP, float* dpos, float* dbias, float* dgamma, float* dbeta,
+                                      float* partials, void* dz_out, int32_t T, int32_t S, int32_t d, int32_t dtype, uint64_t seed,
+                                      uint32_t site, float p_drop, void* stream_) {
+    PB_REQUIRE(row_ids != nullptr, "pb_embed_ln_bwd_packed: row_ids is required");
+    return embed_ln_bwd_impl(dy, ids16, P, seg_off, lin_bias, pos, ln_w, mean, rstd, dP, dpos, dbias, dgamma, dbeta, partials, dz_out, T, S, d,
+                             dtype, seed, site, p_drop, stream_, row_ids);
 }
 
 extern "C" int64_t pb_colsum_partials_floats(int32_t N) { return (int64_t)256 * N; }

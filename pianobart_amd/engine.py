@@ -29,6 +29,31 @@ _NO_FUSED_BIAS = bool(int(os.environ.get('PB_NO_FUSED_BIAS', '0')))     # develo
 LN_EPS = 1e-5
 
 
+# dead-row compaction of the fused pre-train step (Engine._pack_batch): PB_PACK_ROWS=0 keeps every step dense
+_PACK_ROWS = int(os.environ.get('PB_PACK_ROWS', '1'))
+_PACK_TILE = 256                 # packed row counts are rounded up to whole GEMM tiles
+_PACK_MIN_GAIN = 0.97            # stay dense unless at least 3 % of the rows go
+
+
+def plan_packed_rows(live, S, tile=_PACK_TILE):
+    """live[b] = rows of sequence b that must be kept (<= S). Returns (Tp, off, length): the packed side has Tp rows, a multiple of
+    `tile` (the GEMM row tile; len(live) * S must be one) and no more than len(live) * S; sequence b owns rows off[b] .. off[b] +
+    length[b] - 1, length[b] >= live[b]: the Tp - sum(live) rows of slack are handed out as dead rows of the sequences that have
+    some (first come, first served), so that no sequence grows beyond S."""
+    live = np.asarray(live, dtype=np.int64)
+    total = int(live.sum())
+    Tp = min(-(-max(total, 1) // tile) * tile, len(live) * S)
+    cum = np.minimum(np.cumsum(S - live), Tp - total)
+    length = live + np.diff(np.concatenate([[0], cum]))
+    return Tp, np.concatenate([[0], np.cumsum(length)[:-1]]), length
+
+
+class _RowPack:
+    """One packed batch: B, S, Te / Td (rows kept on the encoder / decoder side), the packed inputs enc16 / dec16 / tgt16 /
+    loss_mask, src_* (row b*S + s of every packed row in the padded batch), inv_* (packed row of every (b, s), or -1) and the PackedRows
+    descriptors of the encoder self-, decoder self- and cross-attention."""
+
+
 def _r4(n):
     return (n + 3) // 4 * 4
 
@@ -70,6 +95,8 @@ class Engine:
         self._versions = None
         self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 96, 128))
         self._slabs = None
+        self._pack_state = None
+        self.last_rows = self.last_pairs = None
         self._side, self._side_last, self._readers = None, None, {}
         self._kmax = {}
         self.grad_hook = None          # callable(lo, hi): flat gradient range is final (data-parallel bucketing)
@@ -234,17 +261,50 @@ class Engine:
                   gy=[e(T, d), e(T, d)], gA=e(T, d), gB=e(T, d), gC=e(T, d), dqkv=e(T, 3 * d), dq=e(T, d), dkv=e(T, 2 * d),
                   du=e(T, max(self.fe, self.fd)), genc=e(T, d), dlogits=e(T, ops.VOCAB) if self.mlm is not None else None,
                   dz=e(2 * T, d) if self.code == PB_BF16 else None, onehot=e(2 * T, ops.TAB_TOTAL) if self.code == PB_BF16 else None)
+        ws['Te'] = ws['Td'] = T
         self._ws_cache = {key: ws}          # keep one shape resident
         return ws
+
+    def _ws_rows(self, ws, Te, Td):
+        """The workspace cut to Te encoder-side and Td decoder-side rows (packed step): row-prefix views of the same storage. The
+        shared scratch buffers (gy, gA, dqkv ...) stay whole; backward cuts them per phase."""
+        if Te == ws['T'] and Td == ws['T']:
+            return ws
+        views = ws.setdefault('_views', {})
+        v = views.get((Te, Td))
+        if v is None:
+            if len(views) >= 64:
+                views.clear()
+
+            def layer(L, dec):
+                n = Td if dec else Te
+                return {k: (t if k in ('attn', 'attnc') else t[:Te] if k == 'kvc' else t[:n]) for k, t in L.items()}
+
+            v = dict(ws)
+            v['_base'] = ws
+            v['enc'] = [layer(L, False) for L in ws['enc']]
+            v['dec'] = [layer(L, True) for L in ws['dec']]
+            for k in ('x_enc', 'me', 're'):
+                v[k] = ws[k][:Te]
+            for k in ('x_dec', 'md', 'rd'):
+                v[k] = ws[k][:Td]
+            for k in ('logits', 'dlogits'):
+                v[k] = ws[k][:Td] if ws[k] is not None else None
+            v['Te'], v['Td'] = Te, Td
+            views[(Te, Td)] = v
+        return v
 
     # ------------------------------------------------------------------ building blocks
     def _linear(self, x, wname, bname, out, M, N, K, **kw):
         ops.gemm(x, self.w[wname], out, M=M, N=N, K=K, dtype=self.code, bias=self.wf[bname] if bname else None, **kw)
 
-    def _attn_fwd(self, q, k, v, out, key_mask, causal, B, Sq, Sk, save):
-        """q,k,v,out: (tensor, elem offset, row stride). Unfused form: QK^T -> masked softmax -> PV."""
+    def _attn_fwd(self, q, k, v, out, key_mask, causal, B, Sq, Sk, save, rows=None):
+        """q,k,v,out: (tensor, elem offset, row stride). Unfused form: QK^T -> masked softmax -> PV. rows: packed-row descriptors."""
         H, hd = self.H, self.hd
         ws = self._cur_ws
+        if rows is not None:
+            ops.flash_fwd_packed(q, k, v, out, save['lse'], rows, B, H, hd, hd ** -0.5, causal)
+            return
         if self.use_flash:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
             ops.flash_fwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), save['lse'], key_mask, B, H, Sq, Sk, hd, hd ** -0.5, causal,
@@ -258,7 +318,7 @@ class Engine:
         ops.gemm(P, vt, ot, M=Sq, N=hd, K=Sk, dtype=self.code, b_kc=False, lda=Sk, ldb=vl, ldc=ol, nb1=B, nb2=H,
                  sA=(H * Sq * Sk, Sq * Sk), sB=(Sk * vl, hd), sC=(Sq * ol, hd), b_off=vo, c_off=oo)
 
-    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save, out=None, key_mask=None, causal=False, dbias=None):
+    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save, out=None, key_mask=None, causal=False, dbias=None, rows=None):
         """dbias = (gq, gk, gv) bias-gradient vectors: filled here when the attention kernels can do it (returns True), else left to the caller."""
         H, hd = self.H, self.hd
         ws = self._cur_ws
@@ -272,6 +332,10 @@ class Engine:
                 if getattr(self, '_fbws', None) is None or self._fbws.numel() < need:
                     self._fbws = torch.empty(need, dtype=torch.float32, device=self.device)
                 wsb = self._fbws
+            if rows is not None:
+                ops.flash_bwd_packed(q, k, v, out, dout[0], save['lse'], dq, dk, dv, ws['delta'], rows, B, H, hd, hd ** -0.5, causal,
+                                     dbias=dbias if fuse else None, dbias_ws=wsb)
+                return fuse
             ops.flash_bwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
                           ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal, kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None,
                           dbias=dbias if fuse else None, dbias_ws=wsb)
@@ -302,21 +366,25 @@ class Engine:
                  c_f32=True, nb1=8, sA=(R * 256, 0), sB=(256, 0), sC=(R * self.d, 0))
 
     # ------------------------------------------------------------------ forward
-    def forward_hidden(self, enc16, dec16, emask, dmask, train, seed, reuse_encoder=False, dec_embeds=None):
-        """enc16/dec16: (B,S,8) int16 device; masks (B,S) f32 or None. Returns (dec_hidden, enc_hidden) in storage dtype."""
-        B, S = enc16.shape[:2]
+    def forward_hidden(self, enc16, dec16, emask, dmask, train, seed, reuse_encoder=False, dec_embeds=None, pack=None):
+        """enc16/dec16: (B,S,8) int16 device; masks (B,S) f32 or None. Returns (dec_hidden, enc_hidden) in storage dtype.
+        pack (a _RowPack): enc16 / dec16 hold the packed rows (Te,8) / (Td,8) of the batch and the masks are not read."""
+        B, S = (pack.B, pack.S) if pack is not None else enc16.shape[:2]
         if S > self.Smax:
             raise PBError('sequence length %d exceeds max_position_embeddings %d' % (S, self.Smax))
         self._fwd_token += 1          # any forward (generate included) overwrites the activation workspace: older autograd graphs are stale
-        d, T = self.d, B * S
-        ws = self._ws(B, S)
+        d = self.d
+        Te, Td = (pack.Te, pack.Td) if pack is not None else (B * S, B * S)     # rows on the encoder / decoder side
+        ws = self._ws_rows(self._ws(B, S), Te, Td)
         self._cur_ws = ws
+        r_enc, r_dec, r_cross = (pack.enc, pack.dec, pack.cross) if pack is not None else (None, None, None)
+        ids_e, ids_d = (pack.src_e, pack.src_d) if pack is not None else (None, None)        # row numbers in the padded batch
         p = self.p_drop if train else 0.0
         self.refresh_shadow()
         self.build_ptab()
         # per-batch-row key extents (1 + last visible key): the attention kernels skip the masked PAD tail tile-wise
         self._kmax = {}
-        if self.use_flash and self.hd in (64, 96, 128):
+        if self.use_flash and self.hd in (64, 96, 128) and pack is None:
             for msk in (emask, dmask):
                 if msk is not None and id(msk) not in self._kmax:
                     km = torch.empty(msk.shape[0], dtype=torch.int32, device=msk.device)
@@ -327,24 +395,27 @@ class Engine:
         x = ws['x_enc']
         if not reuse_encoder:
             ops.embed_ln_fwd(enc16, self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], wf['enc.lne.b'], x, ws['me'], ws['re'], S,
-                             LN_EPS, seed, self._site('enc_emb'), p, padded=True)
+                             LN_EPS, seed, self._site('enc_emb'), p, padded=True, row_ids=ids_e)
+        T = Te
         for l in range(self.NE if not reuse_encoder else 0):
             L, pf = ws['enc'][l], 'enc.%d.' % l
             self._linear(x, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
-            self._attn_fwd((L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d), (L['ctx'], 0, d), emask, False, B, S, S, L['attn'])
+            self._attn_fwd((L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d), (L['ctx'], 0, d), emask, False, B, S, S, L['attn'],
+                           rows=r_enc)
             self._linear(L['ctx'], pf + 'wo', pf + 'bo', L['a1'], T, d, d)
-            ops.add_ln_fwd(x, L['a1'], wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], L['y1'], L['m1'], L['r1'], LN_EPS, seed, self._site('enc', l, 0), p)
+            ops.add_ln_fwd(x, L['a1'], wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], L['y1'], L['m1'], L['r1'], LN_EPS, seed, self._site('enc', l, 0), p, row_ids=ids_e)
             self._linear(L['y1'], pf + 'w1', pf + 'b1', L['g'], T, self.fe, d, gelu_aux_out=L['u'])
             self._linear(L['g'], pf + 'w2', pf + 'b2', L['a2'], T, d, self.fe)
-            ops.add_ln_fwd(L['y1'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('enc', l, 1), p)
+            ops.add_ln_fwd(L['y1'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('enc', l, 1), p, row_ids=ids_e)
             x = L['y2']
         enc_out = x if not reuse_encoder else (ws['enc'][-1]['y2'] if self.NE else x)
         if dec16 is None and dec_embeds is None:
             return None, enc_out
         y = ws['x_dec']
+        T = Td
         if dec_embeds is None:
             ops.embed_ln_fwd(dec16, self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], wf['dec.lne.b'], y, ws['md'], ws['rd'], S,
-                             LN_EPS, seed, self._site('dec_emb'), p, padded=True)
+                             LN_EPS, seed, self._site('dec_emb'), p, padded=True, row_ids=ids_d)
         else:
             # decoder_inputs_embeds supplied by the caller (velocity task's label embedding, PianoBart.py:65-66): BART adds the
             # learned positions (offset 2), applies layernorm_embedding, then dropout (modeling_bart.py, BartDecoder.forward)
@@ -365,29 +436,31 @@ class Engine:
             with torch.cuda.stream(self._side):
                 for l in range(self.ND):
                     pf = 'dec.%d.' % l
-                    self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', ws['dec'][l]['kvc'], T, 2 * d, d)
+                    self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', ws['dec'][l]['kvc'], Te, 2 * d, d)
                     kv_ready.append(torch.cuda.Event())
                     kv_ready[-1].record()
         for l in range(self.ND):
             L, pf = ws['dec'][l], 'dec.%d.' % l
             self._linear(y, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
-            self._attn_fwd((L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d), (L['ctx'], 0, d), dmask, True, B, S, S, L['attn'])
+            self._attn_fwd((L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d), (L['ctx'], 0, d), dmask, True, B, S, S, L['attn'],
+                           rows=r_dec)
             self._linear(L['ctx'], pf + 'wo', pf + 'bo', L['a1'], T, d, d)
-            ops.add_ln_fwd(y, L['a1'], wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], L['y1'], L['m1'], L['r1'], LN_EPS, seed, self._site('dec', l, 0), p)
+            ops.add_ln_fwd(y, L['a1'], wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], L['y1'], L['m1'], L['r1'], LN_EPS, seed, self._site('dec', l, 0), p, row_ids=ids_d)
             self._linear(L['y1'], pf + 'wq_c', pf + 'bq_c', L['qc'], T, d, d)
             if kv_ready is None:
-                self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', L['kvc'], T, 2 * d, d)
+                self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', L['kvc'], Te, 2 * d, d)
             else:
                 torch.cuda.current_stream().wait_event(kv_ready[l])
-            self._attn_fwd((L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d), (L['ctxc'], 0, d), emask, False, B, S, S, L['attnc'])
+            self._attn_fwd((L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d), (L['ctxc'], 0, d), emask, False, B, S, S, L['attnc'],
+                           rows=r_cross)
             self._linear(L['ctxc'], pf + 'wo_c', pf + 'bo_c', L['ac'], T, d, d)
-            ops.add_ln_fwd(L['y1'], L['ac'], wf[pf + 'lnc.w'], wf[pf + 'lnc.b'], L['yc'], L['mc'], L['rc'], LN_EPS, seed, self._site('dec', l, 1), p)
+            ops.add_ln_fwd(L['y1'], L['ac'], wf[pf + 'lnc.w'], wf[pf + 'lnc.b'], L['yc'], L['mc'], L['rc'], LN_EPS, seed, self._site('dec', l, 1), p, row_ids=ids_d)
             self._linear(L['yc'], pf + 'w1', pf + 'b1', L['g'], T, self.fd, d, gelu_aux_out=L['u'])
             self._linear(L['g'], pf + 'w2', pf + 'b2', L['a2'], T, d, self.fd)
-            ops.add_ln_fwd(L['yc'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('dec', l, 2), p)
+            ops.add_ln_fwd(L['yc'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('dec', l, 2), p, row_ids=ids_d)
             y = L['y2']
         self._saved = dict(enc16=enc16, dec16=dec16, emask=emask, dmask=dmask, p=p, seed=seed, enc_out=enc_out, dec_out=y, B=B, S=S,
-                           alt=dec_embeds is not None)
+                           alt=dec_embeds is not None, pack=pack)
         return y, enc_out
 
     def heads_forward(self, dec_hidden):
@@ -494,17 +567,17 @@ class Engine:
         a second full round, twice the time, where an ordinary grid merely loses those CUs' share."""
         return 4096 if (self.grad_hook is not None or ((_WGRAD_STREAM & 4) and self._side)) else 0
 
-    def _ffn_ln_bwd(self, L, pf, ff, gy, y_in, seed, site, p):
-        """Backward of y2 = LN2(y_in + drop(fc2(gelu(fc1(y_in))))). gy: grad wrt y2. Returns grad wrt y_in in ws['gA']."""
-        ws, g, d, T = self._cur_ws, self.g, self.d, self._cur_ws['T']
-        gA, gB = ws['gA'], ws['gB']
+    def _ffn_ln_bwd(self, L, pf, ff, gy, y_in, seed, site, p, T, row_ids=None):
+        """Backward of y2 = LN2(y_in + drop(fc2(gelu(fc1(y_in))))). gy: grad wrt y2. Returns grad wrt y_in in ws['gA']. T: rows."""
+        ws, g, d = self._cur_ws, self.g, self.d
+        gA, gB = ws['gA'][:T], ws['gB'][:T]
         da = gB if p > 0 else None
         self._before_write(gA, da)
         ops.add_ln_bwd(gy, y_in, L['a2'], self.wf[pf + 'ln2.w'], L['m2'], L['r2'], gA, da, g[pf + 'ln2.w'], g[pf + 'ln2.b'], g[pf + 'b2'],
-                       self.partials, False, seed, site, p)
+                       self.partials, False, seed, site, p, row_ids=row_ids)
         gb = gB if p > 0 else gA
         self._wgrad(gb, L['g'], pf + 'w2', d, ff, T)
-        du = ws['du'][:, :ff] if ws['du'].shape[1] == ff else ws['du'].view(-1)[:T * ff].view(T, ff)
+        du = ws['du'][:T, :ff] if ws['du'].shape[1] == ff else ws['du'].view(-1)[:T * ff].view(T, ff)
         # dU = (dG W2) * gelu'(U), and db1 = column sums of dU straight from the same epilogue registers
         if _NO_FUSED_BIAS:
             self._dgrad(gb, pf + 'w2', du, T, ff, d, False, gelu_grad_aux_in=L['u'], ldaux=ff)
@@ -531,19 +604,21 @@ class Engine:
             with torch.cuda.stream(self._side):
                 self.grad_hook(a.off, b.off + b.numel)
 
-    def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk, key_mask, causal, dbias=None):
+    def _attn_block_bwd(self, L, pf, names, gy, x_in, q, k, v, dq, dk, dv, ctx, a, attn_save, mean, rstd, lnw, lnb_g, lnw_g, gout, seed, site, p, B, Sq, Sk, key_mask, causal, dbias=None,
+                        T=None, rows=None, row_ids=None):
         """Backward of y = LN(x_in + drop(out_proj(attn(q,k,v)))) up to dq/dk/dv. gy: grad wrt y; gout receives grad wrt x_in
         (residual path only; the projection paths are added by the caller)."""
-        ws, g, d, T = self._cur_ws, self.g, self.d, self._cur_ws['T']
-        gB, gC = ws['gB'], ws['gC']
+        ws, g, d = self._cur_ws, self.g, self.d
+        gB, gC = ws['gB'][:T], ws['gC'][:T]                 # T: rows on the query side
         wo, bo = names
         da = gB if p > 0 else None
         self._before_write(gout, da, dq[0], dk[0], dv[0])
-        ops.add_ln_bwd(gy, x_in, a, lnw, mean, rstd, gout, da, lnw_g, lnb_g, g[bo], self.partials, False, seed, site, p)
+        ops.add_ln_bwd(gy, x_in, a, lnw, mean, rstd, gout, da, lnw_g, lnb_g, g[bo], self.partials, False, seed, site, p, row_ids=row_ids)
         gb = gB if p > 0 else gout
         self._wgrad(gb, ctx, wo, d, d, T)
         self._dgrad(gb, wo, gC, T, d, d, False)
-        return self._attn_bwd((gC, 0, d), q, k, v, dq, dk, dv, B, Sq, Sk, attn_save, out=(ctx, 0, d), key_mask=key_mask, causal=causal, dbias=dbias)
+        return self._attn_bwd((gC, 0, d), q, k, v, dq, dk, dv, B, Sq, Sk, attn_save, out=(ctx, 0, d), key_mask=key_mask, causal=causal, dbias=dbias,
+                              rows=rows)
 
     def backward(self, gy_dec, gy_enc_extra=None):
         """gy_dec: grad wrt decoder output (T,d) storage dtype (None for encoder-only). Writes all parameter gradients
@@ -553,50 +628,56 @@ class Engine:
             raise PBError('backward called without a saved forward')
         ws = self._cur_ws
         B, S, T, d = sv['B'], sv['S'], ws['T'], self.d
+        Te, Td = ws['Te'], ws['Td']                         # rows on the encoder / decoder side (T each unless the step is packed)
+        pack = sv.get('pack')
+        r_enc, r_dec, r_cross = (pack.enc, pack.dec, pack.cross) if pack is not None else (None, None, None)
+        ids_e, ids_d = (pack.src_e, pack.src_d) if pack is not None else (None, None)
         p, seed, wf, g = sv['p'], sv['seed'], self.wf, self.g
         emask, dmask = sv['emask'], sv['dmask']
-        gy, galt = ws['gy']
-        genc = ws['genc']
-        onehot_route = self.code == PB_BF16 and (B * S) % 64 == 0
+        gy, galt = (t[:Td] for t in ws['gy'])
+        genc = ws['genc'][:Te]
+        dq_d, dkv_e, dqkv_d, dqkv_e = ws['dq'][:Td], ws['dkv'][:Te], ws['dqkv'][:Td], ws['dqkv'][:Te]
+        onehot_route = self.code == PB_BF16 and Te % 64 == 0 and Td % 64 == 0
+        base = ws.get('_base', ws)
         if not _NO_DEFER:
             # ~160 bias / LayerNorm-parameter reductions per pass: keep their partial rows and sum them in one launch at the end
-            if 'defer' not in ws:
+            if 'defer' not in base:
                 H, hd, ff = self.H, self.hd, max(self.fe, self.fd)
                 per_layer = 3 * self.partials.numel() + int(LIB.query('pb_gemm_colsum_ws_floats', T, ff)) + \
                     2 * int(LIB.query('pb_flash_bias_ws_floats', B, H, S, S, hd if hd in (64, 96, 128) else 64)) + 64
-                ws['defer'] = (torch.empty((self.NE + self.ND) * per_layer, dtype=torch.float32, device=self.device),
+                base['defer'] = (torch.empty((self.NE + self.ND) * per_layer, dtype=torch.float32, device=self.device),
                                torch.empty(64 * (8 * (self.NE + self.ND) + 8), dtype=torch.uint8, device=self.device))
-            ops.defer_begin(*ws['defer'])
+            ops.defer_begin(*base['defer'])
         if gy_dec is not None:
-            cur = gy_dec
+            cur = gy if gy_dec.data_ptr() == gy.data_ptr() else gy_dec
             for l in reversed(range(self.ND)):
                 L, pf = ws['dec'][l], 'dec.%d.' % l
                 x_in = ws['dec'][l - 1]['y2'] if l > 0 else ws['x_dec']
-                gA = self._ffn_ln_bwd(L, pf, self.fd, cur, L['yc'], seed, self._site('dec', l, 2), p)
+                gA = self._ffn_ln_bwd(L, pf, self.fd, cur, L['yc'], seed, self._site('dec', l, 2), p, Td, row_ids=ids_d)
                 # cross-attention block: y_c = LN(y1 + drop(out_c(attn(q_c(y1), kv_c(enc)))))
                 g1 = gy if cur is not gy else galt
                 fused = self._attn_block_bwd(L, pf, (pf + 'wo_c', pf + 'bo_c'), gA, L['y1'], (L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d),
-                                             (ws['dq'], 0, d), (ws['dkv'], 0, 2 * d), (ws['dkv'], d, 2 * d), L['ctxc'], L['ac'], L['attnc'],
+                                             (dq_d, 0, d), (dkv_e, 0, 2 * d), (dkv_e, d, 2 * d), L['ctxc'], L['ac'], L['attnc'],
                                              L['mc'], L['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1, seed, self._site('dec', l, 1), p, B, S, S, emask, False,
-                                             dbias=(g[pf + 'bq_c'], g[pf + 'bkv_c'][:d], g[pf + 'bkv_c'][d:]))
+                                             dbias=(g[pf + 'bq_c'], g[pf + 'bkv_c'][:d], g[pf + 'bkv_c'][d:]), T=Td, rows=r_cross, row_ids=ids_d)
                 if not fused:
-                    ops.colsum(ws['dq'], g[pf + 'bq_c'], self.partials, T, d)
-                    ops.colsum(ws['dkv'], g[pf + 'bkv_c'], self.partials, T, 2 * d)
-                self._wgrad(ws['dq'], L['y1'], pf + 'wq_c', d, d, T)
-                self._dgrad(ws['dq'], pf + 'wq_c', g1, T, d, d, True)
-                self._wgrad(ws['dkv'], sv['enc_out'], pf + 'wkv_c', 2 * d, d, T)
-                self._dgrad(ws['dkv'], pf + 'wkv_c', genc, T, d, 2 * d, l != self.ND - 1)
+                    ops.colsum(dq_d, g[pf + 'bq_c'], self.partials, Td, d)
+                    ops.colsum(dkv_e, g[pf + 'bkv_c'], self.partials, Te, 2 * d)
+                self._wgrad(dq_d, L['y1'], pf + 'wq_c', d, d, Td)
+                self._dgrad(dq_d, pf + 'wq_c', g1, Td, d, d, True)
+                self._wgrad(dkv_e, sv['enc_out'], pf + 'wkv_c', 2 * d, d, Te)
+                self._dgrad(dkv_e, pf + 'wkv_c', genc, Te, d, 2 * d, l != self.ND - 1)
                 # self-attention block
                 g2 = gy if g1 is not gy else galt
                 bq = g[pf + 'bqkv']
                 fused = self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), g1, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
-                                             (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
+                                             (dqkv_d, 0, 3 * d), (dqkv_d, d, 3 * d), (dqkv_d, 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
                                              L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('dec', l, 0), p, B, S, S, dmask, True,
-                                             dbias=(bq[:d], bq[d:2 * d], bq[2 * d:]))
+                                             dbias=(bq[:d], bq[d:2 * d], bq[2 * d:]), T=Td, rows=r_dec, row_ids=ids_d)
                 if not fused:
-                    ops.colsum(ws['dqkv'], bq, self.partials, T, 3 * d)
-                self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
-                self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
+                    ops.colsum(dqkv_d, bq, self.partials, Td, 3 * d)
+                self._wgrad(dqkv_d, x_in, pf + 'wqkv', 3 * d, d, Td)
+                self._dgrad(dqkv_d, pf + 'wqkv', g2, Td, d, 3 * d, True)
                 cur = g2
                 self._ready(pf + 'wqkv', pf + 'w2')
             if sv.get('alt'):
@@ -613,41 +694,47 @@ class Engine:
             else:
                 ops.embed_ln_bwd(cur, sv['dec16'], self.ptab, wf['lin.b'], wf['dec.pos'], wf['dec.lne.w'], ws['md'], ws['rd'], self.dptab,
                                  g['dec.pos'], g['lin.b'], g['dec.lne.w'], g['dec.lne.b'], self.partials, S, seed, self._site('dec_emb'), p,
-                                 dz_out=ws['dz'][T:] if onehot_route else None, padded=True)
-                if onehot_route:
+                                 dz_out=ws['dz'][Te:Te + Td] if onehot_route else None, padded=True, row_ids=pack.src_d if pack is not None else None)
+                if onehot_route and pack is not None:
+                    ops.pos_grad_packed(ws['dz'][Te:Te + Td], pack.inv_d, g['dec.pos'][2:2 + S], B, S)
+                elif onehot_route:
                     ops.batch_sum(ws['dz'][T:], g['dec.pos'][2:2 + S], B, S * d)
             cur = genc
             if gy_enc_extra is not None:
                 cur = genc.add_(gy_enc_extra)
         else:
             cur = gy_enc_extra
+        gy, galt = (t[:Te] for t in ws['gy'])
         for l in reversed(range(self.NE)):
             L, pf = ws['enc'][l], 'enc.%d.' % l
             x_in = ws['enc'][l - 1]['y2'] if l > 0 else ws['x_enc']
-            gA = self._ffn_ln_bwd(L, pf, self.fe, cur, L['y1'], seed, self._site('enc', l, 1), p)
+            gA = self._ffn_ln_bwd(L, pf, self.fe, cur, L['y1'], seed, self._site('enc', l, 1), p, Te, row_ids=ids_e)
             g2 = gy if cur is not gy else galt
             bq = g[pf + 'bqkv']
             fused = self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), gA, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
-                                         (ws['dqkv'], 0, 3 * d), (ws['dqkv'], d, 3 * d), (ws['dqkv'], 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
+                                         (dqkv_e, 0, 3 * d), (dqkv_e, d, 3 * d), (dqkv_e, 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
                                          L['m1'], L['r1'], wf[pf + 'ln1.w'], g[pf + 'ln1.b'], g[pf + 'ln1.w'], g2, seed, self._site('enc', l, 0), p, B, S, S, emask, False,
-                                         dbias=(bq[:d], bq[d:2 * d], bq[2 * d:]))
+                                         dbias=(bq[:d], bq[d:2 * d], bq[2 * d:]), T=Te, rows=r_enc, row_ids=ids_e)
             if not fused:
-                ops.colsum(ws['dqkv'], bq, self.partials, T, 3 * d)
-            self._wgrad(ws['dqkv'], x_in, pf + 'wqkv', 3 * d, d, T)
-            self._dgrad(ws['dqkv'], pf + 'wqkv', g2, T, d, 3 * d, True)
+                ops.colsum(dqkv_e, bq, self.partials, Te, 3 * d)
+            self._wgrad(dqkv_e, x_in, pf + 'wqkv', 3 * d, d, Te)
+            self._dgrad(dqkv_e, pf + 'wqkv', g2, Te, d, 3 * d, True)
             cur = g2
             self._ready(pf + 'wqkv', pf + 'w2')
         ops.embed_ln_bwd(cur, sv['enc16'], self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], ws['me'], ws['re'], self.dptab,
                          g['enc.pos'], g['lin.b'], g['enc.lne.w'], g['enc.lne.b'], self.partials, S, seed, self._site('enc_emb'), p,
-                         dz_out=ws['dz'][:T] if onehot_route else None, padded=True)
+                         dz_out=ws['dz'][:Te] if onehot_route else None, padded=True, row_ids=pack.src_e if pack is not None else None)
         if onehot_route:
-            # dP = Onehot^T dz over the encoder AND decoder tokens in one split-K MFMA GEMM (K = 2T): no atomics
-            ops.batch_sum(ws['dz'][:T], g['enc.pos'][2:2 + S], B, S * d)
-            ops.onehot_build(sv['enc16'], ws['onehot'][:T], padded=True)
+            # dP = Onehot^T dz over the encoder AND decoder tokens in one split-K MFMA GEMM (K = Te + Td): no atomics
+            if pack is not None:
+                ops.pos_grad_packed(ws['dz'][:Te], pack.inv_e, g['enc.pos'][2:2 + S], B, S)
+            else:
+                ops.batch_sum(ws['dz'][:T], g['enc.pos'][2:2 + S], B, S * d)
+            ops.onehot_build(sv['enc16'], ws['onehot'][:Te], padded=True)
             dec_tab = gy_dec is not None and not sv.get('alt')          # a caller-supplied decoder embedding has no Octuple rows to scatter into
-            K2 = 2 * T if dec_tab else T
+            K2 = Te + Td if dec_tab else Te
             if dec_tab:
-                ops.onehot_build(sv['dec16'], ws['onehot'][T:], padded=True)
+                ops.onehot_build(sv['dec16'], ws['onehot'][Te:Te + Td], padded=True)
             need = 16 * ops.TAB_TOTAL * d
             self._join_side()
             if self._slabs is None or self._slabs.numel() < need:
@@ -674,10 +761,10 @@ class Engine:
 
     def heads_backward(self, dlogits, dec_hidden):
         """dlogits (T,1280) storage dtype -> head grads + grad wrt decoder hidden (returned in ws['gy'][0])."""
-        ws, g, T, d = self._cur_ws, self.g, self._cur_ws['T'], self.d
+        ws, g, T, d = self._cur_ws, self.g, dlogits.shape[0], self.d
         ops.colsum(dlogits, g['head.b'], self.partials, T, ops.VOCAB)
         self._wgrad(dlogits, dec_hidden, 'head.w', ops.VOCAB, d, T)
-        gy = ws['gy'][0]
+        gy = ws['gy'][0][:T]
         self._dgrad(dlogits, 'head.w', gy, T, d, ops.VOCAB, False)
         self._ready('head.w')
         return gy
@@ -734,22 +821,79 @@ class Engine:
         T = B * S
         seed = self._next_seed()
         self._select_grads(False)
-        dec_h, _ = self.forward_hidden(enc16, dec16, emask, dmask, train, seed)
+        pack = self._pack_batch(enc16, dec16, tgt16, loss_mask, emask, dmask) if (_PACK_ROWS and argmax_out is None) else None
+        if pack is not None:
+            enc16, dec16, tgt, lm = pack.enc16, pack.dec16, pack.tgt16, pack.loss_mask
+        else:
+            tgt, lm = tgt16.reshape(T, 8), loss_mask.reshape(T, 8)
+        self.last_rows = (pack.Te, pack.Td, T) if pack is not None else (T, T, T)
+        # (query, key) pairs the three attention forms really cover (bench.py prices the step with them)
+        self.last_pairs = pack.pairs if pack is not None else (B * S * S, B * S * S // 2, B * S * S)
+        dec_h, _ = self.forward_hidden(enc16, dec16, emask, dmask, train, seed, pack=pack)
         logits = self.heads_forward(dec_h)
         ws = self._cur_ws
         sums, counts, coef = self.scal[0:24], self.scal[24:32], self.scal[32:40]
         ops.fill_f32(sums, 0.0)
-        lm = loss_mask.reshape(T, 8)
         ops.mask_count(lm, counts, self.partials)
         if count_hook is not None:
             count_hook(counts)
         ops.loss_coef(counts, self.loss_w if head_w is None else head_w, coef, w_scale)
-        ops.ce_fwd_bwd(logits, tgt16.reshape(T, 8), lm, sums, self.partials, coef, ws['dlogits'] if train else None, argmax_out)
+        ops.ce_fwd_bwd(logits, tgt, lm, sums, self.partials, coef, ws['dlogits'] if train else None, argmax_out)
         if train:
             self.zero_accumulated_grads()
             gy = self.heads_backward(ws['dlogits'], dec_h)
             self.backward(gy)
         return sums
+
+    def _pack_batch(self, enc16, dec16, tgt16, loss_mask, emask, dmask):
+        """Dead-row compaction of one batch (csrc/pb_rowmap.hip has the argument why it changes no result): returns a _RowPack with
+        the packed inputs and the row descriptors of the three attention forms, or None when the step must stay dense (unsupported
+        shape, a decoder mask that is not a prefix mask, or nothing to gain). Costs one small device -> host copy and a stream
+        synchronisation: the packed row counts size every later launch."""
+        B, S = enc16.shape[:2]
+        T = B * S
+        if not (self.use_flash and self.hd in (64, 96, 128) and self.code == PB_BF16 and T % _PACK_TILE == 0 and emask is not None
+                and dmask is not None and self.mlm is not None):
+            return None
+        st = self._pack_state
+        if st is None or st['key'] != (B, S):
+            dev = self.device
+            i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
+            st = self._pack_state = dict(key=(B, S), counts=i32(B, 4), counts_h=torch.empty(B, 4, dtype=torch.int32).pin_memory(),
+                                         desc=i32(6, B), desc_h=torch.empty(6, B, dtype=torch.int32).pin_memory(),
+                                         src_e=i32(T), pos_e=i32(T), inv_e=i32(T), src_d=i32(T), pos_d=i32(T), inv_d=i32(T),
+                                         enc16=torch.empty(T, 8, dtype=torch.int16, device=dev), dec16=torch.empty(T, 8, dtype=torch.int16, device=dev),
+                                         tgt16=torch.empty(T, 8, dtype=torch.int16, device=dev), lm=torch.empty(T, 8, dtype=torch.float32, device=dev))
+        lm3 = loss_mask.reshape(B, S, 8)
+        ops.rowmap_count(emask, dmask, lm3, st['counts'])
+        st['counts_h'].copy_(st['counts'], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        c = st['counts_h'].numpy().astype(np.int64)
+        if not c[:, 3].all():
+            return None
+        (Te, off_e, len_e), (Td, off_d, len_d) = plan_packed_rows(c[:, 0], S), plan_packed_rows(c[:, 2], S)
+        if Te + Td > _PACK_MIN_GAIN * 2 * T:
+            return None
+        st['desc_h'].copy_(torch.from_numpy(np.stack([off_e, len_e, c[:, 0], off_d, len_d, c[:, 1]]).astype(np.int32)))
+        desc = st['desc']
+        desc.copy_(st['desc_h'], non_blocking=True)
+        ops.rowmap_build(emask, None, desc[0], desc[1], st['src_e'], st['pos_e'], st['inv_e'])
+        ops.rowmap_build(dmask, lm3, desc[3], desc[4], st['src_d'], st['pos_d'], st['inv_d'])
+        pk = _RowPack()
+        pk.B, pk.S, pk.Te, pk.Td = B, S, Te, Td
+        pk.src_e, pk.src_d, pk.inv_e, pk.inv_d = st['src_e'], st['src_d'], st['inv_e'], st['inv_d']
+        pk.enc16, pk.dec16, pk.tgt16, pk.loss_mask = st['enc16'][:Te], st['dec16'][:Td], st['tgt16'][:Td], st['lm'][:Td]
+        ops.gather_rows16(enc16, st['src_e'], pk.enc16, Te, 16)
+        ops.gather_rows16(dec16, st['src_d'], pk.dec16, Td, 16)
+        ops.gather_rows16(tgt16, st['src_d'], pk.tgt16, Td, 16)
+        ops.gather_rows16(lm3, st['src_d'], pk.loss_mask, Td, 32)
+        me, md = int(len_e.max()), int(len_d.max())
+        vis_e, vis_d = c[:, 0], c[:, 1]
+        pk.pairs = (int((len_e * vis_e).sum()), int((vis_d * vis_d // 2 + (len_d - vis_d) * vis_d).sum()), int((len_d * vis_e).sum()))
+        pk.enc = ops.PackedRows(desc[0], desc[1], desc[0], desc[1], desc[2], me, me, 'enc')
+        pk.dec = ops.PackedRows(desc[3], desc[4], desc[3], desc[4], desc[5], md, md, 'dec')
+        pk.cross = ops.PackedRows(desc[3], desc[4], desc[0], desc[1], desc[2], md, me, 'cross')
+        return pk
 
     def optimizer_step(self, lr=2e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=3.0, gscale=1.0):
         """clip_grad_norm_(3.0) + HF AdamW on the flat buffers, refreshing the bf16 shadow (pretrain.py:195-196)."""

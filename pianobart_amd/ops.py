@@ -102,15 +102,24 @@ def ids_to_i16(ids):
     return out
 
 
-def embed_ln_fwd(ids16, P, lin_bias, pos, ln_w, ln_b, y, mean, rstd, S, eps, seed, site, p_drop, padded=False):
+def embed_ln_fwd(ids16, P, lin_bias, pos, ln_w, ln_b, y, mean, rstd, S, eps, seed, site, p_drop, padded=False, row_ids=None):
     T, d = y.shape
+    if row_ids is not None:
+        LIB.call('pb_embed_ln_fwd_packed', _p(ids16), _p(row_ids), _p(P), _TAB9 if padded else _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(ln_b),
+                 _p(y), _p(mean), _p(rstd), T, S, d, dtype_code(y.dtype), eps, seed, site, p_drop, _stream())
+        return
     LIB.call('pb_embed_ln_fwd', _p(ids16), _p(P), _TAB9 if padded else _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(ln_b), _p(y), _p(mean),
              _p(rstd), T, S, d, dtype_code(y.dtype), eps, seed, site, p_drop, _stream())
 
 
 def embed_ln_bwd(dy, ids16, P, lin_bias, pos, ln_w, mean, rstd, dP, dpos, dbias, dgamma, dbeta, partials, S, seed, site, p_drop,
-                 dz_out=None, padded=False):
+                 dz_out=None, padded=False, row_ids=None):
     T, d = dy.shape
+    if row_ids is not None:
+        LIB.call('pb_embed_ln_bwd_packed', _p(dy), _p(ids16), _p(row_ids), _p(P), _TAB9 if padded else _SEG9, _p(lin_bias), _p(pos), _p(ln_w),
+                 _p(mean), _p(rstd), _p(dP), _p(dpos), _p(dbias), _p(dgamma), _p(dbeta), _p(partials), _p(dz_out), T, S, d,
+                 dtype_code(dy.dtype), seed, site, p_drop, _stream())
+        return
     LIB.call('pb_embed_ln_bwd', _p(dy), _p(ids16), _p(P), _TAB9 if padded else _SEG9, _p(lin_bias), _p(pos), _p(ln_w), _p(mean), _p(rstd),
              _p(dP), _p(dpos), _p(dbias), _p(dgamma), _p(dbeta), _p(partials), _p(dz_out), T, S, d, dtype_code(dy.dtype), seed, site,
              p_drop, _stream())
@@ -124,14 +133,23 @@ def batch_sum(x, out, B, Sd):
     LIB.call('pb_batch_sum', _p(x), _p(out), B, Sd, dtype_code(x.dtype), _stream())
 
 
-def add_ln_fwd(res, a, ln_w, ln_b, y, mean, rstd, eps, seed, site, p_drop):
+def add_ln_fwd(res, a, ln_w, ln_b, y, mean, rstd, eps, seed, site, p_drop, row_ids=None):
     T, d = y.shape
+    if row_ids is not None:
+        LIB.call('pb_add_ln_fwd_packed', _p(res), _p(a), _p(ln_w), _p(ln_b), _p(y), _p(mean), _p(rstd), _p(row_ids), T, d, dtype_code(y.dtype),
+                 eps, seed, site, p_drop, _stream())
+        return
     LIB.call('pb_add_ln_fwd', _p(res), _p(a), _p(ln_w), _p(ln_b), _p(y), _p(mean), _p(rstd), T, d, dtype_code(y.dtype),
              eps, seed, site, p_drop, _stream())
 
 
-def add_ln_bwd(dy, res, a, ln_w, mean, rstd, dres, da, dgamma, dbeta, dbias_a, partials, accum_dres, seed, site, p_drop):
+def add_ln_bwd(dy, res, a, ln_w, mean, rstd, dres, da, dgamma, dbeta, dbias_a, partials, accum_dres, seed, site, p_drop, row_ids=None):
     T, d = dy.shape
+    if row_ids is not None:
+        LIB.call('pb_add_ln_bwd_packed', _p(dy), _p(res), _p(a), _p(ln_w), _p(mean), _p(rstd), _p(dres), _p(da), _p(dgamma), _p(dbeta),
+                 _p(dbias_a), _p(partials), _p(row_ids), T, d, dtype_code(dy.dtype), int(dres.dtype == torch.float32 and dy.dtype != torch.float32),
+                 int(accum_dres), seed, site, p_drop, _stream())
+        return
     LIB.call('pb_add_ln_bwd', _p(dy), _p(res), _p(a), _p(ln_w), _p(mean), _p(rstd), _p(dres), _p(da), _p(dgamma), _p(dbeta),
              _p(dbias_a), _p(partials), T, d, dtype_code(dy.dtype), int(dres.dtype == torch.float32 and dy.dtype != torch.float32),
              int(accum_dres), seed, site, p_drop, _stream())
@@ -214,6 +232,51 @@ def flash_bwd(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, 
              pp(dkt, dko), pp(dvt, dvo), _p(delta), B, H, Sq, Sk, hd, qb, qs, kb, ks, vb, vs, ob, os_, dqb, dqs, dkb, dks, dvb, dvs,
              scale, int(causal) | (2 if force_generic else 0), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
              _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _stream())
+
+
+class PackedRows:
+    """Row descriptors of one packed attention call (include/pianobart_hip.h, pb_flash_*_packed): device int32 (B) tensors plus
+    the two maxima."""
+
+    def __init__(self, q_off, q_len, k_off, k_len, k_vis, Sq_max, Sk_max, kind=''):
+        self.q_off, self.q_len, self.k_off, self.k_len, self.k_vis, self.Sq_max, self.Sk_max = q_off, q_len, k_off, k_len, k_vis, Sq_max, Sk_max
+        self.kind = kind                    # a label for profiles ('enc', 'dec', 'cross')
+
+
+def flash_fwd_packed(q, k, v, o, lse, rows, B, H, hd, scale, causal):
+    """q,k,v,o: (tensor, element offset, row stride) bf16 over packed rows."""
+    (qt, qo, qs), (kt, ko, ks), (vt, vo, vs), (ot, oo, os_) = q, k, v, o
+    pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 2 * off)
+    LIB.call('pb_flash_fwd_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(lse), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off),
+             _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd, qs, ks, vs, os_, scale, int(causal), _stream())
+
+
+def flash_bwd_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, scale, causal, dbias=None, dbias_ws=None):
+    (qt, qo, qs), (kt, ko, ks), (vt, vo, vs), (ot, oo, os_) = q, k, v, o
+    (dqt, dqo, dqs), (dkt, dko, dks), (dvt, dvo, dvs) = dq, dk, dv
+    pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 2 * off)
+    LIB.call('pb_flash_bwd_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), pp(dqt, dqo), pp(dkt, dko), pp(dvt, dvo),
+             _p(delta), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off), _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd,
+             qs, ks, vs, os_, dqs, dks, dvs, scale, int(causal), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
+             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _stream())
+
+
+def rowmap_count(emask, dmask, loss_mask, counts):
+    B, S = emask.shape
+    LIB.call('pb_rowmap_count', _p(emask), _p(dmask), _p(loss_mask), _p(counts), B, S, _stream())
+
+
+def rowmap_build(mask, loss_mask, off, length, row_src, row_pos, inv):
+    B, S = mask.shape
+    LIB.call('pb_rowmap_build', _p(mask), _p(loss_mask), _p(off), _p(length), _p(row_src), _p(row_pos), _p(inv), B, S, _stream())
+
+
+def gather_rows16(src, row_src, dst, n_rows, row_bytes):
+    LIB.call('pb_gather_rows16', _p(src), _p(row_src), _p(dst), n_rows, row_bytes, _stream())
+
+
+def pos_grad_packed(x, inv, out, B, S):
+    LIB.call('pb_pos_grad_packed', _p(x), _p(inv), _p(out), B, S, x.shape[1], dtype_code(x.dtype), _stream())
 
 
 def corrupt(ids16, out16, loss_mask, choice, choice_out, mask_percent, seed, pad_row, mask_row, n_tokens):

@@ -1,0 +1,283 @@
+"""Dead-row compaction (packed rows): the row-map kernels against numpy, and the packed attention / embedding kernels against the
+dense kernels on the same rows. A packed batch holds, for every sequence, its visible rows first, so on those rows the packed
+kernels walk exactly the tiles the dense ones walk: outputs must agree bit for bit; column sums (bias gradients) are summed in a
+different block structure and agree to f32 rounding."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from pianobart_amd import ops as o
+    return o
+
+
+def _i32(x):
+    return torch.tensor(np.asarray(x), dtype=torch.int32, device='cuda')
+
+
+def _rowmap_numpy(mask, loss_mask, off, length):
+    B, S = mask.shape
+    row_src = -np.ones(int(off[-1] + length[-1]), np.int64)
+    inv = -np.ones((B, S), np.int64)
+    for b in range(B):
+        vis = [s for s in range(S) if mask[b, s] != 0]
+        los = [s for s in range(S) if mask[b, s] == 0 and loss_mask is not None and loss_mask[b, s].any()]
+        dead = [s for s in range(S) if s not in set(vis) | set(los)]
+        order = (vis + los + dead)[:length[b]]
+        for i, s in enumerate(order):
+            row_src[off[b] + i] = b * S + s
+            inv[b, s] = off[b] + i
+    return row_src, inv
+
+
+def test_rowmap_kernels_match_numpy(ops):
+    rng = np.random.default_rng(0)
+    B, S = 5, 333
+    emask = (rng.random((B, S)) > 0.3).astype(np.float32)
+    L = rng.integers(1, S, size=B)
+    dmask = (np.arange(S)[None, :] < L[:, None]).astype(np.float32)
+    dmask[3, 5] = 0                                                      # batch 3: not a prefix mask
+    lm = np.zeros((B, S, 8), np.float32)
+    lm[rng.random((B, S)) > 0.8, 3] = 1.0
+    counts = torch.empty(B, 4, dtype=torch.int32, device='cuda')
+    te, td, tl = (torch.tensor(x, device='cuda') for x in (emask, dmask, lm))
+    ops.rowmap_count(te, td, tl, counts)
+    c = counts.cpu().numpy()
+    assert (c[:, 0] == (emask != 0).sum(1)).all() and (c[:, 1] == (dmask != 0).sum(1)).all()
+    assert (c[:, 2] == ((dmask != 0) | lm.any(-1)).sum(1)).all()
+    assert c[:, 3].tolist() == [1, 1, 1, 0, 1]
+    for mask, t_mask, loss, t_loss in ((emask, te, None, None), (dmask, td, lm, tl)):
+        live = (mask != 0).sum(1) if loss is None else ((mask != 0) | loss.any(-1)).sum(1)
+        length = np.minimum(live + rng.integers(0, 7, size=B), S)       # a few dead fillers per sequence
+        off = np.concatenate([[0], np.cumsum(length)[:-1]])
+        Tp = int(length.sum())
+        row_src, row_pos, inv = (torch.full((n,), -7, dtype=torch.int32, device='cuda') for n in (Tp, Tp, B * S))
+        ops.rowmap_build(t_mask, t_loss, _i32(off), _i32(length), row_src, row_pos, inv)
+        want_src, want_inv = _rowmap_numpy(mask, loss, off, length)
+        assert (row_src.cpu().numpy() == want_src).all()
+        assert (row_pos.cpu().numpy() == want_src % S).all()
+        assert (inv.cpu().numpy().reshape(B, S) == want_inv).all()
+        # gather + the position-table sum through the inverse map
+        src = torch.randn(B * S, 8, device='cuda')
+        dst = torch.empty(Tp, 8, device='cuda')
+        ops.gather_rows16(src, row_src, dst, Tp, 32)
+        assert torch.equal(dst, src[row_src.long()])
+        x = torch.randn(Tp, 64, device='cuda').to(torch.bfloat16)
+        out = torch.ones(S, 64, device='cuda')
+        ops.pos_grad_packed(x, inv, out, B, S)
+        want = torch.ones(S, 64, device='cuda', dtype=torch.float64)
+        want.index_add_(0, (row_src % S).long(), x.double())
+        assert float((out.double() - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('hd', [64, 128])
+@pytest.mark.parametrize('kind', ['self', 'causal', 'cross'])
+def test_packed_attention_equals_dense_on_the_kept_rows(ops, hd, kind):
+    g = torch.Generator(device='cuda').manual_seed(hd)
+    B, H, S = 4, 3, 384
+    d = H * hd
+    scale = hd ** -0.5
+    causal = kind == 'causal'
+    kvis = [300, 129, 384, 64]                                         # visible keys (a prefix of each sequence)
+    klen = [310, 129, 384, 200]                                        # key rows kept (the rest of the kept rows are invisible)
+    qlen = klen if kind != 'cross' else [257, 384, 100, 128]
+    q = (torch.randn(B, S, d, device='cuda', generator=g) * 1.5).to(torch.bfloat16)
+    kv = (torch.randn(B, S, 2 * d, device='cuda', generator=g) * 1.5).to(torch.bfloat16)
+    dout = torch.randn(B, S, d, device='cuda', generator=g).to(torch.bfloat16)
+    for b in range(B):
+        dout[b, qlen[b]:] = 0                                          # dropped query rows: dead in the dense run too
+    km = torch.zeros(B, S, device='cuda')
+    for b in range(B):
+        km[b, :kvis[b]] = 1
+    kmax = _i32(kvis)
+    # dense run
+    o_d = torch.zeros(B, S, d, device='cuda', dtype=torch.bfloat16)
+    lse_d, delta_d = torch.empty(B, H, S, device='cuda'), torch.empty(B, H, S, device='cuda')
+    dq_d, dkv_d = torch.zeros_like(q), torch.zeros_like(kv)
+    ex = lambda t, off, ld: (t, off, ld, S * ld)
+    ops.flash_fwd(ex(q, 0, d), ex(kv, 0, 2 * d), ex(kv, d, 2 * d), ex(o_d, 0, d), lse_d, km, B, H, S, S, hd, scale, causal, kmax=kmax)
+    need = int(ops.LIB.query('pb_flash_bias_ws_floats', B, H, S, S, hd))
+    wsb = torch.empty(need, device='cuda')
+    db_d = [torch.zeros(d, device='cuda') for _ in range(3)]
+    ops.flash_bwd(ex(q, 0, d), ex(kv, 0, 2 * d), ex(kv, d, 2 * d), ex(o_d, 0, d), dout, lse_d, km, ex(dq_d, 0, d), ex(dkv_d, 0, 2 * d),
+                  ex(dkv_d, d, 2 * d), delta_d, B, H, S, S, hd, scale, causal, kmax=kmax, dbias=db_d, dbias_ws=wsb)
+    # packed run on the kept rows
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]])
+    koff = np.concatenate([[0], np.cumsum(klen)[:-1]])
+    pk = lambda t, lens: torch.cat([t[b, :lens[b]] for b in range(B)]).contiguous()
+    qp, kvp, doutp = pk(q, qlen), pk(kv, klen), pk(dout, qlen)
+    Tq, Tk = qp.shape[0], kvp.shape[0]
+    rows = ops.PackedRows(_i32(qoff), _i32(qlen), _i32(koff), _i32(klen), kmax, max(qlen), max(klen))
+    o_p = torch.full((Tq, d), float('nan'), device='cuda', dtype=torch.bfloat16)
+    lse_p = torch.full((B, H, max(qlen)), float('nan'), device='cuda')
+    delta_p = torch.empty(B, H, max(qlen), device='cuda')
+    dq_p = torch.full((Tq, d), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dkv_p = torch.full((Tk, 2 * d), float('nan'), device='cuda', dtype=torch.bfloat16)
+    ops.flash_fwd_packed((qp, 0, d), (kvp, 0, 2 * d), (kvp, d, 2 * d), (o_p, 0, d), lse_p, rows, B, H, hd, scale, causal)
+    db_p = [torch.zeros(d, device='cuda') for _ in range(3)]
+    wsb2 = torch.full((int(ops.LIB.query('pb_flash_bias_ws_floats', B, H, max(qlen), max(klen), hd)),), float('nan'), device='cuda')
+    ops.flash_bwd_packed((qp, 0, d), (kvp, 0, 2 * d), (kvp, d, 2 * d), (o_p, 0, d), doutp, lse_p, (dq_p, 0, d), (dkv_p, 0, 2 * d),
+                         (dkv_p, d, 2 * d), delta_p, rows, B, H, hd, scale, causal, dbias=db_p, dbias_ws=wsb2)
+    torch.cuda.synchronize()
+    assert torch.equal(o_p, pk(o_d, qlen))
+    for b in range(B):
+        assert torch.equal(lse_p[b, :, :qlen[b]], lse_d[b, :, :qlen[b]])
+    assert torch.equal(dq_p, pk(dq_d, qlen))
+    assert torch.equal(dkv_p, pk(dkv_d, klen))
+    for b in range(B):                                                 # invisible kept key rows get exact zeros
+        assert not dkv_p[koff[b] + kvis[b]:koff[b] + klen[b]].any()
+    for a, b_ in zip(db_p, db_d):
+        assert torch.isfinite(a).all()
+        assert float((a - b_).abs().max()) <= 2e-5 * max(1.0, float(b_.abs().max()))
+
+
+def test_packed_embedding_equals_dense_rows(ops):
+    from tests.golden_util import synth_octuple_batch
+    B, S, d = 3, 128, 256
+    enc = synth_octuple_batch(B, S, seed=5)[0].cuda()
+    ids16 = ops.ids_to_i16(enc)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    P = torch.randn(ops.TAB_TOTAL, d, device='cuda', generator=g)
+    lin_b, pos = torch.randn(d, device='cuda', generator=g), torch.randn(S + 2, d, device='cuda', generator=g)
+    w, bb = torch.randn(d, device='cuda', generator=g), torch.randn(d, device='cuda', generator=g)
+    y = torch.empty(B * S, d, device='cuda', dtype=torch.bfloat16)
+    m, r = torch.empty(B * S, device='cuda'), torch.empty(B * S, device='cuda')
+    seed, pd = 1234, 0.1                                               # dropout on: a packed row draws the bits of its row in the padded batch
+    ops.embed_ln_fwd(ids16, P, lin_b, pos, w, bb, y, m, r, S, 1e-5, seed, 0, pd, padded=True)
+    keep = torch.tensor([5, 0, 130, 131, 255, 300, 383, 17], device='cuda', dtype=torch.int32)
+    ids_p = torch.empty(len(keep), 8, dtype=torch.int16, device='cuda')
+    ops.gather_rows16(ids16, keep, ids_p, len(keep), 16)
+    yp = torch.empty(len(keep), d, device='cuda', dtype=torch.bfloat16)
+    mp, rp = torch.empty(len(keep), device='cuda'), torch.empty(len(keep), device='cuda')
+    ops.embed_ln_fwd(ids_p, P, lin_b, pos, w, bb, yp, mp, rp, S, 1e-5, seed, 0, pd, padded=True, row_ids=keep)
+    assert torch.equal(yp, y[keep.long()]) and torch.equal(mp, m[keep.long()]) and torch.equal(rp, r[keep.long()])
+    # backward (dz route): dz rows equal the dense dz rows
+    partials = torch.empty(int(ops.LIB.query('pb_ln_partials_floats', d)), device='cuda')
+    dy = torch.randn(B * S, d, device='cuda', generator=g).to(torch.bfloat16)
+    dz = torch.empty_like(dy)
+    gv = lambda: [torch.zeros(d, device='cuda') for _ in range(3)]
+    ga = gv()
+    ops.embed_ln_bwd(dy, ids16, P, lin_b, pos, w, m, r, None, None, ga[0], ga[1], ga[2], partials, S, seed, 0, pd, dz_out=dz, padded=True)
+    dzp = torch.empty(len(keep), d, device='cuda', dtype=torch.bfloat16)
+    gb = gv()
+    ops.embed_ln_bwd(dy[keep.long()].contiguous(), ids_p, P, lin_b, pos, w, mp, rp, None, None, gb[0], gb[1], gb[2], partials, S, seed, 0, pd,
+                     dz_out=dzp, padded=True, row_ids=keep)
+    assert torch.equal(dzp, dz[keep.long()])
+    # residual + dropout + LayerNorm on packed rows: the same bits, so the same rows
+    res = torch.randn(B * S, d, device='cuda', generator=g).to(torch.bfloat16)
+    a = torch.randn(B * S, d, device='cuda', generator=g).to(torch.bfloat16)
+    ops.add_ln_fwd(res, a, w, bb, y, m, r, 1e-5, seed, 5, pd)
+    kl = keep.long()
+    ops.add_ln_fwd(res[kl].contiguous(), a[kl].contiguous(), w, bb, yp, mp, rp, 1e-5, seed, 5, pd, row_ids=keep)
+    assert torch.equal(yp, y[kl]) and torch.equal(mp, m[kl]) and torch.equal(rp, r[kl])
+    dres, da = torch.empty_like(dy), torch.empty_like(dy)
+    ops.add_ln_bwd(dy, res, a, w, m, r, dres, da, ga[0], ga[1], ga[2], partials, False, seed, 5, pd)
+    dresp, dap = torch.empty_like(dzp), torch.empty_like(dzp)
+    ops.add_ln_bwd(dy[kl].contiguous(), res[kl].contiguous(), a[kl].contiguous(), w, mp, rp, dresp, dap, gb[0], gb[1], gb[2], partials, False, seed, 5, pd,
+                   row_ids=keep)
+    assert torch.equal(dresp, dres[kl]) and torch.equal(dap, da[kl])
+
+
+def _step(eng, args, pack, monkeypatch, seed=77, train=True):
+    from pianobart_amd import engine as E
+    monkeypatch.setattr(E, '_PACK_ROWS', 1 if pack else 0)
+    eng._seed = seed
+    sums = eng.loss_and_grads(*args, train=train).clone()
+    torch.cuda.synchronize()
+    return sums, eng.G32.clone(), eng.last_rows
+
+
+@pytest.mark.parametrize('heads,tail_loss,hole,dropout', [(4, False, False, 0.0), (4, True, False, 0.1), (2, True, True, 0.1)])
+def test_packed_step_equals_dense_step(ops, monkeypatch, heads, tail_loss, hole, dropout):
+    """The fused pre-train step with the dead rows dropped gives the dense step's loss sums and gradients, dropout included (a
+    packed row draws the dropout bits of its row in the padded batch). The comparison is to bf16 rounding: the
+    GEMMs pick their tile shape by the row count, so a kept row's f32 sums are not accumulated in the same order in both runs
+    (measured: hidden states differ by one bf16 ulp, gradient slots by 1e-3 .. 5e-3 relative); the kernels themselves are compared
+    bit for bit above."""
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab, randomize_params, synth_octuple_batch
+    e2w, w2e = load_vocab()
+    B, S, d = 6, 256, 256
+    cfg = BartConfig(max_position_embeddings=S, d_model=d, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+                     encoder_attention_heads=heads, decoder_attention_heads=heads, dropout=dropout)
+    m = PianoBartLM(PianoBart(cfg, e2w, w2e, precision='bf16'))
+    randomize_params(m, 11)
+    m = m.train().cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(B, S, seed=9)]
+    rng = np.random.default_rng(3)
+    Le, Ld = rng.integers(40, S + 1, size=B), rng.integers(40, S + 1, size=B)
+    Le[0], Ld[1] = S, S
+    emask, dmask, loss_mask = emask.clone().float(), dmask.clone().float(), loss_mask.clone().float()
+    for b in range(B):
+        emask[b, :Le[b]] = 1; emask[b, Le[b]:] = 0
+        if hole:
+            emask[b, 3] = 0                                             # an invisible encoder row inside the sequence
+        dmask[b, :Ld[b]] = 1; dmask[b, Ld[b]:] = 0
+        loss_mask[b, Ld[b]:] = 0
+        loss_mask[b, :Ld[b], 0] = 1
+        if tail_loss and Ld[b] + 5 < S:
+            loss_mask[b, Ld[b] + 2, :] = 1                              # loss terms on rows that are not visible as keys
+            loss_mask[b, S - 1, 2] = 1
+    args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+    s0, g0, r0 = _step(eng, args, False, monkeypatch)
+    s1, g1, r1 = _step(eng, args, True, monkeypatch)
+    assert r0 == (B * S, B * S, B * S) and r1[0] < B * S and r1[1] < B * S and r1[0] % 256 == 0 and r1[1] % 256 == 0, (r0, r1)
+    assert torch.equal(s0[8:16], s1[8:16])                              # the mask counts
+    rt, gt = 1e-3, (4e-2 if hole else 2e-2)      # a hole in the encoder mask moves the later keys up by one: other tiles, other roundings
+    assert torch.allclose(s0[:8], s1[:8], rtol=rt), (s0 - s1).abs().max()
+    assert float((s0[16:] - s1[16:]).abs().max()) <= 2                  # argmax hits: a near tie may flip
+    assert torch.isfinite(g1).all()
+    worst = ('', 0.0)
+    for name, sl in eng.slots.items():
+        a, b_ = g0[sl.off:sl.off + sl.numel], g1[sl.off:sl.off + sl.numel]
+        err = float((a - b_).norm()) / (float(a.norm()) + 1e-12)
+        worst = max(worst, (name, err), key=lambda t: t[1])
+    print('packed vs dense: worst gradient slot', worst)
+    assert worst[1] < gt, worst
+    # evaluation (no backward) packs too
+    e0 = _step(eng, args, False, monkeypatch, train=False)[0]
+    e1 = _step(eng, args, True, monkeypatch, train=False)[0]
+    assert torch.allclose(e0[:16], e1[:16], rtol=rt) and float((e0[16:] - e1[16:]).abs().max()) <= 2
+    # a decoder mask with a hole cannot be packed: the step stays dense
+    dm2 = dmask.clone(); dm2[2, 7] = 0
+    r2 = _step(eng, args[:5] + (dm2,), True, monkeypatch)[2]
+    assert r2 == (B * S, B * S, B * S)
+
+
+@pytest.mark.parametrize('M,N,K,lay', [(26624, 768, 3072, 'NT'), (26880, 768, 2304, 'NN'), (26624, 768, 768, 'NT'), (32768, 768, 3072, 'NN'),
+                                       (3328, 768, 3072, 'NT'), (26624 + 40, 768, 1536, 'NN')])
+@pytest.mark.parametrize('epi', ['bias', 'accum', 'f32'])
+def test_gemm_tail_split_matches_whole_tiles(ops, M, N, K, lay, epi):
+    """With PB_GEMM_TAIL_SPLIT the persistent 256x256 GEMM may cut the tiles of a partly filled last round into K ranges
+    (pb_gemm2.hip). Against the same GEMM without the flag: equal up to the order of the f32 partial sums (one bf16 ulp after
+    rounding), and both against an fp32 matmul."""
+    from pianobart_amd._lib import PB_BF16
+    g = torch.Generator(device='cuda').manual_seed(M + K)
+    A = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16)
+    Bm = (torch.randn(N, K, device='cuda', generator=g) * K ** -0.5).to(torch.bfloat16)
+    Bop = Bm if lay == 'NT' else Bm.t().contiguous()                   # NN: B stored [K][N]
+    bias = torch.randn(N, device='cuda', generator=g) if epi == 'bias' else None
+    c32 = epi == 'f32'
+    C0 = torch.randn(M, N, device='cuda', generator=g).to(torch.float32 if c32 else torch.bfloat16)
+    outs = []
+    for flags in (0, 32768):
+        C = C0.clone()
+        ops.gemm(A, Bop, C, M=M, N=N, K=K, dtype=PB_BF16, b_kc=(lay == 'NT'), bias=bias, accum=(epi == 'accum'), c_f32=c32, dbg=flags)
+        outs.append(C.float())
+    ref = A.float() @ Bm.float().t()
+    if bias is not None:
+        ref += bias
+    if epi == 'accum':
+        ref += C0.float()
+    tol = 1e-4 if c32 else 2e-2
+    for o in outs:
+        assert float((o - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) <= (1e-5 if c32 else 1.6e-2) * max(1.0, float(ref.abs().max()))

@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pianobart_amd import ops
 T, N, K = 32768, 3072, 768
+for a in sys.argv[1:]:
+    if a.startswith('--M='):
+        T = int(a[4:])                      # packed step: the encoder / decoder side row counts of the bench batch
 x = torch.randn(T, K, device='cuda').to(torch.bfloat16); w = torch.randn(N, K, device='cuda').to(torch.bfloat16)
 out = torch.empty(T, N, device='cuda', dtype=torch.bfloat16); aux = torch.empty_like(out)
 bias = torch.randn(N, device='cuda')
