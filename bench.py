@@ -34,13 +34,15 @@ def train_flops_per_token(S, d, N, f, V=1280):
     return 3 * 2 * macs / S
 
 
-def train_flops_live_rows(Te, Td, pairs, d, N, f, V=1280):
+def train_flops_live_rows(Te, Td, pairs, d, N, f, V=1280, Ts=None):
     """train_flops_per_token's graph restricted to the rows the step keeps (dead-row compaction): Te encoder-side and Td
-    decoder-side rows, pairs = (query, key) pairs covered by the encoder self-, decoder self- (causal) and cross-attention
-    (each pair costs 2 d MACs forward: QK^T and PV over all heads). With Te = Td = B S and pairs = (B S^2, B S^2 / 2, B S^2)
-    this is train_flops_per_token x B S."""
-    macs = (Te + Td) * 2048 * d + N * Te * (4 * d * d + 2 * d * f) + N * Td * (6 * d * d + 2 * d * f) + N * Te * 2 * d * d \
-        + N * 2 * d * (pairs[0] + pairs[1] + pairs[2]) + Td * d * V
+    decoder-side rows, Ts <= Td rows on the query side of the LAST decoder layer (cross-attention block, FFN) and under the LM
+    heads, pairs = (query, key) pairs covered per layer by the encoder self-, decoder self- (causal) and cross-attention (each
+    pair costs 2 d MACs forward: QK^T and PV over all heads). With Te = Td = Ts = B S and pairs = (B S^2, B S^2 / 2, B S^2) this
+    is train_flops_per_token x B S."""
+    Ts = Td if Ts is None else Ts
+    macs = (Te + Td) * 2048 * d + N * Te * (4 * d * d + 2 * d * f) + N * Td * 4 * d * d + ((N - 1) * Td + Ts) * (2 * d * d + 2 * d * f) \
+        + N * Te * 2 * d * d + N * 2 * d * (pairs[0] + pairs[1] + pairs[2]) + Ts * d * V
     return 3 * 2 * macs
 
 
@@ -330,8 +332,8 @@ def main():
     ref_tflops_per_gpu = fpt * B * S / (ms_per_step * 1e-3) / 1e12               # the reference graph: every padded row credited
     peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3
     T = B * S
-    Te, Td, _ = eng.last_rows
-    live_flops = train_flops_live_rows(Te, Td, eng.last_pairs, args.hs, args.layers, args.ffn)
+    Te, Td, _, Ts = eng.last_rows
+    live_flops = train_flops_live_rows(Te, Td, eng.last_pairs, args.hs, args.layers, args.ffn, Ts=Ts)
     step_tflops_per_gpu = live_flops / (ms_per_step * 1e-3) / 1e12              # the rows and (query, key) pairs the step computes
 
     # ---- roofline of the dominant kernel AS LAUNCHED BY THE STEP (fc1: NT T x ffn x d + bias + GELU + derivative out), and the
@@ -388,9 +390,10 @@ def main():
             "tokens_per_s_per_gpu": value / world,
             "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / peak,
             "reference_graph_tflops_per_gpu": ref_tflops_per_gpu,
-            "rows": {"encoder_side": Te, "decoder_side": Td, "padded": T,
+            "rows": {"encoder_side": Te, "decoder_side": Td, "last_decoder_layer_query_side_and_heads": Ts, "padded": T,
                      "note": "dead-row compaction: rows that are neither visible as attention keys nor carry a loss term are dropped from the "
-                             "step (results unchanged, tests/test_packed_gpu.py); `value` counts all B x S tokens of the batch, the unit the "
+                             "step, and the last decoder layer's cross-attention block, FFN and the LM heads run on the rows with a loss term "
+                             "only (results unchanged, tests/test_packed_gpu.py); `value` counts all B x S tokens of the batch, the unit the "
                              "reference's own tokens/s is in; step_tflops_per_gpu / step_mfma_frac / roofline count only the rows and "
                              "(query, key) pairs that are computed; PB_PACK_ROWS=0 runs the dense step"},
             "train_loss": loss,

@@ -44,8 +44,8 @@ const char* pb_last_error(void);
 #define PB_GEMM_FORCE_192 16384  /* A/B runs: always pick the 256x192 tile when the 256-row kernel is used               */
 #define PB_GEMM_TAIL_SPLIT 32768 /* 256x256 kernel: the tiles of a partly filled last round of the grid may be cut into K ranges that
                                     occupy the idle CUs (f32 partials, finished by a second small launch); a cost model decides.
-                                    Pays for a caller that runs one GEMM at a time (N = 768 at 26 624 rows: +13-17 %); the training
-                                    step fills those CUs from its second stream and does not ask for it                   */
+                                    Pays for a caller that runs one GEMM at a time (N = 768 at 26 624 rows: +13-17 %): the training
+                                    step asks for it in forward; in backward its second stream already fills those CUs     */
 typedef struct pb_gemm_desc {
     const void* A; const void* B; void* C;
     const float* bias;            /* per-n, may be NULL */
@@ -178,18 +178,25 @@ int pb_flash_bwd_packed(const void* q, const void* k, const void* v, const void*
                         float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* stream);
 
 /* ---- row maps for the packed step (pb_rowmap.hip) ------------------------------------------------
- * pb_rowmap_count: counts (B,4) int32 = {encoder rows visible as keys (emask != 0), decoder rows visible as keys (dmask != 0),
- *   decoder live rows (visible, or loss_mask (B,S,8) row != 0), 1 iff the visible decoder positions are exactly 0 .. L-1}.
+ * pb_rowmap_count: counts (B,8) int32 = {encoder rows visible as keys (emask != 0), decoder rows visible as keys (dmask != 0),
+ *   decoder live rows (visible, or loss_mask (B,S,8) row != 0), 1 iff the visible decoder positions are exactly 0 .. L-1,
+ *   decoder rows with a loss term, 0, 0, 0}.
  * pb_rowmap_build: batch b's packed rows off[b] .. off[b] + len[b] - 1 = its positions with mask != 0 (ascending), then those
  *   with a loss term (loss_mask may be NULL), then its first remaining (dead) positions up to len[b]; row_src[r] = b*S + s and
  *   row_pos[r] = s for packed row r, inv (B*S) = packed row of (b, s) or -1. len[b] must cover the first two classes.
- * pb_gather_rows16: dst row r = src row row_src[r] (row_bytes a multiple of 16).
+ * pb_rowmap_build_sub: the rows of an existing packing (present (B*S) = its `inv`) that the LAST decoder layer's query side needs:
+ *   batch b's rows off[b] .. + len[b] - 1 = its positions with a loss term (ascending), then other positions of the packing;
+ *   row_src[r] = b*S + s, row_idx[r] = present[b*S + s] (the row of the existing packing). len[b] <= rows of b in that packing.
+ * pb_gather_rows16: dst row r = src row row_src[r] (row_bytes a multiple of 16). pb_scatter_rows16: dst row row_dst[r] = src row r.
  * pb_pos_grad_packed: out (S,d) f32 += sum_b x[inv[b][s]] (the position-table gradient; replaces pb_batch_sum). */
 int pb_rowmap_count(const float* emask, const float* dmask, const float* loss_mask, int32_t* counts, int32_t B, int32_t S,
                     void* stream);
 int pb_rowmap_build(const float* mask, const float* loss_mask, const int32_t* off, const int32_t* len, int32_t* row_src,
                     int32_t* row_pos, int32_t* inv, int32_t B, int32_t S, void* stream);
+int pb_rowmap_build_sub(const float* loss_mask, const int32_t* present, const int32_t* off, const int32_t* len,
+                        int32_t* row_src, int32_t* row_idx, int32_t B, int32_t S, void* stream);
 int pb_gather_rows16(const void* src, const int32_t* row_src, void* dst, int64_t n_rows, int32_t row_bytes, void* stream);
+int pb_scatter_rows16(const void* src, const int32_t* row_dst, void* dst, int64_t n_rows, int32_t row_bytes, void* stream);
 int pb_pos_grad_packed(const void* x, const int32_t* inv, float* out, int32_t B, int32_t S, int32_t d, int32_t dtype,
                        void* stream);
 

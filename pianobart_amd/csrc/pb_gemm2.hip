@@ -747,9 +747,10 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
             // tools/gemm_tail_ab.py): a split saves nkt - ceil(nkt / split) steps of the last round and costs the finishing launch
             // (~5 us) plus the trip of rem x split f32 tiles (256 KiB each) out to the slabs and back at ~5 TB/s. Measured at
             // 26 624 rows: K = 3072 154 -> 134 us, K = 2304 128 -> 107 us; K = 768 loses (46 -> 52 us) and so does a half-full round
-            // (32 768 rows, 138 -> 136 us): the model turns those down. Only on request (PB_GEMM_TAIL_SPLIT): in the training step the
-            // second stream's weight-gradient GEMMs already fill the CUs a short last round leaves idle, and the same-box A/B of the
-            // whole step showed no gain (62.4 vs 62.6 ms); a single-stream caller gets the 13-17 % of the table above.
+            // (32 768 rows, 138 -> 136 us): the model turns those down. Only on request (PB_GEMM_TAIL_SPLIT): in the backward pass of the
+            // training step the second stream's weight-gradient GEMMs already fill the CUs a short last round leaves idle (allowed
+            // everywhere, the same-box A/B of the whole step showed no gain: 62.4 vs 62.6 ms); the forward projections, which run
+            // alone, ask for it.
             const int smax = std::min(std::min(ncu / rem, nkt / 3), 8);
             int best = 1; float best_net = 0.f;
             for (int sp = 2; sp <= smax; ++sp) {

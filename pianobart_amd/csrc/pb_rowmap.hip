@@ -27,39 +27,47 @@ __device__ __forceinline__ bool row_has_loss(const float* __restrict__ loss_mask
 __global__ __launch_bounds__(256) void rowmap_count_kernel(const float* __restrict__ emask, const float* __restrict__ dmask,
                                                            const float* __restrict__ loss_mask, int* __restrict__ counts, int S) {
     const int b = blockIdx.x, t = threadIdx.x;
-    int ev = 0, dv = 0, last = 0, live = 0;
+    int ev = 0, dv = 0, last = 0, live = 0, nloss = 0;
     for (int s = t; s < S; s += 256) {
         const long row = (long)b * S + s;
         ev += emask[row] != 0.f;
-        const bool v = dmask[row] != 0.f;
+        const bool v = dmask[row] != 0.f, hl = row_has_loss(loss_mask, row);
         dv += v;
         if (v) last = max(last, s + 1);
-        live += v || row_has_loss(loss_mask, row);
+        live += v || hl;
+        nloss += hl;
     }
-    __shared__ int red[4][256];
-    red[0][t] = ev; red[1][t] = dv; red[2][t] = last; red[3][t] = live;
+    __shared__ int red[5][256];
+    red[0][t] = ev; red[1][t] = dv; red[2][t] = last; red[3][t] = live; red[4][t] = nloss;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (t < o) {
             red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] = max(red[2][t], red[2][t + o]); red[3][t] += red[3][t + o];
+            red[4][t] += red[4][t + o];
         }
         __syncthreads();
     }
     if (t == 0) {
-        counts[4 * b + 0] = red[0][0];
-        counts[4 * b + 1] = red[1][0];
-        counts[4 * b + 2] = red[3][0];
-        counts[4 * b + 3] = red[1][0] == red[2][0];           // the visible decoder positions are exactly 0 .. L-1
+        counts[8 * b + 0] = red[0][0];
+        counts[8 * b + 1] = red[1][0];
+        counts[8 * b + 2] = red[3][0];
+        counts[8 * b + 3] = red[1][0] == red[2][0];           // the visible decoder positions are exactly 0 .. L-1
+        counts[8 * b + 4] = red[4][0];                        // decoder rows that carry a loss term
+        counts[8 * b + 5] = counts[8 * b + 6] = counts[8 * b + 7] = 0;
     }
 }
 
 __global__ __launch_bounds__(256) void rowmap_build_kernel(const float* __restrict__ mask, const float* __restrict__ loss_mask,
                                                            const int* __restrict__ off, const int* __restrict__ len,
-                                                           int* __restrict__ row_src, int* __restrict__ row_pos, int* __restrict__ inv, int S) {
+                                                           int* __restrict__ row_src, int* __restrict__ row_pos, int* __restrict__ inv, int S,
+                                                           const int* __restrict__ present) {
     const int b = blockIdx.x, t = threadIdx.x;
     const int per = (S + 255) / 256, s0 = min(S, t * per), s1 = min(S, s0 + per);
+    // present == NULL: visible / loss-only / dead. present != NULL (subset of an existing packing, mask unused): rows with a loss
+    // term, then other rows of that packing (present[row] >= 0), never the rest; row_pos then receives present[row].
     auto cls = [&](int s) {
         const long row = (long)b * S + s;
+        if (present) return row_has_loss(loss_mask, row) ? 0 : (present[row] >= 0 ? 1 : 2);
         return mask[row] != 0.f ? 0 : (row_has_loss(loss_mask, row) ? 1 : 2);
     };
     int c[3] = {0, 0, 0};
@@ -82,9 +90,9 @@ __global__ __launch_bounds__(256) void rowmap_build_kernel(const float* __restri
         const long row = (long)b * S + s;
         if (idx < L) {
             row_src[o + idx] = (int)row;
-            row_pos[o + idx] = s;
-            inv[row] = o + idx;
-        } else {
+            row_pos[o + idx] = present ? present[row] : s;
+            if (inv) inv[row] = o + idx;
+        } else if (inv) {
             inv[row] = -1;
         }
     }
@@ -96,6 +104,15 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(const uint4* __restr
         const long r = i / q;
         const int w = (int)(i - r * q);
         dst[i] = src[(long)row_src[r] * q + w];
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_rows16_kernel(const uint4* __restrict__ src, const int* __restrict__ row_dst, uint4* __restrict__ dst,
+                                                             long n, int q) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * q; i += (long)gridDim.x * 256) {
+        const long r = i / q;
+        const int w = (int)(i - r * q);
+        dst[(long)row_dst[r] * q + w] = src[i];
     }
 }
 
@@ -128,7 +145,28 @@ extern "C" int pb_rowmap_build(const float* mask, const float* loss_mask, const 
                                int32_t* inv, int32_t B, int32_t S, void* stream_) {
     PB_REQUIRE(mask && off && len && row_src && row_pos && inv, "pb_rowmap_build: NULL argument");
     if (B <= 0 || S <= 0) return 0;
-    hipLaunchKernelGGL(rowmap_build_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, mask, loss_mask, off, len, row_src, row_pos, inv, S);
+    hipLaunchKernelGGL(rowmap_build_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, mask, loss_mask, off, len, row_src, row_pos, inv, S,
+                       (const int*)nullptr);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_rowmap_build_sub(const float* loss_mask, const int32_t* present, const int32_t* off, const int32_t* len, int32_t* row_src,
+                                   int32_t* row_idx, int32_t B, int32_t S, void* stream_) {
+    PB_REQUIRE(loss_mask && present && off && len && row_src && row_idx, "pb_rowmap_build_sub: NULL argument");
+    if (B <= 0 || S <= 0) return 0;
+    hipLaunchKernelGGL(rowmap_build_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, (const float*)nullptr, loss_mask, off, len, row_src, row_idx,
+                       (int*)nullptr, S, present);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pb_scatter_rows16(const void* src, const int32_t* row_dst, void* dst, int64_t n_rows, int32_t row_bytes, void* stream_) {
+    PB_REQUIRE(row_bytes > 0 && row_bytes % 16 == 0, "pb_scatter_rows16: row_bytes=%d is not a multiple of 16", row_bytes);
+    if (n_rows <= 0) return 0;
+    const int q = row_bytes / 16;
+    const int grid = (int)min((long)2048, (long)((n_rows * q + 255) / 256));
+    hipLaunchKernelGGL(scatter_rows16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const uint4*)src, row_dst, (uint4*)dst, (long)n_rows, q);
     PB_LAUNCH_CHECK();
     return 0;
 }

@@ -29,10 +29,16 @@ _NO_FUSED_BIAS = bool(int(os.environ.get('PB_NO_FUSED_BIAS', '0')))     # develo
 LN_EPS = 1e-5
 
 
+# copies of the backward scratch buffers that the second stream's weight-gradient GEMMs read (gB, du, dq, dkv, dqkv): with 2 the main
+# stream can write the next sublayer's cotangent while the weight gradient of the previous one is still reading its own
+_RING = int(os.environ.get('PB_RING', '2'))
+_FWD_GEMM_FLAGS = int(os.environ.get('PB_FWD_GEMM_FLAGS', '32768'))      # PB_GEMM_TAIL_SPLIT for the forward projections (0: off)
 # dead-row compaction of the fused pre-train step (Engine._pack_batch): PB_PACK_ROWS=0 keeps every step dense
 _PACK_ROWS = int(os.environ.get('PB_PACK_ROWS', '1'))
 _PACK_TILE = 256                 # packed row counts are rounded up to whole GEMM tiles
 _PACK_MIN_GAIN = 0.97            # stay dense unless at least 3 % of the rows go
+_SUB_LAST = int(os.environ.get('PB_SUB_LAST', '1'))     # last decoder layer: query side and LM heads on the loss rows only (packed step)
+_SUB_MIN_GAIN = 0.75             # ... unless more than 3/4 of the decoder rows carry a loss term
 
 
 def plan_packed_rows(live, S, tile=_PACK_TILE):
@@ -41,9 +47,10 @@ def plan_packed_rows(live, S, tile=_PACK_TILE):
     length[b] - 1, length[b] >= live[b]: the Tp - sum(live) rows of slack are handed out as dead rows of the sequences that have
     some (first come, first served), so that no sequence grows beyond S."""
     live = np.asarray(live, dtype=np.int64)
+    cap = np.broadcast_to(np.asarray(S, dtype=np.int64), live.shape)     # S may also be one capacity per sequence
     total = int(live.sum())
-    Tp = min(-(-max(total, 1) // tile) * tile, len(live) * S)
-    cum = np.minimum(np.cumsum(S - live), Tp - total)
+    Tp = min(-(-max(total, 1) // tile) * tile, int(cap.sum()))
+    cum = np.minimum(np.cumsum(cap - live), Tp - total)
     length = live + np.diff(np.concatenate([[0], cum]))
     return Tp, np.concatenate([[0], np.cumsum(length)[:-1]]), length
 
@@ -96,6 +103,7 @@ class Engine:
         self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 96, 128))
         self._slabs = None
         self._pack_state = None
+        self._tables_ready = False          # forward_hidden's table work was already issued by _pack_batch for this step
         self.last_rows = self.last_pairs = None
         self._side, self._side_last, self._readers = None, None, {}
         self._kmax = {}
@@ -296,7 +304,8 @@ class Engine:
 
     # ------------------------------------------------------------------ building blocks
     def _linear(self, x, wname, bname, out, M, N, K, **kw):
-        ops.gemm(x, self.w[wname], out, M=M, N=N, K=K, dtype=self.code, bias=self.wf[bname] if bname else None, **kw)
+        # forward GEMMs run alone on their stream (nothing fills a partly filled last round of the persistent grid): allow the tail split
+        ops.gemm(x, self.w[wname], out, M=M, N=N, K=K, dtype=self.code, bias=self.wf[bname] if bname else None, dbg=_FWD_GEMM_FLAGS, **kw)
 
     def _attn_fwd(self, q, k, v, out, key_mask, causal, B, Sq, Sk, save, rows=None):
         """q,k,v,out: (tensor, elem offset, row stride). Unfused form: QK^T -> masked softmax -> PV. rows: packed-row descriptors."""
@@ -380,8 +389,10 @@ class Engine:
         r_enc, r_dec, r_cross = (pack.enc, pack.dec, pack.cross) if pack is not None else (None, None, None)
         ids_e, ids_d = (pack.src_e, pack.src_d) if pack is not None else (None, None)        # row numbers in the padded batch
         p = self.p_drop if train else 0.0
-        self.refresh_shadow()
-        self.build_ptab()
+        if not self._tables_ready:
+            self.refresh_shadow()
+            self.build_ptab()
+        self._tables_ready = False
         # per-batch-row key extents (1 + last visible key): the attention kernels skip the masked PAD tail tile-wise
         self._kmax = {}
         if self.use_flash and self.hd in (64, 96, 128) and pack is None:
@@ -439,6 +450,8 @@ class Engine:
                     self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', ws['dec'][l]['kvc'], Te, 2 * d, d)
                     kv_ready.append(torch.cuda.Event())
                     kv_ready[-1].record()
+        sub = pack.sub if pack is not None else None
+        sub_layer = None
         for l in range(self.ND):
             L, pf = ws['dec'][l], 'dec.%d.' % l
             self._linear(y, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
@@ -446,28 +459,39 @@ class Engine:
                            rows=r_dec)
             self._linear(L['ctx'], pf + 'wo', pf + 'bo', L['a1'], T, d, d)
             ops.add_ln_fwd(y, L['a1'], wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], L['y1'], L['m1'], L['r1'], LN_EPS, seed, self._site('dec', l, 0), p, row_ids=ids_d)
-            self._linear(L['y1'], pf + 'wq_c', pf + 'bq_c', L['qc'], T, d, d)
+            # the rest of the layer (cross-attention block, FFN) works on the query side only: in the last layer of a packed step that
+            # is the rows with a loss term (pack.sub), gathered out of y1
+            Lq, y1, Tq, ids_q, r_x = L, L['y1'], T, ids_d, r_cross
+            if sub is not None and l == self.ND - 1:
+                Tq, ids_q, r_x = sub.T, sub.src, sub.cross
+                Lq = {k: L[k][:Tq] for k in ('qc', 'ctxc', 'ac', 'yc', 'mc', 'rc', 'u', 'g', 'a2', 'y2', 'm2', 'r2')}
+                y1 = Lq['y1s'] = self._y1s(ws, L['y1'])[:Tq]
+                ops.gather_rows16(L['y1'], sub.idx, y1, Tq, 2 * d)
+                Lq['attnc'] = L['attnc']
+                sub_layer = Lq
+            self._linear(y1, pf + 'wq_c', pf + 'bq_c', Lq['qc'], Tq, d, d)
             if kv_ready is None:
                 self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', L['kvc'], Te, 2 * d, d)
             else:
                 torch.cuda.current_stream().wait_event(kv_ready[l])
-            self._attn_fwd((L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d), (L['ctxc'], 0, d), emask, False, B, S, S, L['attnc'],
-                           rows=r_cross)
-            self._linear(L['ctxc'], pf + 'wo_c', pf + 'bo_c', L['ac'], T, d, d)
-            ops.add_ln_fwd(L['y1'], L['ac'], wf[pf + 'lnc.w'], wf[pf + 'lnc.b'], L['yc'], L['mc'], L['rc'], LN_EPS, seed, self._site('dec', l, 1), p, row_ids=ids_d)
-            self._linear(L['yc'], pf + 'w1', pf + 'b1', L['g'], T, self.fd, d, gelu_aux_out=L['u'])
-            self._linear(L['g'], pf + 'w2', pf + 'b2', L['a2'], T, d, self.fd)
-            ops.add_ln_fwd(L['yc'], L['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], L['y2'], L['m2'], L['r2'], LN_EPS, seed, self._site('dec', l, 2), p, row_ids=ids_d)
-            y = L['y2']
+            self._attn_fwd((Lq['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d), (Lq['ctxc'], 0, d), emask, False, B, S, S, L['attnc'],
+                           rows=r_x)
+            self._linear(Lq['ctxc'], pf + 'wo_c', pf + 'bo_c', Lq['ac'], Tq, d, d)
+            ops.add_ln_fwd(y1, Lq['ac'], wf[pf + 'lnc.w'], wf[pf + 'lnc.b'], Lq['yc'], Lq['mc'], Lq['rc'], LN_EPS, seed, self._site('dec', l, 1), p, row_ids=ids_q)
+            self._linear(Lq['yc'], pf + 'w1', pf + 'b1', Lq['g'], Tq, self.fd, d, gelu_aux_out=Lq['u'])
+            self._linear(Lq['g'], pf + 'w2', pf + 'b2', Lq['a2'], Tq, d, self.fd)
+            ops.add_ln_fwd(Lq['yc'], Lq['a2'], wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], Lq['y2'], Lq['m2'], Lq['r2'], LN_EPS, seed, self._site('dec', l, 2), p, row_ids=ids_q)
+            y = Lq['y2']
         self._saved = dict(enc16=enc16, dec16=dec16, emask=emask, dmask=dmask, p=p, seed=seed, enc_out=enc_out, dec_out=y, B=B, S=S,
-                           alt=dec_embeds is not None, pack=pack)
+                           alt=dec_embeds is not None, pack=pack, sub_layer=sub_layer)
         return y, enc_out
 
     def heads_forward(self, dec_hidden):
         ws = self._cur_ws
         T = dec_hidden.shape[0]
-        ops.gemm(dec_hidden, self.w['head.w'], ws['logits'], M=T, N=ops.VOCAB, K=self.d, dtype=self.code, bias=self.wf['head.b'], c_f32=True)
-        return ws['logits']
+        logits = ws['logits'][:T]
+        ops.gemm(dec_hidden, self.w['head.w'], logits, M=T, N=ops.VOCAB, K=self.d, dtype=self.code, bias=self.wf['head.b'], c_f32=True)
+        return logits
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dy, x, gname, M, N, T, ldy=None, ldx=None, dy_off=0, x_off=0, g_off=0):
@@ -550,6 +574,26 @@ class Engine:
             self._side_last = None
         self._readers.clear()
 
+    def _y1s(self, ws, like):
+        base = ws.get('_base', ws)
+        if 'y1s' not in base:
+            base['y1s'] = torch.empty(base['T'], self.d, dtype=like.dtype, device=like.device)
+        return base['y1s']
+
+    def _ring(self, name):
+        """The next copy of backward scratch buffer `name` (round robin over _RING copies) when weight gradients run on the second
+        stream; the one buffer otherwise."""
+        ws = self._cur_ws
+        base = ws.get('_base', ws)
+        if _RING < 2 or not (_WGRAD_STREAM & 1) or not self._side:
+            return base[name]
+        ring = base.setdefault('_ring', {})
+        ent = ring.get(name)
+        if ent is None:
+            ent = ring[name] = [[base[name]] + [torch.empty_like(base[name]) for _ in range(_RING - 1)], 0]
+        ent[1] = (ent[1] + 1) % len(ent[0])
+        return ent[0][ent[1]]
+
     def _dgrad(self, dy, wname, out, T, N, K, accum, ldy=None, **kw):
         """out(T,N) (+)= dy(T,K) @ W(K,N)   (NN GEMM, W stored [K][N])."""
         self._before_write(out)
@@ -570,14 +614,15 @@ class Engine:
     def _ffn_ln_bwd(self, L, pf, ff, gy, y_in, seed, site, p, T, row_ids=None):
         """Backward of y2 = LN2(y_in + drop(fc2(gelu(fc1(y_in))))). gy: grad wrt y2. Returns grad wrt y_in in ws['gA']. T: rows."""
         ws, g, d = self._cur_ws, self.g, self.d
-        gA, gB = ws['gA'][:T], ws['gB'][:T]
+        gA, gB = ws['gA'][:T], self._ring('gB')[:T]
         da = gB if p > 0 else None
         self._before_write(gA, da)
         ops.add_ln_bwd(gy, y_in, L['a2'], self.wf[pf + 'ln2.w'], L['m2'], L['r2'], gA, da, g[pf + 'ln2.w'], g[pf + 'ln2.b'], g[pf + 'b2'],
                        self.partials, False, seed, site, p, row_ids=row_ids)
         gb = gB if p > 0 else gA
         self._wgrad(gb, L['g'], pf + 'w2', d, ff, T)
-        du = ws['du'][:T, :ff] if ws['du'].shape[1] == ff else ws['du'].view(-1)[:T * ff].view(T, ff)
+        du = self._ring('du')
+        du = du[:T, :ff] if du.shape[1] == ff else du.view(-1)[:T * ff].view(T, ff)
         # dU = (dG W2) * gelu'(U), and db1 = column sums of dU straight from the same epilogue registers
         if _NO_FUSED_BIAS:
             self._dgrad(gb, pf + 'w2', du, T, ff, d, False, gelu_grad_aux_in=L['u'], ldaux=ff)
@@ -609,7 +654,7 @@ class Engine:
         """Backward of y = LN(x_in + drop(out_proj(attn(q,k,v)))) up to dq/dk/dv. gy: grad wrt y; gout receives grad wrt x_in
         (residual path only; the projection paths are added by the caller)."""
         ws, g, d = self._cur_ws, self.g, self.d
-        gB, gC = ws['gB'][:T], ws['gC'][:T]                 # T: rows on the query side
+        gB, gC = self._ring('gB')[:T], ws['gC'][:T]         # T: rows on the query side
         wo, bo = names
         da = gB if p > 0 else None
         self._before_write(gout, da, dq[0], dk[0], dv[0])
@@ -632,11 +677,11 @@ class Engine:
         pack = sv.get('pack')
         r_enc, r_dec, r_cross = (pack.enc, pack.dec, pack.cross) if pack is not None else (None, None, None)
         ids_e, ids_d = (pack.src_e, pack.src_d) if pack is not None else (None, None)
+        sub = pack.sub if pack is not None else None
         p, seed, wf, g = sv['p'], sv['seed'], self.wf, self.g
         emask, dmask = sv['emask'], sv['dmask']
         gy, galt = (t[:Td] for t in ws['gy'])
         genc = ws['genc'][:Te]
-        dq_d, dkv_e, dqkv_d, dqkv_e = ws['dq'][:Td], ws['dkv'][:Te], ws['dqkv'][:Td], ws['dqkv'][:Te]
         onehot_route = self.code == PB_BF16 and Te % 64 == 0 and Td % 64 == 0
         base = ws.get('_base', ws)
         if not _NO_DEFER:
@@ -653,22 +698,37 @@ class Engine:
             for l in reversed(range(self.ND)):
                 L, pf = ws['dec'][l], 'dec.%d.' % l
                 x_in = ws['dec'][l - 1]['y2'] if l > 0 else ws['x_dec']
-                gA = self._ffn_ln_bwd(L, pf, self.fd, cur, L['yc'], seed, self._site('dec', l, 2), p, Td, row_ids=ids_d)
+                # query side of the layer: all decoder rows, or (last layer of a packed step) the rows with a loss term
+                Lq, y1, Tq, ids_q, r_x = L, L['y1'], Td, ids_d, r_cross
+                if sub is not None and l == self.ND - 1:
+                    Lq, Tq, ids_q, r_x = sv['sub_layer'], sub.T, sub.src, sub.cross
+                    y1 = Lq['y1s']
+                    cur = cur[:Tq]
+                gA = self._ffn_ln_bwd(Lq, pf, self.fd, cur, Lq['yc'], seed, self._site('dec', l, 2), p, Tq, row_ids=ids_q)
                 # cross-attention block: y_c = LN(y1 + drop(out_c(attn(q_c(y1), kv_c(enc)))))
-                g1 = gy if cur is not gy else galt
-                fused = self._attn_block_bwd(L, pf, (pf + 'wo_c', pf + 'bo_c'), gA, L['y1'], (L['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d),
-                                             (dq_d, 0, d), (dkv_e, 0, 2 * d), (dkv_e, d, 2 * d), L['ctxc'], L['ac'], L['attnc'],
-                                             L['mc'], L['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1, seed, self._site('dec', l, 1), p, B, S, S, emask, False,
-                                             dbias=(g[pf + 'bq_c'], g[pf + 'bkv_c'][:d], g[pf + 'bkv_c'][d:]), T=Td, rows=r_cross, row_ids=ids_d)
+                dq_d, dkv_e, dqkv_d = self._ring('dq')[:Tq], self._ring('dkv')[:Te], self._ring('dqkv')[:Td]
+                g1 = gy if cur.data_ptr() != gy.data_ptr() else galt
+                g1q = g1[:Tq]
+                fused = self._attn_block_bwd(Lq, pf, (pf + 'wo_c', pf + 'bo_c'), gA, y1, (Lq['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d),
+                                             (dq_d, 0, d), (dkv_e, 0, 2 * d), (dkv_e, d, 2 * d), Lq['ctxc'], Lq['ac'], L['attnc'],
+                                             Lq['mc'], Lq['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1q, seed, self._site('dec', l, 1), p, B, S, S, emask, False,
+                                             dbias=(g[pf + 'bq_c'], g[pf + 'bkv_c'][:d], g[pf + 'bkv_c'][d:]), T=Tq, rows=r_x, row_ids=ids_q)
                 if not fused:
-                    ops.colsum(dq_d, g[pf + 'bq_c'], self.partials, Td, d)
+                    ops.colsum(dq_d, g[pf + 'bq_c'], self.partials, Tq, d)
                     ops.colsum(dkv_e, g[pf + 'bkv_c'], self.partials, Te, 2 * d)
-                self._wgrad(dq_d, L['y1'], pf + 'wq_c', d, d, Td)
-                self._dgrad(dq_d, pf + 'wq_c', g1, Td, d, d, True)
+                self._wgrad(dq_d, y1, pf + 'wq_c', d, d, Tq)
+                self._dgrad(dq_d, pf + 'wq_c', g1q, Tq, d, d, True)
                 self._wgrad(dkv_e, sv['enc_out'], pf + 'wkv_c', 2 * d, d, Te)
                 self._dgrad(dkv_e, pf + 'wkv_c', genc, Te, d, 2 * d, l != self.ND - 1)
+                if Tq != Td:
+                    # the gradient wrt y1 lives on the loss rows: spread it over the decoder rows (zeros elsewhere) in the buffer `cur` has left
+                    full = gy if g1.data_ptr() != gy.data_ptr() else galt
+                    self._before_write(full)
+                    ops.fill_f32(full.view(torch.float32) if full.dtype != torch.float32 else full, 0.0)
+                    ops.scatter_rows16(g1q, sub.idx, full, Tq, d * full.element_size())
+                    g1 = full
                 # self-attention block
-                g2 = gy if g1 is not gy else galt
+                g2 = gy if g1.data_ptr() != gy.data_ptr() else galt
                 bq = g[pf + 'bqkv']
                 fused = self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), g1, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
                                              (dqkv_d, 0, 3 * d), (dqkv_d, d, 3 * d), (dqkv_d, 2 * d, 3 * d), L['ctx'], L['a1'], L['attn'],
@@ -709,6 +769,7 @@ class Engine:
             L, pf = ws['enc'][l], 'enc.%d.' % l
             x_in = ws['enc'][l - 1]['y2'] if l > 0 else ws['x_enc']
             gA = self._ffn_ln_bwd(L, pf, self.fe, cur, L['y1'], seed, self._site('enc', l, 1), p, Te, row_ids=ids_e)
+            dqkv_e = self._ring('dqkv')[:Te]
             g2 = gy if cur is not gy else galt
             bq = g[pf + 'bqkv']
             fused = self._attn_block_bwd(L, pf, (pf + 'wo', pf + 'bo'), gA, x_in, (L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d),
@@ -821,12 +882,15 @@ class Engine:
         T = B * S
         seed = self._next_seed()
         self._select_grads(False)
+        self._tables_ready = False
         pack = self._pack_batch(enc16, dec16, tgt16, loss_mask, emask, dmask) if (_PACK_ROWS and argmax_out is None) else None
         if pack is not None:
             enc16, dec16, tgt, lm = pack.enc16, pack.dec16, pack.tgt16, pack.loss_mask
+            if pack.sub is not None:                                   # the last decoder layer hands over the rows with a loss term only
+                tgt, lm = pack.sub.tgt16, pack.sub.loss_mask
         else:
             tgt, lm = tgt16.reshape(T, 8), loss_mask.reshape(T, 8)
-        self.last_rows = (pack.Te, pack.Td, T) if pack is not None else (T, T, T)
+        self.last_rows = (pack.Te, pack.Td, T, pack.sub.T if pack.sub is not None else pack.Td) if pack is not None else (T, T, T, T)
         # (query, key) pairs the three attention forms really cover (bench.py prices the step with them)
         self.last_pairs = pack.pairs if pack is not None else (B * S * S, B * S * S // 2, B * S * S)
         dec_h, _ = self.forward_hidden(enc16, dec16, emask, dmask, train, seed, pack=pack)
@@ -838,10 +902,11 @@ class Engine:
         if count_hook is not None:
             count_hook(counts)
         ops.loss_coef(counts, self.loss_w if head_w is None else head_w, coef, w_scale)
-        ops.ce_fwd_bwd(logits, tgt, lm, sums, self.partials, coef, ws['dlogits'] if train else None, argmax_out)
+        dlogits = ws['dlogits'][:logits.shape[0]] if train else None
+        ops.ce_fwd_bwd(logits, tgt, lm, sums, self.partials, coef, dlogits, argmax_out)
         if train:
             self.zero_accumulated_grads()
-            gy = self.heads_backward(ws['dlogits'], dec_h)
+            gy = self.heads_backward(dlogits, dec_h)
             self.backward(gy)
         return sums
 
@@ -859,14 +924,20 @@ class Engine:
         if st is None or st['key'] != (B, S):
             dev = self.device
             i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
-            st = self._pack_state = dict(key=(B, S), counts=i32(B, 4), counts_h=torch.empty(B, 4, dtype=torch.int32).pin_memory(),
-                                         desc=i32(6, B), desc_h=torch.empty(6, B, dtype=torch.int32).pin_memory(),
-                                         src_e=i32(T), pos_e=i32(T), inv_e=i32(T), src_d=i32(T), pos_d=i32(T), inv_d=i32(T),
+            st = self._pack_state = dict(key=(B, S), counts=i32(B, 8), counts_h=torch.empty(B, 8, dtype=torch.int32).pin_memory(),
+                                         desc=i32(8, B), desc_h=torch.empty(8, B, dtype=torch.int32).pin_memory(),
+                                         src_e=i32(T), pos_e=i32(T), inv_e=i32(T), src_d=i32(T), pos_d=i32(T), inv_d=i32(T), src_s=i32(T), idx_s=i32(T),
+                                         tgt16_s=torch.empty(T, 8, dtype=torch.int16, device=dev), lm_s=torch.empty(T, 8, dtype=torch.float32, device=dev),
                                          enc16=torch.empty(T, 8, dtype=torch.int16, device=dev), dec16=torch.empty(T, 8, dtype=torch.int16, device=dev),
                                          tgt16=torch.empty(T, 8, dtype=torch.int16, device=dev), lm=torch.empty(T, 8, dtype=torch.float32, device=dev))
         lm3 = loss_mask.reshape(B, S, 8)
         ops.rowmap_count(emask, dmask, lm3, st['counts'])
         st['counts_h'].copy_(st['counts'], non_blocking=True)
+        # work of the step that does not depend on the row counts goes in front of the wait: the GPU projects the Octuple table while the
+        # host plans the packing
+        self.refresh_shadow()
+        self.build_ptab()
+        self._tables_ready = True
         torch.cuda.current_stream().synchronize()
         c = st['counts_h'].numpy().astype(np.int64)
         if not c[:, 3].all():
@@ -874,7 +945,13 @@ class Engine:
         (Te, off_e, len_e), (Td, off_d, len_d) = plan_packed_rows(c[:, 0], S), plan_packed_rows(c[:, 2], S)
         if Te + Td > _PACK_MIN_GAIN * 2 * T:
             return None
-        st['desc_h'].copy_(torch.from_numpy(np.stack([off_e, len_e, c[:, 0], off_d, len_d, c[:, 1]]).astype(np.int32)))
+        # the last decoder layer's query side (cross-attention, FFN) and the LM heads are only needed on rows that carry a loss term:
+        # every other layer's output is a later layer's key / value input, the last layer's is read by the loss alone
+        Ts, off_s, len_s = plan_packed_rows(c[:, 4], len_d)
+        sub = _SUB_LAST and self.ND > 0 and Ts <= _SUB_MIN_GAIN * Td
+        if not sub:
+            off_s, len_s = off_d, len_d
+        st['desc_h'].copy_(torch.from_numpy(np.stack([off_e, len_e, c[:, 0], off_d, len_d, c[:, 1], off_s, len_s]).astype(np.int32)))
         desc = st['desc']
         desc.copy_(st['desc_h'], non_blocking=True)
         ops.rowmap_build(emask, None, desc[0], desc[1], st['src_e'], st['pos_e'], st['inv_e'])
@@ -893,6 +970,17 @@ class Engine:
         pk.enc = ops.PackedRows(desc[0], desc[1], desc[0], desc[1], desc[2], me, me, 'enc')
         pk.dec = ops.PackedRows(desc[3], desc[4], desc[3], desc[4], desc[5], md, md, 'dec')
         pk.cross = ops.PackedRows(desc[3], desc[4], desc[0], desc[1], desc[2], md, me, 'cross')
+        pk.sub = None
+        if sub:
+            sb = pk.sub = _RowPack()
+            sb.T, sb.src, sb.idx = Ts, st['src_s'], st['idx_s']
+            ops.rowmap_build_sub(lm3, st['inv_d'], desc[6], desc[7], sb.src, sb.idx)
+            sb.tgt16, sb.loss_mask = st['tgt16_s'][:Ts], st['lm_s'][:Ts]
+            ops.gather_rows16(pk.tgt16, sb.idx, sb.tgt16, Ts, 16)
+            ops.gather_rows16(pk.loss_mask, sb.idx, sb.loss_mask, Ts, 32)
+            ms = int(len_s.max())
+            sb.cross = ops.PackedRows(desc[6], desc[7], desc[0], desc[1], desc[2], ms, me, 'cross')
+            pk.pairs = pk.pairs[:2] + (pk.pairs[2] * (self.ND - 1) // self.ND + int((len_s * vis_e).sum()) // self.ND,)     # layer mean
         return pk
 
     def optimizer_step(self, lr=2e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=3.0, gscale=1.0):

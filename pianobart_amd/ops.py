@@ -271,6 +271,15 @@ def rowmap_build(mask, loss_mask, off, length, row_src, row_pos, inv):
     LIB.call('pb_rowmap_build', _p(mask), _p(loss_mask), _p(off), _p(length), _p(row_src), _p(row_pos), _p(inv), B, S, _stream())
 
 
+def rowmap_build_sub(loss_mask, present, off, length, row_src, row_idx):
+    B, S = loss_mask.shape[:2]
+    LIB.call('pb_rowmap_build_sub', _p(loss_mask), _p(present), _p(off), _p(length), _p(row_src), _p(row_idx), B, S, _stream())
+
+
+def scatter_rows16(src, row_dst, dst, n_rows, row_bytes):
+    LIB.call('pb_scatter_rows16', _p(src), _p(row_dst), _p(dst), n_rows, row_bytes, _stream())
+
+
 def gather_rows16(src, row_src, dst, n_rows, row_bytes):
     LIB.call('pb_gather_rows16', _p(src), _p(row_src), _p(dst), n_rows, row_bytes, _stream())
 

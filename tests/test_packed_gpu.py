@@ -45,13 +45,13 @@ def test_rowmap_kernels_match_numpy(ops):
     dmask[3, 5] = 0                                                      # batch 3: not a prefix mask
     lm = np.zeros((B, S, 8), np.float32)
     lm[rng.random((B, S)) > 0.8, 3] = 1.0
-    counts = torch.empty(B, 4, dtype=torch.int32, device='cuda')
+    counts = torch.empty(B, 8, dtype=torch.int32, device='cuda')
     te, td, tl = (torch.tensor(x, device='cuda') for x in (emask, dmask, lm))
     ops.rowmap_count(te, td, tl, counts)
     c = counts.cpu().numpy()
     assert (c[:, 0] == (emask != 0).sum(1)).all() and (c[:, 1] == (dmask != 0).sum(1)).all()
     assert (c[:, 2] == ((dmask != 0) | lm.any(-1)).sum(1)).all()
-    assert c[:, 3].tolist() == [1, 1, 1, 0, 1]
+    assert c[:, 3].tolist() == [1, 1, 1, 0, 1] and (c[:, 4] == lm.any(-1).sum(1)).all()
     for mask, t_mask, loss, t_loss in ((emask, te, None, None), (dmask, td, lm, tl)):
         live = (mask != 0).sum(1) if loss is None else ((mask != 0) | loss.any(-1)).sum(1)
         length = np.minimum(live + rng.integers(0, 7, size=B), S)       # a few dead fillers per sequence
@@ -74,6 +74,29 @@ def test_rowmap_kernels_match_numpy(ops):
         want = torch.ones(S, 64, device='cuda', dtype=torch.float64)
         want.index_add_(0, (row_src % S).long(), x.double())
         assert float((out.double() - want).abs().max()) < 1e-5
+    # the loss rows of the decoder packing (+ a few other rows of it): what the last decoder layer's query side runs on
+    inv_np = inv.cpu().numpy().reshape(B, S)
+    nloss = lm.any(-1).sum(1)
+    len_s = np.minimum(nloss + 3, length)
+    off_s = np.concatenate([[0], np.cumsum(len_s)[:-1]])
+    Ts = int(len_s.sum())
+    src_s, idx_s = (torch.full((Ts,), -7, dtype=torch.int32, device='cuda') for _ in range(2))
+    ops.rowmap_build_sub(tl, inv, _i32(off_s), _i32(len_s), src_s, idx_s)
+    got_src, got_idx = src_s.cpu().numpy(), idx_s.cpu().numpy()
+    for b in range(B):
+        los = [s for s in range(S) if lm[b, s].any()]
+        oth = [s for s in range(S) if not lm[b, s].any() and inv_np[b, s] >= 0]
+        order = (los + oth)[:len_s[b]]
+        assert got_src[off_s[b]:off_s[b] + len_s[b]].tolist() == [b * S + s for s in order]
+        assert got_idx[off_s[b]:off_s[b] + len_s[b]].tolist() == [inv_np[b, s] for s in order]
+    # scatter is the inverse of gather
+    full = torch.randn(Tp, 8, device='cuda')
+    part = torch.empty(Ts, 8, device='cuda')
+    ops.gather_rows16(full, idx_s, part, Ts, 32)
+    back = torch.zeros_like(full)
+    ops.scatter_rows16(part, idx_s, back, Ts, 32)
+    keep = torch.zeros(Tp, dtype=torch.bool, device='cuda'); keep[idx_s.long()] = True
+    assert torch.equal(back[keep], full[keep]) and not back[~keep].any()
 
 
 @pytest.mark.parametrize('hd', [64, 128])
@@ -193,8 +216,9 @@ def _step(eng, args, pack, monkeypatch, seed=77, train=True):
     return sums, eng.G32.clone(), eng.last_rows
 
 
-@pytest.mark.parametrize('heads,tail_loss,hole,dropout', [(4, False, False, 0.0), (4, True, False, 0.1), (2, True, True, 0.1)])
-def test_packed_step_equals_dense_step(ops, monkeypatch, heads, tail_loss, hole, dropout):
+@pytest.mark.parametrize('heads,tail_loss,hole,dropout,sparse', [(4, False, False, 0.0, False), (4, True, False, 0.1, True), (2, True, True, 0.1, True),
+                                                                 (4, False, False, 0.0, True)])
+def test_packed_step_equals_dense_step(ops, monkeypatch, heads, tail_loss, hole, dropout, sparse):
     """The fused pre-train step with the dead rows dropped gives the dense step's loss sums and gradients, dropout included (a
     packed row draws the dropout bits of its row in the padded batch). The comparison is to bf16 rounding: the
     GEMMs pick their tile shape by the row count, so a kept row's f32 sums are not accumulated in the same order in both runs
@@ -222,14 +246,16 @@ def test_packed_step_equals_dense_step(ops, monkeypatch, heads, tail_loss, hole,
             emask[b, 3] = 0                                             # an invisible encoder row inside the sequence
         dmask[b, :Ld[b]] = 1; dmask[b, Ld[b]:] = 0
         loss_mask[b, Ld[b]:] = 0
-        loss_mask[b, :Ld[b], 0] = 1
+        loss_mask[b, :Ld[b], 0] = torch.tensor((rng.random(Ld[b]) < 0.15).astype(np.float32), device='cuda') if sparse else 1
+        loss_mask[b, 1, 0] = 1
         if tail_loss and Ld[b] + 5 < S:
             loss_mask[b, Ld[b] + 2, :] = 1                              # loss terms on rows that are not visible as keys
             loss_mask[b, S - 1, 2] = 1
     args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
     s0, g0, r0 = _step(eng, args, False, monkeypatch)
     s1, g1, r1 = _step(eng, args, True, monkeypatch)
-    assert r0 == (B * S, B * S, B * S) and r1[0] < B * S and r1[1] < B * S and r1[0] % 256 == 0 and r1[1] % 256 == 0, (r0, r1)
+    assert r0 == (B * S,) * 4 and r1[0] < B * S and r1[1] < B * S and r1[0] % 256 == 0 and r1[1] % 256 == 0, (r0, r1)
+    assert (r1[3] < r1[1] and r1[3] % 256 == 0) if sparse else r1[3] == r1[1], r1     # sparse loss rows: the last decoder layer's query side shrinks
     assert torch.equal(s0[8:16], s1[8:16])                              # the mask counts
     rt, gt = 1e-3, (4e-2 if hole else 2e-2)      # a hole in the encoder mask moves the later keys up by one: other tiles, other roundings
     assert torch.allclose(s0[:8], s1[:8], rtol=rt), (s0 - s1).abs().max()
@@ -249,7 +275,7 @@ def test_packed_step_equals_dense_step(ops, monkeypatch, heads, tail_loss, hole,
     # a decoder mask with a hole cannot be packed: the step stays dense
     dm2 = dmask.clone(); dm2[2, 7] = 0
     r2 = _step(eng, args[:5] + (dm2,), True, monkeypatch)[2]
-    assert r2 == (B * S, B * S, B * S)
+    assert r2 == (B * S,) * 4
 
 
 @pytest.mark.parametrize('M,N,K,lay', [(26624, 768, 3072, 'NT'), (26880, 768, 2304, 'NN'), (26624, 768, 768, 'NT'), (32768, 768, 3072, 'NN'),
