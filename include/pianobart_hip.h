@@ -229,6 +229,11 @@ int pb_adamw_step(float* p, const float* g, float* m, float* v, void* shadow /*b
 int pb_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int pb_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 int pb_fill_f32(float* dst, float value, int64_t n, void* stream);
+/* Transposed copies of the weight matrices inside the flat bf16 shadow: table (device, n_matrices x 4 int32) = {element offset, R, C,
+ * index of the matrix's first 64x64 tile}; matrix e (R x C row-major at src + offset) is written C x R at dst + offset; R, C and
+ * offset multiples of 8; n_tiles = sum of ceil(R/64) ceil(C/64). The backward's dX = dY W then reads W^T as a K-contiguous operand
+ * (the NT form of the GEMM kernel is 7-20 % faster than the NN form). */
+int pb_transpose_batch_bf16(const void* src, void* dst, const int32_t* table, int32_t n_matrices, int32_t n_tiles, void* stream);
 /* dst[i] = bf16(sum_r f32(src[r*n + i])), r < rows; n % 8 == 0: the f32 accumulation of the bf16 gradient chunks a rank owns in the
  * data-parallel exchange (pianobart_amd/parallel.py; replaces the logits gather + gradient reduce of nn.DataParallel, pretrain.py:63-65) */
 int pb_sum_rows_bf16(const void* src, void* dst, int32_t rows, int64_t n, void* stream);

@@ -113,6 +113,55 @@ __global__ __launch_bounds__(OPT_THREADS) void sum_rows_bf16_kernel(const bf16_t
 
 int opt_grid(long n4) { return (int)std::max(1L, std::min((long)OPT_BLOCKS, (n4 + OPT_THREADS - 1) / OPT_THREADS)); }
 
+// Batched bf16 transpose inside one flat buffer: table entry e = {element offset, R, C, first tile}; matrix e (R x C, row-major at
+// src + offset) is written C x R at dst + offset. One workgroup per 64 x 64 tile, through LDS. Dimensions multiples of 8.
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int4* __restrict__ table, int n) {
+    __shared__ short tile[64][66];
+    __shared__ int4 ent;
+    const int t = threadIdx.x, b = blockIdx.x;
+    if (t == 0) {
+        int e = 0;
+        while (e + 1 < n && table[e + 1].w <= b) ++e;
+        ent = table[e];
+    }
+    __syncthreads();
+    const long off = ent.x;
+    const int R = ent.y, C = ent.z, lt = b - ent.w, tc = (C + 63) / 64;
+    const int r0 = (lt / tc) * 64, c0 = (lt % tc) * 64;
+    const short* S = reinterpret_cast<const short*>(src) + off;
+    short* D = reinterpret_cast<short*>(dst) + off;
+    {
+        const int r = t >> 2, c = (t & 3) * 16;
+        if (r0 + r < R) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (c0 + c + 8 * h < C) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(S + (long)(r0 + r) * C + c0 + c + 8 * h);
+                    const short* e = reinterpret_cast<const short*>(&v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) tile[r][c + 8 * h + j] = e[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int orow = t >> 2, oc = (t & 3) * 16;              // output row = source column
+        if (c0 + orow < C) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (r0 + oc + 8 * h < R) {
+                    uint4 v;
+                    short* e = reinterpret_cast<short*>(&v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = tile[oc + 8 * h + j][orow];
+                    *reinterpret_cast<uint4*>(D + (long)(c0 + orow) * R + r0 + oc + 8 * h) = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ---- fine-tune regulariser `loss += weight * torch.norm(param, p=2)` per parameter tensor (finetune.py:241-243)
@@ -199,6 +248,14 @@ extern "C" int pb_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void*
 extern "C" int pb_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream_) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(opt_grid(n >> 2)), dim3(OPT_THREADS), 0, (hipStream_t)stream_, (const bf16_t*)src, dst, (long)n);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pb_transpose_batch_bf16(const void* src, void* dst, const int32_t* table, int32_t n_matrices, int32_t n_tiles, void* stream_) {
+    PB_REQUIRE(src && dst && table && src != dst, "pb_transpose_batch_bf16: NULL or aliased argument");
+    if (n_matrices <= 0 || n_tiles <= 0) return 0;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)src, (bf16_t*)dst,
+                       reinterpret_cast<const int4*>(table), n_matrices);
     PB_LAUNCH_CHECK();
     return 0;
 }

@@ -32,6 +32,7 @@ LN_EPS = 1e-5
 # copies of the backward scratch buffers that the second stream's weight-gradient GEMMs read (gB, du, dq, dkv, dqkv): with 2 the main
 # stream can write the next sublayer's cotangent while the weight gradient of the previous one is still reading its own
 _RING = int(os.environ.get('PB_RING', '2'))
+_DGRAD_NT = int(os.environ.get('PB_DGRAD_NT', '1'))    # backward dX = dY W from transposed weight copies (NT GEMM) instead of the NN form
 _FWD_GEMM_FLAGS = int(os.environ.get('PB_FWD_GEMM_FLAGS', '32768'))      # PB_GEMM_TAIL_SPLIT for the forward projections (0: off)
 # dead-row compaction of the fused pre-train step (Engine._pack_batch): PB_PACK_ROWS=0 keeps every step dense
 _PACK_ROWS = int(os.environ.get('PB_PACK_ROWS', '1'))
@@ -216,6 +217,23 @@ class Engine:
             self.wf[name] = P32[s.off:s.off + s.numel].view(s.shape)
             self.g[name] = self.G32[s.off:s.off + s.numel].view(s.shape)
             self.w[name] = (self.Pbf[s.off:s.off + s.numel].view(s.shape) if self.code == PB_BF16 else self.wf[name])
+        # transposed bf16 copies of the layer matrices for the backward's dX = dY W (read K-contiguous, the faster form of the GEMM
+        # kernel): same offsets in a second flat buffer, rewritten by one batched launch whenever the shadow changed
+        self.wT, self._wT_table, self._wT_tiles = {}, None, 0
+        self._shadow_gen, self._wT_gen, self._wT_done = 0, -1, None
+        if self.code == PB_BF16 and _DGRAD_NT:
+            self.PbfT = torch.empty_like(self.Pbf)
+            rows, tiles = [], 0
+            for name, s in self.slots.items():
+                if len(s.shape) == 2 and s.off < self.n_matrix and name not in ('emb', 'lin.w') and s.shape[0] % 8 == 0 and s.shape[1] % 8 == 0 \
+                        and s.off % 8 == 0:
+                    R, C = s.shape
+                    rows.append([s.off, R, C, tiles])
+                    tiles += -(-R // 64) * -(-C // 64)
+                    self.wT[name] = self.PbfT[s.off:s.off + s.numel].view(C, R)
+            if rows:
+                self._wT_table = torch.tensor(rows, dtype=torch.int32, device=device)
+                self._wT_tiles = tiles
         self.Gcur = self.G32
         self.opt_m = self.opt_v = None
         self._versions = None
@@ -238,6 +256,35 @@ class Engine:
         if force or ver != self._versions:
             ops.cast_f32_to_bf16(self.P32, self.Pbf)
             self._versions = ver
+            self._shadow_gen += 1
+
+    def _refresh_wT(self, on_side=False):
+        """Rewrite the transposed weight copies from the current shadow. on_side: on the second stream (after the optimizer, so that
+        it runs beside the next forward); the backward waits for it in _ensure_wT."""
+        if self._wT_table is None:
+            return
+        gen = self._shadow_gen
+        if on_side and self._side:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                ops.transpose_batch_bf16(self.Pbf, self.PbfT, self._wT_table, self._wT_tiles)
+                self._wT_done = torch.cuda.Event()
+                self._wT_done.record()
+        else:
+            ops.transpose_batch_bf16(self.Pbf, self.PbfT, self._wT_table, self._wT_tiles)
+            self._wT_done = None
+        self._wT_gen = gen
+
+    def _ensure_wT(self):
+        if self._wT_table is None:
+            return
+        if self._wT_gen != self._shadow_gen:
+            self._refresh_wT()
+        if self._wT_done is not None:
+            torch.cuda.current_stream().wait_event(self._wT_done)
+            self._wT_done = None
 
     # ------------------------------------------------------------------ workspace
     def _ws(self, B, S):
@@ -597,6 +644,10 @@ class Engine:
     def _dgrad(self, dy, wname, out, T, N, K, accum, ldy=None, **kw):
         """out(T,N) (+)= dy(T,K) @ W(K,N)   (NN GEMM, W stored [K][N])."""
         self._before_write(out)
+        wT = self.wT.get(wname)
+        if wT is not None:                                        # W^T (N,K): both operands K-contiguous
+            ops.gemm(dy, wT, out, M=T, N=N, K=K, dtype=self.code, lda=ldy or K, ldb=K, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
+            return
         ops.gemm(dy, self.w[wname], out, M=T, N=N, K=K, dtype=self.code, b_kc=False, lda=ldy or K, ldb=N, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
 
     def _cs_ws(self, M, N):
@@ -671,6 +722,7 @@ class Engine:
         sv = self._saved
         if sv is None:
             raise PBError('backward called without a saved forward')
+        self._ensure_wT()
         ws = self._cur_ws
         B, S, T, d = sv['B'], sv['S'], ws['T'], self.d
         Te, Td = ws['Te'], ws['Td']                         # rows on the encoder / decoder side (T each unless the step is packed)
@@ -823,6 +875,7 @@ class Engine:
     def heads_backward(self, dlogits, dec_hidden):
         """dlogits (T,1280) storage dtype -> head grads + grad wrt decoder hidden (returned in ws['gy'][0])."""
         ws, g, T, d = self._cur_ws, self.g, dlogits.shape[0], self.d
+        self._ensure_wT()
         ops.colsum(dlogits, g['head.b'], self.partials, T, ops.VOCAB)
         self._wgrad(dlogits, dec_hidden, 'head.w', ops.VOCAB, d, T)
         gy = ws['gy'][0][:T]
@@ -995,6 +1048,8 @@ class Engine:
         ops.adamw_step(self.P32, self.G32, self.opt_m, self.opt_v, self.Pbf, clip, lr, betas[0], betas[1], eps, weight_decay, self.step_count)
         if self.code == PB_BF16:
             self._versions = sum(p._version for p in self.params)
+            self._shadow_gen += 1
+            self._refresh_wT(on_side=True)
 
     # ------------------------------------------------------------------ generate (model.py:28-66)
     def generate(self, enc_ids, emask, sample_row, use_cache=True):

@@ -207,6 +207,10 @@ def sum_rows_bf16(src, dst, rows):
     LIB.call('pb_sum_rows_bf16', _p(src), _p(dst), rows, dst.numel(), _stream())
 
 
+def transpose_batch_bf16(src, dst, table, n_tiles):
+    LIB.call('pb_transpose_batch_bf16', _p(src), _p(dst), _p(table), table.shape[0], n_tiles, _stream())
+
+
 def fill_f32(dst, value):
     LIB.call('pb_fill_f32', _p(dst), value, dst.numel(), _stream())
 

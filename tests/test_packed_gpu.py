@@ -307,3 +307,25 @@ def test_gemm_tail_split_matches_whole_tiles(ops, M, N, K, lay, epi):
     for o in outs:
         assert float((o - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
     assert float((outs[0] - outs[1]).abs().max()) <= (1e-5 if c32 else 1.6e-2) * max(1.0, float(ref.abs().max()))
+
+
+def test_transpose_batch_bf16(ops):
+    """The transposed weight copies the backward's dX = dY W reads (Engine._refresh_wT): several matrices of one flat buffer in one launch."""
+    g = torch.Generator(device='cuda').manual_seed(4)
+    shapes = [(2304, 768), (768, 768), (8, 16), (3072, 768), (72, 200), (1280, 768)]
+    offs, cur = [], 16
+    for R, C in shapes:
+        offs.append(cur)
+        cur += R * C + 24
+    src = torch.randn(cur, device='cuda', generator=g).to(torch.bfloat16)
+    dst = torch.full_like(src, 7.0)
+    table, tiles = [], 0
+    for (R, C), o in zip(shapes, offs):
+        table.append([o, R, C, tiles])
+        tiles += -(-R // 64) * -(-C // 64)
+    ops.transpose_batch_bf16(src, dst, torch.tensor(table, dtype=torch.int32, device='cuda'), tiles)
+    covered = torch.zeros(cur, dtype=torch.bool, device='cuda')
+    for (R, C), o in zip(shapes, offs):
+        assert torch.equal(dst[o:o + R * C].view(C, R), src[o:o + R * C].view(R, C).t())
+        covered[o:o + R * C] = True
+    assert bool((dst[~covered] == 7.0).all())
