@@ -337,6 +337,15 @@ int pb_decode_step(const pb_decode_plan* plan, int32_t i, void* stream);
  * not be read, nor written by anything else, before the flush. */
 int pb_defer_begin(float* arena, int64_t arena_floats, void* table, int32_t table_entries);
 int pb_defer_flush(void* stream);
+
+/* ---- events for ordering two streams of one GPU (Engine's second stream) ---------------------------
+ * mode bit 0: hipEventDisableSystemFence, bit 1: hipEventReleaseToDevice (both on top of hipEventDisableTiming): the producer and
+ * the consumer are kernels on the same device, so the system-scope write-back / invalidate of a default event is not needed.
+ * The handle is an opaque hipEvent_t. */
+int pb_event_create(void** ev, int32_t mode);
+int pb_event_destroy(void* ev);
+int pb_event_record(void* ev, void* stream);
+int pb_stream_wait_event(void* stream, void* ev);
 int32_t pb_defer_desc_bytes(void);
 
 #ifdef __cplusplus

@@ -32,6 +32,10 @@ LN_EPS = 1e-5
 # copies of the backward scratch buffers that the second stream's weight-gradient GEMMs read (gB, du, dq, dkv, dqkv): with 2 the main
 # stream can write the next sublayer's cotangent while the weight gradient of the previous one is still reading its own
 _RING = int(os.environ.get('PB_RING', '2'))
+# events that order the two streams: 1 = HIP events without the system-scope fence (hipEventDisableSystemFence: 59.5 -> 59.1 ms/step),
+# 2 = hipEventReleaseToDevice (no gain; the two together are rejected), 0 = plain hipEventDisableTiming events,
+# -1 = torch.cuda.Event (same as 0, created per use)
+_EVENT_MODE = int(os.environ.get('PB_EVENT_MODE', '1'))
 _DGRAD_NT = int(os.environ.get('PB_DGRAD_NT', '1'))    # backward dX = dY W from transposed weight copies (NT GEMM) instead of the NN form
 _FWD_GEMM_FLAGS = int(os.environ.get('PB_FWD_GEMM_FLAGS', '32768'))      # PB_GEMM_TAIL_SPLIT for the forward projections (0: off)
 # dead-row compaction of the fused pre-train step (Engine._pack_batch): PB_PACK_ROWS=0 keeps every step dense
@@ -54,6 +58,37 @@ def plan_packed_rows(live, S, tile=_PACK_TILE):
     cum = np.minimum(np.cumsum(cap - live), Tp - total)
     length = live + np.diff(np.concatenate([[0], cum]))
     return Tp, np.concatenate([[0], np.cumsum(length)[:-1]]), length
+
+
+class _HipEvent:
+    """One HIP event of the engine's pool (pb_event_*): record() on the current stream, wait_on(stream)."""
+    __slots__ = ('h',)
+
+    def __init__(self, mode):
+        import ctypes
+        self.h = ctypes.c_void_p()
+        LIB.call('pb_event_create', ctypes.byref(self.h), mode)
+
+    def record(self):
+        import ctypes
+        LIB.call('pb_event_record', self.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return self
+
+    def wait_on(self, stream):
+        import ctypes
+        LIB.call('pb_stream_wait_event', ctypes.c_void_p(stream.cuda_stream), self.h)
+
+
+class _TorchEvent:
+    __slots__ = ('e',)
+
+    def record(self):
+        self.e = torch.cuda.Event()
+        self.e.record()
+        return self
+
+    def wait_on(self, stream):
+        stream.wait_event(self.e)
 
 
 class _RowPack:
@@ -104,6 +139,7 @@ class Engine:
         self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 96, 128))
         self._slabs = None
         self._pack_state = None
+        self._ev_pool = None
         self._tables_ready = False          # forward_hidden's table work was already issued by _pack_batch for this step
         self.last_rows = self.last_pairs = None
         self._side, self._side_last, self._readers = None, None, {}
@@ -265,13 +301,10 @@ class Engine:
             return
         gen = self._shadow_gen
         if on_side and self._side:
-            ev = torch.cuda.Event()
-            ev.record()
-            self._side.wait_event(ev)
+            self._event().wait_on(self._side)
             with torch.cuda.stream(self._side):
                 ops.transpose_batch_bf16(self.Pbf, self.PbfT, self._wT_table, self._wT_tiles)
-                self._wT_done = torch.cuda.Event()
-                self._wT_done.record()
+                self._wT_done = self._event()
         else:
             ops.transpose_batch_bf16(self.Pbf, self.PbfT, self._wT_table, self._wT_tiles)
             self._wT_done = None
@@ -283,7 +316,7 @@ class Engine:
         if self._wT_gen != self._shadow_gen:
             self._refresh_wT()
         if self._wT_done is not None:
-            torch.cuda.current_stream().wait_event(self._wT_done)
+            self._wT_done.wait_on(torch.cuda.current_stream())
             self._wT_done = None
 
     # ------------------------------------------------------------------ workspace
@@ -487,16 +520,13 @@ class Engine:
         if (_WGRAD_STREAM & 2) and self._side_stream() is not None:
             # every decoder layer's cross-attention K/V projection depends on the encoder output only: issue them all on the second
             # stream now, to fill the CUs the decoder's N = d GEMMs leave idle
-            ev = torch.cuda.Event()
-            ev.record()
-            self._side.wait_event(ev)
+            self._event().wait_on(self._side)
             kv_ready = []
             with torch.cuda.stream(self._side):
                 for l in range(self.ND):
                     pf = 'dec.%d.' % l
                     self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', ws['dec'][l]['kvc'], Te, 2 * d, d)
-                    kv_ready.append(torch.cuda.Event())
-                    kv_ready[-1].record()
+                    kv_ready.append(self._event())
         sub = pack.sub if pack is not None else None
         sub_layer = None
         for l in range(self.ND):
@@ -520,7 +550,7 @@ class Engine:
             if kv_ready is None:
                 self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', L['kvc'], Te, 2 * d, d)
             else:
-                torch.cuda.current_stream().wait_event(kv_ready[l])
+                kv_ready[l].wait_on(torch.cuda.current_stream())
             self._attn_fwd((Lq['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d), (Lq['ctxc'], 0, d), emask, False, B, S, S, L['attnc'],
                            rows=r_x)
             self._linear(Lq['ctxc'], pf + 'wo_c', pf + 'bo_c', Lq['ac'], Tq, d, d)
@@ -561,13 +591,10 @@ class Engine:
             return launch(self._bwd_dbg())
         # the weight gradient is off the critical path of backward: run it on a second stream, where its workgroups fill the CUs the
         # main stream's kernels leave idle (the half-empty last round of the N = d GEMMs). Writers of `dy` wait in _before_write.
-        ev = torch.cuda.Event()
-        ev.record()
-        self._side.wait_event(ev)
+        self._event().wait_on(self._side)
         with torch.cuda.stream(self._side):
             launch(self._bwd_dbg())
-            done = torch.cuda.Event()
-            done.record()
+            done = self._event()
         self._readers[dy.untyped_storage().data_ptr()] = done
         self._side_last = done
 
@@ -613,13 +640,23 @@ class Engine:
                 if t is not None:
                     ev = self._readers.pop(t.untyped_storage().data_ptr(), None)
                     if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
+                        ev.wait_on(torch.cuda.current_stream())
 
     def _join_side(self):
         if self._side_last is not None:
-            torch.cuda.current_stream().wait_event(self._side_last)
+            self._side_last.wait_on(torch.cuda.current_stream())
             self._side_last = None
         self._readers.clear()
+
+    def _event(self):
+        """A recorded event on the current stream (from a round-robin pool far longer than the events a step has in flight)."""
+        if _EVENT_MODE < 0:
+            return _TorchEvent().record()
+        pool = self._ev_pool
+        if pool is None:
+            pool = self._ev_pool = [[_HipEvent(_EVENT_MODE) for _ in range(2048)], 0]
+        pool[1] = (pool[1] + 1) % len(pool[0])
+        return pool[0][pool[1]].record()
 
     def _y1s(self, ws, like):
         base = ws.get('_base', ws)
@@ -694,9 +731,7 @@ class Engine:
                 return self.grad_hook(a.off, b.off + b.numel)
             # the range was produced by both streams: let the second stream catch up with this one and issue the exchange from it
             # (the collective's own stream orders itself after the stream that is current at the call), so this one never waits
-            ev = torch.cuda.Event()
-            ev.record()
-            self._side.wait_event(ev)
+            self._event().wait_on(self._side)
             with torch.cuda.stream(self._side):
                 self.grad_hook(a.off, b.off + b.numel)
 

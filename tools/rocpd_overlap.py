@@ -36,3 +36,15 @@ main = max(streams, key=lambda s: len([r for r in R if r[2] == s[0]]))[0]
 ev = sorted((r[0], r[1]) for r in R if r[2] == main)
 gaps = [s1 - e0 for (s0, e0), (s1, e1) in zip(ev, ev[1:]) if s1 - e0 > 5000]
 print('  main-stream gaps > 5 us: %d, total %.2f ms' % (len(gaps), sum(gaps) / 1e6))
+if '--gaps' in sys.argv:
+    # where the main stream stalls: its largest gaps with the kernels on either side, and a histogram by (previous, next) kernel
+    import re
+    short = lambda n: re.sub(r'^_ZN\d+_GLOBAL__N_1\d+', '', n)[:40]
+    mr = sorted((r for r in R if r[2] == main), key=lambda r: r[0])
+    gl = sorted(((b[0] - a[1], short(a[4]), short(b[4])) for a, b in zip(mr, mr[1:]) if b[0] - a[1] > 3000), reverse=True)
+    hist = {}
+    for g, pa, nb in gl:
+        h = hist.setdefault((pa, nb), [0, 0]); h[0] += 1; h[1] += g
+    print('  gaps > 3 us on the main stream: %d, total %.2f ms; by (previous kernel -> next kernel):' % (len(gl), sum(g for g, _, _ in gl) / 1e6))
+    for (pa, nb), (n, tot) in sorted(hist.items(), key=lambda kv: -kv[1][1])[:25]:
+        print('    %4d x  avg %6.1f us  total %7.1f us   %s -> %s' % (n, tot / n / 1e3, tot / 1e3, pa, nb))
