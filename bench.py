@@ -295,6 +295,7 @@ def main():
     enc16, dec16, tgt16 = ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target)
     loss_mask = loss_mask.contiguous()
     reducer = GradReducer(eng, world) if (world > 1 or args.force_reducer) else None
+    eng.pipeline_updates = not os.environ.get('PB_NO_PIPELINE_UPDATES')     # the parameter update runs beside the next step's forward (Engine.optimizer_step)
 
     def step():
         sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=True,

@@ -114,6 +114,9 @@ class Engine:
         if precision not in ('bf16', 'fp32'):
             raise PBError('precision must be "bf16" or "fp32"')
         self.pb, self.mlm = pianobart, mask_lm
+        for mod in (pianobart, mask_lm):
+            if mod is not None and hasattr(mod, 'register_state_dict_pre_hook'):         # a checkpoint must not read parameters a pipelined update is still writing
+                mod.register_state_dict_pre_hook(lambda *a, **k: self.finish_updates())
         self.precision = precision
         self.code = PB_BF16 if precision == 'bf16' else PB_F32
         self.xdt = torch.bfloat16 if precision == 'bf16' else torch.float32
@@ -140,6 +143,8 @@ class Engine:
         self._slabs = None
         self._pack_state = None
         self._ev_pool = None
+        self.pipeline_updates = False       # optimizer_step may leave the parameter update running on the second stream (see there)
+        self._upd, self._upd_waited, self._upd_groups = None, 0, None
         self._tables_ready = False          # forward_hidden's table work was already issued by _pack_batch for this step
         self.last_rows = self.last_pairs = None
         self._side, self._side_last, self._readers = None, None, {}
@@ -290,6 +295,7 @@ class Engine:
             return
         ver = sum(p._version for p in self.params)
         if force or ver != self._versions:
+            self._await_updates(2)
             ops.cast_f32_to_bf16(self.P32, self.Pbf)
             self._versions = ver
             self._shadow_gen += 1
@@ -469,6 +475,7 @@ class Engine:
         r_enc, r_dec, r_cross = (pack.enc, pack.dec, pack.cross) if pack is not None else (None, None, None)
         ids_e, ids_d = (pack.src_e, pack.src_d) if pack is not None else (None, None)        # row numbers in the padded batch
         p = self.p_drop if train else 0.0
+        self._await_updates(0)
         if not self._tables_ready:
             self.refresh_shadow()
             self.build_ptab()
@@ -490,6 +497,8 @@ class Engine:
         T = Te
         for l in range(self.NE if not reuse_encoder else 0):
             L, pf = ws['enc'][l], 'enc.%d.' % l
+            if l == 2:
+                self._await_updates(1)
             self._linear(x, pf + 'wqkv', pf + 'bqkv', L['qkv'], T, 3 * d, d)
             self._attn_fwd((L['qkv'], 0, 3 * d), (L['qkv'], d, 3 * d), (L['qkv'], 2 * d, 3 * d), (L['ctx'], 0, d), emask, False, B, S, S, L['attn'],
                            rows=r_enc)
@@ -502,6 +511,7 @@ class Engine:
         enc_out = x if not reuse_encoder else (ws['enc'][-1]['y2'] if self.NE else x)
         if dec16 is None and dec_embeds is None:
             return None, enc_out
+        self._await_updates(2)
         y = ws['x_dec']
         T = Td
         if dec_embeds is None:
@@ -1023,6 +1033,7 @@ class Engine:
         st['counts_h'].copy_(st['counts'], non_blocking=True)
         # work of the step that does not depend on the row counts goes in front of the wait: the GPU projects the Octuple table while the
         # host plans the packing
+        self._await_updates(0)
         self.refresh_shadow()
         self.build_ptab()
         self._tables_ready = True
@@ -1080,11 +1091,57 @@ class Engine:
         sq, clip = self.scal[40:41], self.scal[41:42]
         ops.grad_sqnorm(self.G32, self.partials, sq)
         ops.clip_coef(sq, max_norm, gscale, clip)
+        if self.pipeline_updates and self.code == PB_BF16 and self._side_stream() is not None:
+            # The update itself streams 30 bytes per parameter (1.3 ms at cfg 2) and only the NEXT forward needs its result, layer by
+            # layer: run it on the second stream in the order the forward reads the parameters, in three groups with an event each
+            # (_await_updates), followed by the transposed copies the backward reads.
+            self._event().wait_on(self._side)
+            with torch.cuda.stream(self._side):
+                evs = []
+                for ranges in self._update_groups():
+                    for lo, hi in ranges:
+                        ops.adamw_step(self.P32[lo:hi], self.G32[lo:hi], self.opt_m[lo:hi], self.opt_v[lo:hi], self.Pbf[lo:hi], clip, lr, betas[0], betas[1],
+                                       eps, weight_decay, self.step_count)
+                    evs.append(self._event())
+                self._versions = sum(p._version for p in self.params)
+                self._shadow_gen += 1
+                if self._wT_table is not None:
+                    ops.transpose_batch_bf16(self.Pbf, self.PbfT, self._wT_table, self._wT_tiles)
+                    self._wT_done = self._event()
+                    self._wT_gen = self._shadow_gen
+            self._upd, self._upd_waited = evs, 0
+            return
         ops.adamw_step(self.P32, self.G32, self.opt_m, self.opt_v, self.Pbf, clip, lr, betas[0], betas[1], eps, weight_decay, self.step_count)
         if self.code == PB_BF16:
             self._versions = sum(p._version for p in self.params)
             self._shadow_gen += 1
             self._refresh_wT(on_side=True)
+
+    def _update_groups(self):
+        """Flat-buffer ranges of the three update groups: {vectors and tables, Octuple embeddings, the first two encoder layers},
+        {the other encoder layers}, {decoder layers, LM heads}."""
+        if self._upd_groups is None:
+            first = lambda names: next((self.slots[n].off for n in names if n in self.slots), self.n_matrix)
+            a2 = first(['dec.0.wqkv', 'head.w'])
+            a1 = min(first(['enc.2.wqkv']), a2)
+            self._upd_groups = [[(0, a1), (self.n_matrix, self.n_total)], [(a1, a2)], [(a2, self.n_matrix)]]
+            self._upd_groups = [[(lo, hi) for lo, hi in g if hi > lo] for g in self._upd_groups]
+        return self._upd_groups
+
+    def _await_updates(self, group=2):
+        """The current stream waits until the pipelined optimizer step has written update groups 0 .. group."""
+        if self._upd is None:
+            return
+        cur = torch.cuda.current_stream()
+        while self._upd_waited <= group:
+            self._upd[self._upd_waited].wait_on(cur)
+            self._upd_waited += 1
+        if self._upd_waited >= len(self._upd):
+            self._upd = None
+
+    def finish_updates(self):
+        """Call before reading parameters from outside the engine (checkpoints) when pipeline_updates is on."""
+        self._await_updates(2)
 
     # ------------------------------------------------------------------ generate (model.py:28-66)
     def generate(self, enc_ids, emask, sample_row, use_cache=True):
@@ -1093,6 +1150,7 @@ class Engine:
         (model.py:42-45); here the encoder runs once, the cross-attention K/V of every decoder layer are projected once,
         and each step feeds ONE decoder token through the layers against a self-attention K/V cache. Position-i logits
         only depend on decoder inputs <= i (causal), so the tokens are identical (tests/test_model_gpu.py)."""
+        self._await_updates(2)
         if not use_cache:
             return self._generate_nocache(enc_ids, emask, sample_row)
         if self.hd not in (32, 64, 96, 128):                 # pb_attn_decode's row-chunk layouts; other head sizes use the training kernels

@@ -154,6 +154,7 @@ class Pretrainer:
         print("Use GPU", self.device)
         self.engine = self.model._get_engine()
         self.engine.bind(self.device)
+        self.engine.pipeline_updates = True                     # the AdamW pass of step i runs beside the forward of step i + 1 (Engine.optimizer_step)
         self.train_data = train_dataloader
         self.valid_data = valid_dataloader
         self.lr = lr
@@ -189,6 +190,7 @@ class Pretrainer:
     def save_checkpoint(self, epoch, best_acc, valid_acc, valid_loss, train_loss, is_best, filename):
         """pretrain.py:96-110: same dict keys; 'state_dict' holds PianoBart only; optimizer = flat HF-AdamW state."""
         eng = self.engine
+        eng.finish_updates()                                    # a pipelined parameter update may still be writing the moments
         opt = {'step': eng.step_count, 'lr': self.lr, 'betas': (0.9, 0.999), 'eps': 1e-6, 'weight_decay': 0.01,
                'exp_avg': None if eng.opt_m is None else eng.opt_m.detach().cpu(),
                'exp_avg_sq': None if eng.opt_v is None else eng.opt_v.detach().cpu()}

@@ -329,3 +329,41 @@ def test_transpose_batch_bf16(ops):
         assert torch.equal(dst[o:o + R * C].view(C, R), src[o:o + R * C].view(R, C).t())
         covered[o:o + R * C] = True
     assert bool((dst[~covered] == 7.0).all())
+
+
+def test_pipelined_parameter_update_takes_the_same_steps(ops):
+    """Engine.pipeline_updates: the AdamW pass and the transposed weight copies run on the second stream beside the next forward,
+    which waits group by group. Three training steps must leave bit-identical parameters, moments and loss sums; a state_dict
+    taken right after a step must hold the updated values."""
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab, randomize_params, synth_octuple_batch
+    e2w, w2e = load_vocab()
+    B, S, d = 4, 256, 256
+    cfg = BartConfig(max_position_embeddings=S, d_model=d, encoder_layers=3, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+                     encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.1)
+    batch = [t.cuda() for t in synth_octuple_batch(B, S, seed=21)]
+    enc, dec, loss_mask, emask, dmask, target = batch
+    args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+    res = []
+    for pipelined in (False, True):
+        m = PianoBartLM(PianoBart(cfg, e2w, w2e, precision='bf16'))
+        randomize_params(m, 11)
+        m = m.train().cuda()
+        eng = m._get_engine()
+        eng.bind(torch.device('cuda', 0))
+        eng.pipeline_updates = pipelined
+        eng._seed = 5
+        sums = []
+        for _ in range(3):
+            sums.append(eng.loss_and_grads(*args, train=True).clone())
+            eng.optimizer_step(lr=1e-3)
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}       # right behind the step: the hook must wait for the update
+        torch.cuda.synchronize()
+        assert not pipelined or eng._side_stream() is None or eng._upd is None
+        res.append((torch.stack(sums), eng.P32.clone(), eng.opt_m.clone(), eng.opt_v.clone(), eng.Pbf.clone(), sd))
+    a, b = res
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    for k in a[5]:
+        assert torch.equal(a[5][k], b[5][k]), k
+    assert float((a[0][0] - a[0][2]).abs().max()) > 0                         # the steps did move the parameters
