@@ -306,7 +306,7 @@ class Engine:
         if self._wT_table is None:
             return
         gen = self._shadow_gen
-        if on_side and self._side:
+        if on_side and self._side and _WGRAD_STREAM:
             self._event().wait_on(self._side)
             with torch.cuda.stream(self._side):
                 ops.transpose_batch_bf16(self.Pbf, self.PbfT, self._wT_table, self._wT_tiles)
@@ -1091,7 +1091,7 @@ class Engine:
         sq, clip = self.scal[40:41], self.scal[41:42]
         ops.grad_sqnorm(self.G32, self.partials, sq)
         ops.clip_coef(sq, max_norm, gscale, clip)
-        if self.pipeline_updates and self.code == PB_BF16 and self._side_stream() is not None:
+        if self.pipeline_updates and self.code == PB_BF16 and _WGRAD_STREAM and self._side_stream() is not None:
             # The update itself streams 30 bytes per parameter (1.3 ms at cfg 2) and only the NEXT forward needs its result, layer by
             # layer: run it on the second stream in the order the forward reads the parameters, in three groups with an event each
             # (_await_updates), followed by the transposed copies the backward reads.

@@ -1,15 +1,15 @@
 """Two-stream view of a rocprofv3 rocpd database of `bench.py`: per-stream busy time, their union and the main stream's gaps over the
-shortest full step (steps are delimited by the AdamW kernel). Usage: python tools/rocpd_overlap.py <results.db>"""
+shortest full step (steps are delimited by the gradient-norm kernel that precedes the parameter update). Usage: python tools/rocpd_overlap.py <results.db>"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if 'kernel_dispatch' in t][0]; ks = [t for t in tabs if 'kernel_symbol' in t][0]
 rows = list(db.execute(f"select d.start, d.end, d.stream_id, d.queue_id, s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-ad = [r for r in rows if 'adamw' in r[4]]
-spans = [(ad[i + 1][1] - ad[i][1], i) for i in range(len(ad) - 1)]
-print('steps (ms between AdamW ends):', ' '.join('%.2f' % (d / 1e6) for d, _ in spans), '-> the shortest one below (the host, slowed by the profiler, starves some)')
+ad = [r for r in rows if 'sqnorm_kernel' in r[4]]          # one per step, right behind the backward pass (the update itself may be chunked / on the second stream)
+spans = [(ad[i + 1][0] - ad[i][0], i) for i in range(len(ad) - 1)]
+print('steps (ms between gradient-norm kernels):', ' '.join('%.2f' % (d / 1e6) for d, _ in spans), '-> the shortest one below (the host, slowed by the profiler, starves some)')
 _, i = min(spans)
-t0, t1 = ad[i][1], ad[i + 1][1]
+t0, t1 = ad[i][0], ad[i + 1][0]
 R = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 
 
@@ -27,7 +27,7 @@ def busy(rs):
 
 
 streams = sorted({(r[2], r[3]) for r in R})
-print('step: %.2f ms between AdamW ends; %d kernels' % ((t1 - t0) / 1e6, len(R)))
+print('step: %.2f ms between gradient-norm kernels; %d kernels' % ((t1 - t0) / 1e6, len(R)))
 for st, q in streams:
     rs = [r for r in R if r[2] == st]
     print('  stream %d (hw queue %d): %5d kernels, busy %.2f ms, sum of durations %.2f ms' % (st, q, len(rs), busy(rs), sum(r[1] - r[0] for r in rs) / 1e6))
