@@ -603,10 +603,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #undef G3_MMA
 }
 
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, long n, float* __restrict__ out, int accum) {
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 s = *reinterpret_cast<const f32x4*>(slabs + 4 * i);
+        if (accum) s += *reinterpret_cast<const f32x4*>(out + 4 * i);
         for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * n + 4 * i);
         *reinterpret_cast<f32x4*>(out + 4 * i) = s;
     }
@@ -695,8 +696,8 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096 | 8192 | 16384 | 32768)))) {
-        pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue");
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096 | 8192 | 16384 | 32768)))) {
+        pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue other than accumulate");
         return -2;
     }
     Gemm2Args a;
@@ -710,7 +711,9 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if (nsplit > 1 && nb1 * a.nb2 != 1) { pb_set_error("pb_gemm: split-K with batches is not supported"); return -2; }
     a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2; a.sC1 = d->sC1; a.sC2 = d->sC2;
     a.sCz = (long)d->M * d->N;
-    a.alpha = d->alpha; a.flags = d->flags; a.cs_ws = nullptr;
+    a.alpha = d->alpha; a.cs_ws = nullptr;
+    a.flags = nsplit > 1 ? (d->flags & ~PB_GEMM_ACCUM) : d->flags;          // split-K: the slabs are overwritten, the accumulation into C happens in the reduce
+
     // Tile / kernel choice, from same-process A/B runs of every cfg-2 shape (tools/gemm_ab.py, T = 32768 tokens):
     // the 256x256 ping-pong kernel wherever the output is at least 512 wide -- NT fc1 910 vs 750 TF (128x128), fc2 1110 vs 1050,
     // NN dfc1 937 vs 899, TN w1 930 vs 820 (one-barrier 256x256) -- and 128x128 tiles (2 workgroups per CU) below that and for
@@ -804,7 +807,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         if (d->ldc != d->N) { pb_set_error("pb_gemm: split-K needs a dense C (ldc == N)"); return -2; }
         const long n = (long)d->M * d->N;
         const int g = (int)std::max(1L, std::min(2048L, (n / 4 + 255) / 256));
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(g), dim3(256), 0, stream, (const float*)d->slabs, nsplit, n, (float*)d->C);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(g), dim3(256), 0, stream, (const float*)d->slabs, nsplit, n, (float*)d->C, (int)((d->flags & PB_GEMM_ACCUM) != 0));
         if (hipGetLastError() != hipSuccess) { pb_set_error("pb_reduce_slabs launch failed"); return -1; }
     }
     return (d->colsum_out && !cs_fused) ? 2 : 0;

@@ -36,6 +36,7 @@ _RING = int(os.environ.get('PB_RING', '2'))
 # 2 = hipEventReleaseToDevice (no gain; the two together are rejected), 0 = plain hipEventDisableTiming events,
 # -1 = torch.cuda.Event (same as 0, created per use)
 _EVENT_MODE = int(os.environ.get('PB_EVENT_MODE', '1'))
+_SIDE_TAIL = int(os.environ.get('PB_SIDE_TAIL', '1'))  # end of backward: decoder half of dP, the deferred reductions and one f32 GEMM on the second stream
 _DGRAD_NT = int(os.environ.get('PB_DGRAD_NT', '1'))    # backward dX = dY W from transposed weight copies (NT GEMM) instead of the NN form
 _FWD_GEMM_FLAGS = int(os.environ.get('PB_FWD_GEMM_FLAGS', '32768'))      # PB_GEMM_TAIL_SPLIT for the forward projections (0: off)
 # dead-row compaction of the fused pre-train step (Engine._pack_batch): PB_PACK_ROWS=0 keeps every step dense
@@ -143,6 +144,7 @@ class Engine:
         self._slabs = None
         self._pack_state = None
         self._ev_pool = None
+        self._slabs_oh = [None, None]
         self.pipeline_updates = False       # optimizer_step may leave the parameter update running on the second stream (see there)
         self._upd, self._upd_waited, self._upd_groups = None, 0, None
         self._tables_ready = False          # forward_hidden's table work was already issued by _pack_batch for this step
@@ -780,6 +782,7 @@ class Engine:
         gy, galt = (t[:Td] for t in ws['gy'])
         genc = ws['genc'][:Te]
         onehot_route = self.code == PB_BF16 and Te % 64 == 0 and Td % 64 == 0
+        dec_tab_done = None                                  # event: the decoder tokens' half of dP has been written
         base = ws.get('_base', ws)
         if not _NO_DEFER:
             # ~160 bias / LayerNorm-parameter reductions per pass: keep their partial rows and sum them in one launch at the end
@@ -856,6 +859,10 @@ class Engine:
                     ops.pos_grad_packed(ws['dz'][Te:Te + Td], pack.inv_d, g['dec.pos'][2:2 + S], B, S)
                 elif onehot_route:
                     ops.batch_sum(ws['dz'][T:], g['dec.pos'][2:2 + S], B, S * d)
+                if onehot_route:
+                    # the decoder tokens' half of dP = Onehot^T dz is ready now: on the second stream, beside the encoder's backward
+                    ops.onehot_build(sv['dec16'], ws['onehot'][Te:Te + Td], padded=True)
+                    dec_tab_done = self._onehot_gemm(ws['onehot'][Te:Te + Td], ws['dz'][Te:Te + Td], Td, False, side=bool(_SIDE_TAIL))
             cur = genc
             if gy_enc_extra is not None:
                 cur = genc.add_(gy_enc_extra)
@@ -879,6 +886,14 @@ class Engine:
             self._dgrad(dqkv_e, pf + 'wqkv', g2, Te, d, 3 * d, True)
             cur = g2
             self._ready(pf + 'wqkv', pf + 'w2')
+        # the layers have left their last bias / LayerNorm-parameter partial sums: the one launch that reduces them all runs on the second
+        # stream, beside the embedding gradients
+        side_tail = _SIDE_TAIL and not _NO_DEFER and (_WGRAD_STREAM & 1) and self._side_stream() is not None and self.grad_hook is None
+        if side_tail:
+            self._event().wait_on(self._side)
+            with torch.cuda.stream(self._side):
+                ops.defer_flush()
+                self._side_last = self._event()
         ops.embed_ln_bwd(cur, sv['enc16'], self.ptab, wf['lin.b'], wf['enc.pos'], wf['enc.lne.w'], ws['me'], ws['re'], self.dptab,
                          g['enc.pos'], g['lin.b'], g['enc.lne.w'], g['enc.lne.b'], self.partials, S, seed, self._site('enc_emb'), p,
                          dz_out=ws['dz'][:Te] if onehot_route else None, padded=True, row_ids=pack.src_e if pack is not None else None)
@@ -889,28 +904,48 @@ class Engine:
             else:
                 ops.batch_sum(ws['dz'][:T], g['enc.pos'][2:2 + S], B, S * d)
             ops.onehot_build(sv['enc16'], ws['onehot'][:Te], padded=True)
-            dec_tab = gy_dec is not None and not sv.get('alt')          # a caller-supplied decoder embedding has no Octuple rows to scatter into
-            K2 = Te + Td if dec_tab else Te
-            if dec_tab:
-                ops.onehot_build(sv['dec16'], ws['onehot'][Te:Te + Td], padded=True)
-            need = 16 * ops.TAB_TOTAL * d
-            self._join_side()
-            if self._slabs is None or self._slabs.numel() < need:
-                self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
-            ops.gemm(ws['onehot'], ws['dz'], self.dptab, M=ops.TAB_TOTAL, N=d, K=K2, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.TAB_TOTAL, ldb=d, dbg=self._bwd_dbg(),
-                     ldc=d, c_f32=True, splitk=16, slabs=self._slabs, tile256=True)
+            # the encoder tokens' half, added to the decoder's (a caller-supplied decoder embedding has no Octuple rows to scatter into)
+            if dec_tab_done is not None:
+                dec_tab_done.wait_on(torch.cuda.current_stream())
+            self._onehot_gemm(ws['onehot'][:Te], ws['dz'][:Te], Te, dec_tab_done is not None, side=False)
         # projected-table gradient -> embedding tables and the shared merge Linear (exact f32)
         E, W, R = self.wf['emb'], self.wf['lin.w'], ops.TAB_ROWS
+        lin_w = lambda: ops.gemm(self.dptab, E, g['lin.w'], M=d, N=256, K=R, dtype=PB_F32, a_kc=False, b_kc=False, lda=d, ldb=256, ldc=2048, alpha=16.0,
+                                 c_f32=True, nb1=8, sA=(R * d, 0), sB=(R * 256, 0), sC=(256, 0))
+        if side_tail:                                           # two small f32 GEMMs that both read dP: one per stream
+            self._event().wait_on(self._side)
+            with torch.cuda.stream(self._side):
+                lin_w()
+                self._side_last = self._event()
         ops.gemm(self.dptab, W, g['emb'], M=R, N=256, K=d, dtype=PB_F32, b_kc=False, lda=d, ldb=2048, ldc=256, alpha=16.0, c_f32=True,
                  nb1=8, sA=(R * d, 0), sB=(256, 0), sC=(R * 256, 0))
-        ops.gemm(self.dptab, E, g['lin.w'], M=d, N=256, K=R, dtype=PB_F32, a_kc=False, b_kc=False, lda=d, ldb=256, ldc=2048, alpha=16.0,
-                 c_f32=True, nb1=8, sA=(R * d, 0), sB=(R * 256, 0), sC=(256, 0))
+        if not side_tail:
+            lin_w()
         self._ready('emb', 'lin.w')
-        if not _NO_DEFER:
+        if not _NO_DEFER and not side_tail:
             ops.defer_flush()
         self._join_side()
         if self.grad_hook is not None and self.Gcur is self.G32:
             self.grad_hook(self.n_matrix, self.n_total)          # vectors / position tables (accumulated region)
+
+    def _onehot_gemm(self, onehot, dz, K, accum, side):
+        """dP (+)= Onehot^T dz over K token rows: one split-K MFMA GEMM (no atomics). side: on the second stream; returns its event."""
+        d = self.d
+        which = 1 if side else 0
+        need = 16 * ops.TAB_TOTAL * d
+        if self._slabs_oh[which] is None:
+            self._slabs_oh[which] = torch.empty(need, dtype=torch.float32, device=self.device)
+        launch = lambda: ops.gemm(onehot, dz, self.dptab, M=ops.TAB_TOTAL, N=d, K=K, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.TAB_TOTAL, ldb=d,
+                                  dbg=self._bwd_dbg(), ldc=d, c_f32=True, accum=accum, splitk=16, slabs=self._slabs_oh[which], tile256=True)
+        if side and (_WGRAD_STREAM & 1) and self._side_stream() is not None:
+            self._event().wait_on(self._side)
+            with torch.cuda.stream(self._side):
+                launch()
+                done = self._event()
+            self._side_last = done
+            return done
+        launch()
+        return self._event()
 
     def zero_accumulated_grads(self):
         """Vector/table gradients are accumulated by the kernels (+=): zero them (and dP) before a backward."""

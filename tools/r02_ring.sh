@@ -1,8 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_packed_gpu.py -x -q -m gpu -k "pipelined or step" 2>&1 | tail -4
-for r in 1 "" 1 ""; do
-  PB_NO_PIPELINE_UPDATES=$r timeout 600 python bench.py --no-cpu-baseline --no-probe --steps 40 --warmup 10 2>/dev/null | python -c "
+for r in 0 1 0 1 0 1; do
+  PB_SIDE_TAIL=$r timeout 600 python bench.py --no-cpu-baseline --no-probe --steps 40 --warmup 10 2>/dev/null | python -c "
 import json,sys
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('PB_NO_PIPELINE_UPDATES=$r', round(j['ms_per_step'],2), round(j['ms_per_step_median_hip_events'],2), j['train_loss'])"
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('PB_SIDE_TAIL=$r', round(j['ms_per_step'],2), round(j['ms_per_step_median_hip_events'],2), j['train_loss'])"
 done

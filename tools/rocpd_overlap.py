@@ -48,3 +48,15 @@ if '--gaps' in sys.argv:
     print('  gaps > 3 us on the main stream: %d, total %.2f ms; by (previous kernel -> next kernel):' % (len(gl), sum(g for g, _, _ in gl) / 1e6))
     for (pa, nb), (n, tot) in sorted(hist.items(), key=lambda kv: -kv[1][1])[:25]:
         print('    %4d x  avg %6.1f us  total %7.1f us   %s -> %s' % (n, tot / n / 1e3, tot / 1e3, pa, nb))
+if '--tail' in sys.argv:
+    # the end of the backward pass: every kernel of the last 2.5 ms before the gradient-norm kernel, both streams
+    import re
+    short = lambda n: re.sub(r'^_ZN\d+_GLOBAL__N_1\d+', '', n)[:46]
+    print('  last 2.5 ms of the step (us relative to the gradient-norm kernel; stream, start, end, kernel):')
+    for r in R:
+        if r[1] > t1 - 2500000:
+            print('    s%d %9.1f %9.1f  %s' % (r[2], (r[0] - t1) / 1e3, (r[1] - t1) / 1e3, short(r[4])))
+    nxt = [r for r in rows if r[0] >= t1][:40]
+    print('  first 40 kernels of the next step:')
+    for r in nxt:
+        print('    s%d %9.1f %9.1f  %s' % (r[2], (r[0] - t1) / 1e3, (r[1] - t1) / 1e3, short(r[4])))
