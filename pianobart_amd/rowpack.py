@@ -1,0 +1,115 @@
+"""Dead-row compaction of a pre-train batch for the fused step (Engine.loss_and_grads): the host side of csrc/pb_rowmap.hip.
+
+A row of the padded batch is dead when nothing reads what is computed for it (an encoder row that is masked as a key; a decoder
+row that is masked as a key and carries no loss term); DESIGN.md 5 "Packed rows" has the argument why dropping them changes no
+result. `pack_batch` asks the device for the per-sequence counts, plans the packed layout on the host (one small device -> host
+copy and a stream synchronisation per step: the packed row counts size every later launch) and gathers the packed inputs."""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import PB_BF16
+
+PACK_TILE = 256                 # packed row counts are rounded up to whole GEMM tiles
+PACK_MIN_GAIN = 0.97            # stay dense unless at least 3 % of the rows go
+SUB_LAST = int(os.environ.get('PBSUB_LAST', '1'))     # last decoder layer: query side and LM heads on the loss rows only
+SUB_MIN_GAIN = 0.75             # ... unless more than 3/4 of the decoder rows carry a loss term
+
+
+def plan_packed_rows(live, S, tile=PACK_TILE):
+    """live[b] = rows of sequence b that must be kept (<= S). Returns (Tp, off, length): the packed side has Tp rows, a multiple of
+    `tile` (the GEMM row tile; len(live) * S must be one) and no more than len(live) * S; sequence b owns rows off[b] .. off[b] +
+    length[b] - 1, length[b] >= live[b]: the Tp - sum(live) rows of slack are handed out as dead rows of the sequences that have
+    some (first come, first served), so that no sequence grows beyond S."""
+    live = np.asarray(live, dtype=np.int64)
+    cap = np.broadcast_to(np.asarray(S, dtype=np.int64), live.shape)     # S may also be one capacity per sequence
+    total = int(live.sum())
+    Tp = min(-(-max(total, 1) // tile) * tile, int(cap.sum()))
+    cum = np.minimum(np.cumsum(cap - live), Tp - total)
+    length = live + np.diff(np.concatenate([[0], cum]))
+    return Tp, np.concatenate([[0], np.cumsum(length)[:-1]]), length
+
+
+class RowPack:
+    """One packed batch: B, S, Te / Td (rows kept on the encoder / decoder side), the packed inputs enc16 / dec16 / tgt16 /
+    loss_mask, src_* (row b*S + s of every packed row in the padded batch), inv_* (packed row of every (b, s), or -1) and the PackedRows
+    descriptors of the encoder self-, decoder self- and cross-attention."""
+
+
+
+def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
+    """Dead-row compaction of one batch (csrc/pb_rowmap.hip has the argument why it changes no result): returns a RowPack with
+    the packed inputs and the row descriptors of the three attention forms, or None when the step must stay dense (unsupported
+    shape, a decoder mask that is not a prefix mask, or nothing to gain). Costs one small device -> host copy and a stream
+    synchronisation: the packed row counts size every later launch."""
+    B, S = enc16.shape[:2]
+    T = B * S
+    if not (eng.use_flash and eng.hd in (64, 96, 128) and eng.code == PB_BF16 and T % PACK_TILE == 0 and emask is not None
+            and dmask is not None and eng.mlm is not None):
+        return None
+    st = eng._pack_state
+    if st is None or st['key'] != (B, S):
+        dev = eng.device
+        i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
+        st = eng._pack_state = dict(key=(B, S), counts=i32(B, 8), counts_h=torch.empty(B, 8, dtype=torch.int32).pin_memory(),
+                                     desc=i32(8, B), desc_h=torch.empty(8, B, dtype=torch.int32).pin_memory(),
+                                     src_e=i32(T), pos_e=i32(T), inv_e=i32(T), src_d=i32(T), pos_d=i32(T), inv_d=i32(T), src_s=i32(T), idx_s=i32(T),
+                                     tgt16_s=torch.empty(T, 8, dtype=torch.int16, device=dev), lm_s=torch.empty(T, 8, dtype=torch.float32, device=dev),
+                                     enc16=torch.empty(T, 8, dtype=torch.int16, device=dev), dec16=torch.empty(T, 8, dtype=torch.int16, device=dev),
+                                     tgt16=torch.empty(T, 8, dtype=torch.int16, device=dev), lm=torch.empty(T, 8, dtype=torch.float32, device=dev))
+    lm3 = loss_mask.reshape(B, S, 8)
+    ops.rowmap_count(emask, dmask, lm3, st['counts'])
+    st['counts_h'].copy_(st['counts'], non_blocking=True)
+    # work of the step that does not depend on the row counts goes in front of the wait: the GPU projects the Octuple table while the
+    # host plans the packing
+    eng._await_updates(0)
+    eng.refresh_shadow()
+    eng.build_ptab()
+    eng._tables_ready = True
+    torch.cuda.current_stream().synchronize()
+    c = st['counts_h'].numpy().astype(np.int64)
+    if not c[:, 3].all():
+        return None
+    (Te, off_e, len_e), (Td, off_d, len_d) = plan_packed_rows(c[:, 0], S), plan_packed_rows(c[:, 2], S)
+    if Te + Td > PACK_MIN_GAIN * 2 * T:
+        return None
+    # the last decoder layer's query side (cross-attention, FFN) and the LM heads are only needed on rows that carry a loss term:
+    # every other layer's output is a later layer's key / value input, the last layer's is read by the loss alone
+    Ts, off_s, len_s = plan_packed_rows(c[:, 4], len_d)
+    sub = SUB_LAST and eng.ND > 0 and Ts <= SUB_MIN_GAIN * Td
+    if not sub:
+        off_s, len_s = off_d, len_d
+    st['desc_h'].copy_(torch.from_numpy(np.stack([off_e, len_e, c[:, 0], off_d, len_d, c[:, 1], off_s, len_s]).astype(np.int32)))
+    desc = st['desc']
+    desc.copy_(st['desc_h'], non_blocking=True)
+    ops.rowmap_build(emask, None, desc[0], desc[1], st['src_e'], st['pos_e'], st['inv_e'])
+    ops.rowmap_build(dmask, lm3, desc[3], desc[4], st['src_d'], st['pos_d'], st['inv_d'])
+    pk = RowPack()
+    pk.B, pk.S, pk.Te, pk.Td = B, S, Te, Td
+    pk.src_e, pk.src_d, pk.inv_e, pk.inv_d = st['src_e'], st['src_d'], st['inv_e'], st['inv_d']
+    pk.enc16, pk.dec16, pk.tgt16, pk.loss_mask = st['enc16'][:Te], st['dec16'][:Td], st['tgt16'][:Td], st['lm'][:Td]
+    ops.gather_rows16(enc16, st['src_e'], pk.enc16, Te, 16)
+    ops.gather_rows16(dec16, st['src_d'], pk.dec16, Td, 16)
+    ops.gather_rows16(tgt16, st['src_d'], pk.tgt16, Td, 16)
+    ops.gather_rows16(lm3, st['src_d'], pk.loss_mask, Td, 32)
+    me, md = int(len_e.max()), int(len_d.max())
+    vis_e, vis_d = c[:, 0], c[:, 1]
+    pk.pairs = (int((len_e * vis_e).sum()), int((vis_d * vis_d // 2 + (len_d - vis_d) * vis_d).sum()), int((len_d * vis_e).sum()))
+    pk.enc = ops.PackedRows(desc[0], desc[1], desc[0], desc[1], desc[2], me, me, 'enc')
+    pk.dec = ops.PackedRows(desc[3], desc[4], desc[3], desc[4], desc[5], md, md, 'dec')
+    pk.cross = ops.PackedRows(desc[3], desc[4], desc[0], desc[1], desc[2], md, me, 'cross')
+    pk.sub = None
+    if sub:
+        sb = pk.sub = RowPack()
+        sb.T, sb.src, sb.idx = Ts, st['src_s'], st['idx_s']
+        ops.rowmap_build_sub(lm3, st['inv_d'], desc[6], desc[7], sb.src, sb.idx)
+        sb.tgt16, sb.loss_mask = st['tgt16_s'][:Ts], st['lm_s'][:Ts]
+        ops.gather_rows16(pk.tgt16, sb.idx, sb.tgt16, Ts, 16)
+        ops.gather_rows16(pk.loss_mask, sb.idx, sb.loss_mask, Ts, 32)
+        ms = int(len_s.max())
+        sb.cross = ops.PackedRows(desc[6], desc[7], desc[0], desc[1], desc[2], ms, me, 'cross')
+        pk.pairs = pk.pairs[:2] + (pk.pairs[2] * (eng.ND - 1) // eng.ND + int((len_s * vis_e).sum()) // eng.ND,)     # layer mean
+    return pk
+

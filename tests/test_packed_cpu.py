@@ -1,8 +1,8 @@
-"""Host side of the dead-row compaction: the row plan (Engine._pack_batch -> plan_packed_rows). The kernels are tested on the GPU
+"""Host side of the dead-row compaction: the row plan (rowpack.pack_batch -> plan_packed_rows). The kernels are tested on the GPU
 (tests/test_packed_gpu.py)."""
 import numpy as np
 
-from pianobart_amd.engine import plan_packed_rows
+from pianobart_amd.rowpack import plan_packed_rows
 
 
 def test_plan_keeps_every_live_row_and_fills_whole_tiles():
