@@ -227,7 +227,7 @@ def _step(eng, args, pack, monkeypatch, seed=77, train=True):
 
 
 @pytest.mark.parametrize('heads,tail_loss,hole,dropout,sparse', [(4, False, False, 0.0, False), (4, True, False, 0.1, True), (2, True, True, 0.1, True),
-                                                                 (4, False, False, 0.0, True)])
+                                                                 (4, False, False, 0.0, True), (-4, True, False, 0.1, True)])
 def test_packed_step_equals_dense_step(ops, monkeypatch, heads, tail_loss, hole, dropout, sparse):
     """The fused pre-train step with the dead rows dropped gives the dense step's loss sums and gradients, dropout included (a
     packed row draws the dropout bits of its row in the padded batch). The comparison is to bf16 rounding: the
@@ -238,6 +238,8 @@ def test_packed_step_equals_dense_step(ops, monkeypatch, heads, tail_loss, hole,
     from tests.golden_util import load_vocab, randomize_params, synth_octuple_batch
     e2w, w2e = load_vocab()
     B, S, d = 6, 256, 256
+    if heads < 0:                                                       # head_dim 96 (the secondary cfg-2 shape's head size)
+        heads, d = -heads, 384
     cfg = BartConfig(max_position_embeddings=S, d_model=d, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
                      encoder_attention_heads=heads, decoder_attention_heads=heads, dropout=dropout)
     m = PianoBartLM(PianoBart(cfg, e2w, w2e, precision='bf16'))
