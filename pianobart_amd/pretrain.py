@@ -109,6 +109,16 @@ def load_data_pretrain(datasets, mode, root='Data/output_pretrain'):
     return pool.subset(index[:split]), pool.subset(index[split:])
 
 
+def _loader_kw(num_workers):
+    """Worker processes survive the epochs: forking and importing five of them costs seconds, every epoch, in the reference's
+    DataLoader(num_workers=5). No pin_memory: a batch is 0.5 MB of int16, and pinning one per step (hipHostMalloc / hipHostFree)
+    synchronises the device -- measured 63.1 -> 65.5 ms per batch."""
+    kw = dict(num_workers=num_workers)
+    if num_workers > 0:
+        kw.update(persistent_workers=True, prefetch_factor=4)
+    return kw
+
+
 def make_loaders(X_train, X_val, batch_size, num_workers, seed=None):
     """main.py:28-35. One process: the reference's two DataLoaders. Under torchrun `batch_size` stays the GLOBAL batch (what
     nn.DataParallel scatters, pretrain.py:63-65): each rank loads batch_size / world samples per step through a
@@ -117,8 +127,9 @@ def make_loaders(X_train, X_val, batch_size, num_workers, seed=None):
     from torch.utils.data.distributed import DistributedSampler
     rank, world = _dist_env()
     if world == 1:
-        return (DataLoader(MidiDataset(X=X_train), batch_size=batch_size, num_workers=num_workers, shuffle=True),
-                DataLoader(MidiDataset(X=X_val), batch_size=batch_size, num_workers=num_workers))
+        kw = _loader_kw(num_workers)
+        return (DataLoader(MidiDataset(X=X_train), batch_size=batch_size, shuffle=True, **kw),
+                DataLoader(MidiDataset(X=X_val), batch_size=batch_size, **kw))
     if batch_size % world:
         raise PBError('--batch_size %d is the global batch and must be a multiple of the %d ranks' % (batch_size, world))
     if seed is None:
@@ -127,7 +138,7 @@ def make_loaders(X_train, X_val, batch_size, num_workers, seed=None):
     for X, shuffle in ((X_train, True), (X_val, False)):
         ds = MidiDataset(X=X)
         sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed)
-        loaders.append(DataLoader(ds, batch_size=batch_size // world, num_workers=num_workers, sampler=sampler))
+        loaders.append(DataLoader(ds, batch_size=batch_size // world, sampler=sampler, **_loader_kw(num_workers)))
     return tuple(loaders)
 
 
@@ -236,17 +247,10 @@ class Pretrainer:
     def iteration(self, training_data, max_seq_len, train=True):
         eng = self.engine
         total_acc, total_losses, nb = np.zeros(8), 0.0, 0
-        for ori_seq_batch in training_data:
-            enc16, dec16, tgt16, loss_mask, emask, dmask = self.prepare_batch(ori_seq_batch)
-            sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=train,
-                                      count_hook=self.reducer.reduce_counts if self.reducer else None)
-            if train:
-                if self.reducer:
-                    self.reducer.all_reduce_grads()
-                eng.optimizer_step(lr=self.lr)
-            if self.reducer:
-                self.reducer.reduce_sums(sums)
-            s = sums.double().cpu().numpy()                          # the one host sync of the step
+        def report(sums):
+            """The log lines of one step (pretrain.py:198-207) from its 24 sums: the one device -> host read of the step."""
+            nonlocal total_acc, total_losses, nb
+            s = sums.double().cpu().numpy()
             losses = s[0:8] / s[8:16]
             accs = s[16:24] / s[8:16]
             total_loss = float((losses * self._w).sum() / self._w.sum())
@@ -256,6 +260,26 @@ class Pretrainer:
             total_acc += accs
             total_losses += total_loss
             nb += 1
+
+        # The sums of step i are read (and its lines written) after step i + 1 has been handed to the GPU: fetching and preparing
+        # the next batch on the host then runs beside the device step instead of between two of them.
+        pending = None
+        for ori_seq_batch in training_data:
+            enc16, dec16, tgt16, loss_mask, emask, dmask = self.prepare_batch(ori_seq_batch)
+            sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=train,
+                                      count_hook=self.reducer.reduce_counts if self.reducer else None)
+            if train:
+                if self.reducer:
+                    self.reducer.all_reduce_grads()
+                eng.optimizer_step(lr=self.lr)
+            sums = sums.clone()                                     # the engine reuses its scalar buffer in the next step
+            if self.reducer:
+                self.reducer.reduce_sums(sums)
+            if pending is not None:
+                report(pending)
+            pending = sums
+        if pending is not None:
+            report(pending)
         n = max(1, len(training_data))
         return round(total_losses / n, 3), [round(float(x) / n, 3) for x in total_acc]
 
