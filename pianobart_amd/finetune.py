@@ -285,7 +285,8 @@ def _finetune_loaders(args):
     """The three DataLoaders of main.py:126-141 (train shuffled) + the shape of the test labels."""
     from torch.utils.data import DataLoader
     X_train, X_val, X_test, y_train, y_val, y_test = load_data_finetune(args.dataset, args.task, args.dataroot)
-    loaders = [DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=shuffle)
+    from .pretrain import _loader_kw                                          # persistent workers (see there)
+    loaders = [DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, shuffle=shuffle, **_loader_kw(args.num_workers))
                for X, y, shuffle in ((X_train, y_train, True), (X_val, y_val, False), (X_test, y_test, False))]
     for tag, ld in zip(('train', 'valid', 'valid'), loaders):                  # the reference prints "valid_loader" twice
         print('   len of %s_loader' % tag, len(ld))

@@ -171,11 +171,12 @@ def finetune_generation(argv=None):
     else:
         with open(args.dict_file, 'rb') as f:
             e2w, w2e = pickle.load(f)
+    from .pretrain import _loader_kw                              # persistent workers (see there)
     print("\nLoading Dataset")
     X_train, X_val, X_test, y_train, y_val, y_test = load_data_generation(args.datasets, args.dataroot)
     loaders = []
     for X, y, shuffle, tag in ((X_train, y_train, True, 'train'), (X_val, y_val, False, 'valid'), (X_test, y_test, False, 'valid')):
-        loaders.append(DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, num_workers=args.num_workers, shuffle=shuffle))
+        loaders.append(DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, shuffle=shuffle, **_loader_kw(args.num_workers)))
         print("   len of %s_loader" % tag, len(loaders[-1]))
     print("\nBuilding BART model")
     pianobart = PianoBart(bartConfig=BartConfig(max_position_embeddings=args.max_seq_len, d_model=args.hs, encoder_layers=args.layers,
