@@ -379,3 +379,34 @@ def test_pipelined_parameter_update_takes_the_same_steps(ops):
     for k in a[5]:
         assert torch.equal(a[5][k], b[5][k]), k
     assert float((a[0][0] - a[0][2]).abs().max()) > 0                         # the steps did move the parameters
+
+
+def test_packed_step_with_an_empty_sequence(ops, monkeypatch):
+    """Edge of the row maps: a sequence with no visible encoder row at all (its decoder queries then see no cross-attention key:
+    zero rows, like the padded kernels) and a decoder side that is just the SOS row; packed and padded steps must agree."""
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab, randomize_params, synth_octuple_batch
+    e2w, w2e = load_vocab()
+    B, S, d = 4, 256, 256
+    cfg = BartConfig(max_position_embeddings=S, d_model=d, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+                     encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.0)
+    m = PianoBartLM(PianoBart(cfg, e2w, w2e, precision='bf16'))
+    randomize_params(m, 13)
+    m = m.train().cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(B, S, seed=4)]
+    emask, dmask, loss_mask = emask.clone().float(), dmask.clone().float(), loss_mask.clone().float()
+    emask[0] = 0                                                        # nothing of sequence 0 is visible to anybody
+    dmask[0] = 0; dmask[0, 0] = 1
+    loss_mask[0] = 0; loss_mask[0, 0] = 1
+    emask[1, 100:] = 0; dmask[1, 50:] = 0; loss_mask[1, 50:] = 0
+    args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+    s0, g0, r0 = _step(eng, args, False, monkeypatch)
+    s1, g1, r1 = _step(eng, args, True, monkeypatch)
+    assert r1[0] < B * S and r1[1] < B * S, r1
+    assert torch.isfinite(s1).all() and torch.isfinite(g1).all()
+    assert torch.equal(s0[8:16], s1[8:16]) and torch.allclose(s0[:8], s1[:8], rtol=1e-3)
+    for name, sl in eng.slots.items():
+        a, b_ = g0[sl.off:sl.off + sl.numel], g1[sl.off:sl.off + sl.numel]
+        assert float((a - b_).norm()) <= 2e-2 * float(a.norm()) + 1e-6, name
