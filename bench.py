@@ -354,6 +354,10 @@ def main():
                     step()
                 torch.cuda.synchronize()
                 families, table, shapes = probe.summary(nprobe, peak)
+            if os.environ.get('PB_PROBE_DUMP'):                      # developer aid: every op label of the probed steps, not only the top 12
+                with open(os.environ['PB_PROBE_DUMP'], 'w') as fh:
+                    for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+                        fh.write('%9.1f us x %5.1f  %8.1f TF  %s\n' % (1e3 * v[0] / v[2], v[2] / nprobe, (v[1] / (v[0] * 1e-3) / 1e12) if v[1] else 0.0, k))
             key = [k for k in shapes if any(k.startswith('gemm NT %dx%dx%d+bias+gelu' % (m_, args.ffn, args.hs)) for m_ in {Te, Td})]
             if key:                                                   # fc1 of the encoder (M = Te) and decoder (M = Td) layers
                 n_ = sum(shapes[k][2] for k in key)

@@ -31,12 +31,11 @@ LN_EPS = 1e-5
 
 
 # copies of the backward scratch buffers that the second stream's weight-gradient GEMMs read (gB, du, dq, dkv, dqkv): with 2 the main
-# stream can write the next sublayer's cotangent while the weight gradient of the previous one is still reading its own
-_RING = int(os.environ.get('PB_RING', '2'))
-# events that order the two streams: 1 = HIP events without the system-scope fence (hipEventDisableSystemFence: 59.5 -> 59.1 ms/step),
-# 2 = hipEventReleaseToDevice (no gain; the two together are rejected), 0 = plain hipEventDisableTiming events,
-# -1 = torch.cuda.Event (same as 0, created per use)
-_EVENT_MODE = int(os.environ.get('PB_EVENT_MODE', '1'))
+# stream can write the next sublayer's cotangent while the weight gradient of the previous one is still reading its own (3: slower)
+_RING = 2
+# events that order the two streams: HIP events without the system-scope fence (hipEventDisableSystemFence: 59.5 -> 59.1 ms/step
+# against plain hipEventDisableTiming events; hipEventReleaseToDevice: no gain)
+_EVENT_MODE = 1
 _SIDE_TAIL = int(os.environ.get('PB_SIDE_TAIL', '1'))  # end of backward: decoder half of dP, the deferred reductions and one f32 GEMM on the second stream
 _DGRAD_NT = int(os.environ.get('PB_DGRAD_NT', '1'))    # backward dX = dY W from transposed weight copies (NT GEMM) instead of the NN form
 _FWD_GEMM_FLAGS = int(os.environ.get('PB_FWD_GEMM_FLAGS', '32768'))      # PB_GEMM_TAIL_SPLIT for the forward projections (0: off)
@@ -61,18 +60,6 @@ class _HipEvent:
     def wait_on(self, stream):
         import ctypes
         LIB.call('pb_stream_wait_event', ctypes.c_void_p(stream.cuda_stream), self.h)
-
-
-class _TorchEvent:
-    __slots__ = ('e',)
-
-    def record(self):
-        self.e = torch.cuda.Event()
-        self.e.record()
-        return self
-
-    def wait_on(self, stream):
-        stream.wait_event(self.e)
 
 
 def _r4(n):
@@ -639,8 +626,6 @@ class Engine:
 
     def _event(self):
         """A recorded event on the current stream (from a round-robin pool far longer than the events a step has in flight)."""
-        if _EVENT_MODE < 0:
-            return _TorchEvent().record()
         pool = self._ev_pool
         if pool is None:
             pool = self._ev_pool = [[_HipEvent(_EVENT_MODE) for _ in range(2048)], 0]
@@ -714,9 +699,6 @@ class Engine:
         if self.grad_hook is not None and self.Gcur is self.G32:
             a, b = self.slots[first], self.slots[last or first]
             if self._side_last is None:
-                return self.grad_hook(a.off, b.off + b.numel)
-            if os.environ.get('PB_READY_JOIN'):
-                self._join_side()
                 return self.grad_hook(a.off, b.off + b.numel)
             # the range was produced by both streams: let the second stream catch up with this one and issue the exchange from it
             # (the collective's own stream orders itself after the stream that is current at the call), so this one never waits

@@ -159,7 +159,8 @@ class FinetuneTrainer:
         self.head_optim = HeadAdamW([p for p in self.model.parameters() if id(p) not in in_engine], lr=lr, weight_decay=0.01,
                                     never=[pianobart.bart.shared.weight])      # never read, never a gradient (SURVEY a-3)
         self.lr = lr
-        # one process per GPU (torch.distributed.run): every rank steps its own mini-batch, gradients are AVERAGED over the ranks -- the
+        # one process per GPU (torch.distributed.run): every rank steps its own shard of the global mini-batch (make_finetune_loaders),
+        # gradients are AVERAGED over the ranks -- the
         # backbone's through the engine's bucket exchange (summed, then scaled by 1 / world in the optimizer step), the head parameters'
         # with one all-reduce of the head optimizer's flat gradient buffer. data_parallel=True installs this at world size 1 (tests).
         self.world = int(os.environ.get('WORLD_SIZE', 1))
@@ -221,6 +222,10 @@ class FinetuneTrainer:
     def iteration(self, training_data, mode, seq):
         total_acc, total_cnt, total_loss = 0.0, 0, 0.0
         self.model.train(mode == 0)
+        sampler = getattr(training_data, 'sampler', None)
+        if mode == 0 and hasattr(sampler, 'set_epoch'):                      # rank-sharded training set: a new permutation per epoch
+            self._epoch = getattr(self, '_epoch', -1) + 1
+            sampler.set_epoch(self._epoch)
         all_output, cnt = (torch.empty(self.testset_shape) if mode == 2 else None), 0
         with torch.set_grad_enabled(mode == 0):
             for x, y in training_data:
@@ -269,7 +274,10 @@ class FinetuneTrainer:
                         self.head_optim.G.mul_(1.0 / self.world)
                     self.engine.optimizer_step(lr=self.lr, max_norm=float('inf'), gscale=1.0 / self.world)   # no clipping in fine-tune (finetune.py:227)
                     self.head_optim.step(gathered=self.reducer is not None)
-        res = (round(total_loss / len(training_data), 4), round(total_acc / total_cnt, 4))
+        nb = len(training_data)
+        if mode == 0 and self.world > 1:                                     # every rank saw its own shard: report the job's numbers
+            total_loss, total_acc, total_cnt, nb = reduce_epoch_sums([total_loss, total_acc, total_cnt, nb], self.device)
+        res = (round(total_loss / nb, 4), round(total_acc / total_cnt, 4))
         return res + (all_output,) if mode == 2 else res
 
     def save_checkpoint(self, epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename):
@@ -281,13 +289,43 @@ class FinetuneTrainer:
             shutil.copyfile(filename, filename.split('.')[0] + '_best.ckpt')
 
 
-def _finetune_loaders(args):
-    """The three DataLoaders of main.py:126-141 (train shuffled) + the shape of the test labels."""
+def make_finetune_loaders(arrays, batch_size, num_workers, seed=2023):
+    """The three DataLoaders of main.py:126-141 / 240-255 (train shuffled) from (X_train, X_val, X_test, y_train, y_val, y_test).
+    Under torchrun `batch_size` stays the GLOBAL batch (what nn.DataParallel scatters): the TRAIN loader hands each rank
+    batch_size / world samples per step through a DistributedSampler (same permutation seed on every rank; the trainer calls
+    set_epoch); the validation and test loaders stay whole on every rank, so every rank reports the same numbers and the
+    (N, S) test output needs no gather."""
     from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from .pretrain import _dist_env, _loader_kw                               # persistent workers (see there)
+    X_train, X_val, X_test, y_train, y_val, y_test = arrays
+    rank, world = _dist_env()
+    kw = _loader_kw(num_workers)
+    train_ds = FinetuneDataset(X=X_train, y=y_train)
+    if world > 1:
+        if batch_size % world:
+            raise PBError('--batch_size %d is the global batch and must be a multiple of the %d ranks' % (batch_size, world))
+        sampler = DistributedSampler(train_ds, num_replicas=world, rank=rank, shuffle=True, seed=seed)
+        train = DataLoader(train_ds, batch_size=batch_size // world, sampler=sampler, **kw)
+    else:
+        train = DataLoader(train_ds, batch_size=batch_size, shuffle=True, **kw)
+    return [train] + [DataLoader(FinetuneDataset(X=X, y=y), batch_size=batch_size, **kw) for X, y in ((X_val, y_val), (X_test, y_test))]
+
+
+def reduce_epoch_sums(values, device):
+    """Sum a list of per-rank epoch counters over the ranks (training metrics of a rank-sharded epoch); identity at world size 1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t)
+    return t.cpu().tolist()
+
+
+def _finetune_loaders(args):
+    """The three DataLoaders of main.py:126-141 (train shuffled; rank-sharded under torchrun) + the shape of the test labels."""
     X_train, X_val, X_test, y_train, y_val, y_test = load_data_finetune(args.dataset, args.task, args.dataroot)
-    from .pretrain import _loader_kw                                          # persistent workers (see there)
-    loaders = [DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, shuffle=shuffle, **_loader_kw(args.num_workers))
-               for X, y, shuffle in ((X_train, y_train, True), (X_val, y_val, False), (X_test, y_test, False))]
+    loaders = make_finetune_loaders((X_train, X_val, X_test, y_train, y_val, y_test), args.batch_size, args.num_workers)
     for tag, ld in zip(('train', 'valid', 'valid'), loaders):                  # the reference prints "valid_loader" twice
         print('   len of %s_loader' % tag, len(ld))
     return loaders, y_test.shape
@@ -324,7 +362,8 @@ def finetune(argv=None):
     filename = os.path.join(save_dir, 'model.ckpt')
     print('   save model at {}'.format(filename))
     best_acc, stale = 0, 0
-    with open(os.path.join(save_dir, 'log'), 'a') as log:
+    rank0 = int(os.environ.get('RANK', 0)) == 0                                # one writer: every rank holds the same model and numbers
+    with open(os.path.join(save_dir, 'log') if rank0 else os.devnull, 'a') as log:
         log.write('Loading pre-trained model from ' + best_mdl.split('/')[-1] + '\n')
         for epoch in range(args.epochs):
             (train_loss, train_acc), (valid_loss, valid_acc) = trainer.train(), trainer.valid()
@@ -334,7 +373,8 @@ def finetune(argv=None):
             stale = 0 if is_best else stale + 1
             print('epoch: {}/{} | Train Loss: {} | Train acc: {} | Valid Loss: {} | Valid acc: {} | Test loss: {} | Test acc: {}'.format(
                 epoch + 1, args.epochs, train_loss, train_acc, valid_loss, valid_acc, test_loss, test_acc))
-            trainer.save_checkpoint(epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename)
+            if rank0:
+                trainer.save_checkpoint(epoch, train_acc, valid_acc, valid_loss, train_loss, is_best, filename)
             log.write('Epoch {}: train_loss={}, valid_loss={}, test_loss={}, train_acc={}, valid_acc={}, test_acc={}\n'.format(
                 epoch + 1, train_loss, valid_loss, test_loss, train_acc, valid_acc, test_acc))
             log.flush()

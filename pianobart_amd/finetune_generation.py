@@ -68,7 +68,9 @@ class GenerationTrainer:
             raise PBError('pianobart_amd has no CPU execution path')
         if cuda_devices is not None and len(cuda_devices) > 1:
             raise PBError('nn.DataParallel is replaced by one process per GPU (torch.distributed.run)')
-        self.device = torch.device('cuda', cuda_devices[0] if cuda_devices else 0)
+        dev_id = int(os.environ['LOCAL_RANK']) if 'LOCAL_RANK' in os.environ else (cuda_devices[0] if cuda_devices else 0)
+        self.device = torch.device('cuda', dev_id)                              # torchrun: one GPU per rank
+        torch.cuda.set_device(self.device)
         print('   device:', self.device)
         self.pianobart = pianobart
         self.model = (model if model is not None else PianoBartLM(pianobart)).to(self.device)
@@ -107,6 +109,10 @@ class GenerationTrainer:
         eng, pad = self.engine, int(self.pianobart.bar_pad_word)
         total_acc, total_loss = np.zeros(8), 0.0
         all_output, cnt = (torch.empty(self.testset_shape) if mode == 2 else None), 0
+        sampler = getattr(training_data, 'sampler', None)
+        if mode == 0 and hasattr(sampler, 'set_epoch'):                      # rank-sharded training set (make_finetune_loaders)
+            self._epoch = getattr(self, '_epoch', -1) + 1
+            sampler.set_epoch(self._epoch)
         for x, y in training_data:
             x, y = x.to(self.device).long(), y.to(self.device).long()
             B, S = x.shape[:2]
@@ -157,8 +163,7 @@ def finetune_generation(argv=None):
     the n_tokens-weighted validation accuracy, the reference's checkpoint keys and log / stdout line formats."""
     import pickle
     import random
-    from torch.utils.data import DataLoader
-    from .finetune import FinetuneDataset
+    from .finetune import make_finetune_loaders
     from .model import BartConfig, PianoBart
     for seed_fn in (torch.manual_seed, np.random.seed, random.seed):
         seed_fn(2023)
@@ -171,13 +176,12 @@ def finetune_generation(argv=None):
     else:
         with open(args.dict_file, 'rb') as f:
             e2w, w2e = pickle.load(f)
-    from .pretrain import _loader_kw                              # persistent workers (see there)
     print("\nLoading Dataset")
     X_train, X_val, X_test, y_train, y_val, y_test = load_data_generation(args.datasets, args.dataroot)
-    loaders = []
-    for X, y, shuffle, tag in ((X_train, y_train, True, 'train'), (X_val, y_val, False, 'valid'), (X_test, y_test, False, 'valid')):
-        loaders.append(DataLoader(FinetuneDataset(X=X, y=y), batch_size=args.batch_size, shuffle=shuffle, **_loader_kw(args.num_workers)))
-        print("   len of %s_loader" % tag, len(loaders[-1]))
+    # train loader rank-sharded under torchrun (global --batch_size), validation / test whole on every rank
+    loaders = make_finetune_loaders((X_train, X_val, X_test, y_train, y_val, y_test), args.batch_size, args.num_workers)
+    for tag, ld in zip(('train', 'valid', 'valid'), loaders):
+        print("   len of %s_loader" % tag, len(ld))
     print("\nBuilding BART model")
     pianobart = PianoBart(bartConfig=BartConfig(max_position_embeddings=args.max_seq_len, d_model=args.hs, encoder_layers=args.layers,
                                                 encoder_ffn_dim=args.ffn_dims, encoder_attention_heads=args.heads, decoder_layers=args.layers,

@@ -14,7 +14,7 @@ from ._lib import PB_BF16
 
 PACK_TILE = 256                 # packed row counts are rounded up to whole GEMM tiles
 PACK_MIN_GAIN = 0.97            # stay dense unless at least 3 % of the rows go
-SUB_LAST = int(os.environ.get('PBSUB_LAST', '1'))     # last decoder layer: query side and LM heads on the loss rows only
+SUB_LAST = int(os.environ.get('PB_SUB_LAST', '1'))     # last decoder layer: query side and LM heads on the loss rows only
 SUB_MIN_GAIN = 0.75             # ... unless more than 3/4 of the decoder rows carry a loss term
 
 

@@ -268,7 +268,10 @@ def test_bf16_step_matches_fp32_step_cfg2_shape(ops):
     Philox masks in both precisions): loss, global gradient norm and every parameter tensor's gradient, bf16 vs exact f32. Then the
     bf16 step again on one stream: bit-identical to the two-stream schedule at this size."""
     from pianobart_amd import engine as E
-    ebf, mbf, batch = _compare_steps(ops, 1024, 768, 12, 3072, 12, 8, tol_loss=1e-3, tol_gn=2e-2, tol_slot=0.1)
+    # bounds ~2x the measured differences (loss 2.4e-5 .. 3.4e-5, gradient norm 3.3e-3 .. 3.7e-3, worst tensor 3.5e-2)
+    ebf, mbf, batch = _compare_steps(ops, 1024, 768, 12, 3072, 12, 8, tol_loss=2e-4, tol_gn=1e-2, tol_slot=0.07)
+    Te, Td, T, Ts = ebf.last_rows
+    assert Te < T and Td < T and Ts < Td, ebf.last_rows      # the bf16 side of this comparison is the PACKED step
     if ebf._side_stream() is not None:
         two = ebf.G32.clone()
         saved = E._WGRAD_STREAM
@@ -292,6 +295,8 @@ def test_bf16_step_at_full_bench_batch_is_finite_and_consistent(ops):
     batch = [t.cuda() for t in synth_octuple_batch(32, 1024, seed=1234)]
     eng, loss, sums = _step(ops, m, batch, 5)
     assert math.isfinite(loss) and bool(torch.isfinite(eng.G32).all())
+    Te, Td, T, Ts = eng.last_rows
+    assert T == 32768 and Te < T and Td < T and Ts < Td, eng.last_rows      # the bench's own row counts: packed, last layer on the loss rows
     g_full = eng.G32.double().clone()
     parts = torch.zeros(24, dtype=torch.double)
     for i in range(4):
@@ -305,7 +310,7 @@ def test_bf16_step_at_full_bench_batch_is_finite_and_consistent(ops):
 
 def test_bf16_step_matches_fp32_step_cfg5_shape(ops):
     """configs[4] shape: 24L / 1024 / ffn 4096 / 16 heads, S = 2048, B = 1 (d = 1024 row kernels, head_dim 64 at S = 2048)."""
-    _compare_steps(ops, 2048, 1024, 24, 4096, 16, 1, tol_loss=2e-3, tol_gn=2e-2, tol_slot=0.15)
+    _compare_steps(ops, 2048, 1024, 24, 4096, 16, 1, tol_loss=5e-4, tol_gn=1e-2, tol_slot=0.1)      # measured 1.1e-4 / 2.8e-3 / 4.7e-2
 
 
 def test_g10_cfg2_shape_spot_check_bf16():
@@ -334,5 +339,5 @@ def test_g10_cfg2_shape_spot_check_bf16():
     clear = z['top2_gap'] > 5e-2 * float(z['logit_absmax'])
     print('cfg2 bf16 logits rel = %.3e; argmax agreement %.4f overall, %.4f of the %.1f %% with a top-2 gap > 5%% of max|logit|'
           % (rel, agree, float((arg[clear] == ref[clear]).mean()), 100 * clear.mean()))
-    assert rel < 4e-2
+    assert rel < 2.5e-2                                  # measured 1.4e-2 - 1.5e-2
     assert agree > 0.995 and np.array_equal(arg[clear], ref[clear])

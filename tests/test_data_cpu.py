@@ -108,3 +108,72 @@ def test_per_rank_random_streams_differ(monkeypatch):
         m = PianoBartLM(PianoBart(cfg, e2w, w2e))
         seeds.append(Engine(m.pianobart, m.mask_lm, 'bf16')._seed)
     assert len(set(seeds)) == 3 and seeds[0] == 0x5EED1234
+
+
+def _ft_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pianobart_amd.finetune import make_finetune_loaders, reduce_epoch_sums
+        X = np.arange(11 * 4 * 8).reshape(11, 4, 8)
+        y = np.arange(11)
+        arrays = (X, X[:5], X[:3], y, y[:5], y[:3])
+        tr, va, te = make_finetune_loaders(arrays, batch_size=4, num_workers=0)
+        epochs = []
+        for e in range(2):
+            tr.sampler.set_epoch(e)
+            epochs.append([int(v) for _, yy in tr for v in yy])
+        sums = reduce_epoch_sums([1.0 + rank, 10.0], 'cpu')
+        q.put((rank, tr.batch_size, epochs, [int(v) for _, yy in va for v in yy], [int(v) for _, yy in te for v in yy], sums))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_finetune_loaders_shard_the_training_set_gloo():
+    """the fine-tune drivers under torchrun must not feed every rank the same batches. Train loader: rank-sharded
+    (global batch 4 -> 2 per rank, disjoint cover, new permutation per epoch); validation / test: whole on every rank; epoch
+    counters summed over the ranks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_ft_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, bs0, ep0, va0, te0, s0), (_, bs1, ep1, va1, te1, s1) = res
+    assert bs0 == bs1 == 2
+    for e in range(2):
+        assert set(ep0[e]) | set(ep1[e]) == set(range(11)) and len(set(ep0[e]) & set(ep1[e])) <= 1
+    assert ep0[0] != ep0[1]
+    assert va0 == va1 == list(range(5)) and te0 == te1 == list(range(3))
+    assert s0 == s1 == [3.0, 20.0]
+
+
+def test_documented_env_toggles_are_the_ones_the_code_reads():
+    """ADVICE r2 (PBSUB_LAST): every PB_* name DESIGN.md / README.md / INTEGRATION.md mention is read somewhere in the package,
+    bench.py or tools/, and every PB_* environment read in the package is documented in DESIGN.md."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rd = lambda *p: open(os.path.join(root, *p), errors='ignore').read()
+    code = {}
+    for dirpath, _, files in list(os.walk(os.path.join(root, 'pianobart_amd'))) + list(os.walk(os.path.join(root, 'tools'))) + [(root, [], ['bench.py'])]:
+        for f in files:
+            if f.endswith(('.py', '.sh', '.hip', '.h')):
+                code[os.path.join(dirpath, f)] = rd(dirpath, f)
+    read = set()
+    for path, txt in code.items():
+        read |= set(re.findall(r"environ(?:\.get\(|\[|\.setdefault\()\s*'(PB_[A-Z0-9_]+)'", txt))
+        read |= set(re.findall(r"\b(PB_[A-Z0-9_]+)=", txt)) if path.endswith('.sh') else set()
+    docs = rd('DESIGN.md') + rd('README.md') + rd('INTEGRATION.md')
+    flags = set(re.findall(r'\bPB_GEMM_[A-Z0-9_]+|\bPB_BF16|\bPB_F32', docs + ''.join(code.values())))       # C-ABI constants, not environment names
+    documented = set(re.findall(r'`(PB_[A-Z0-9_]+)(?:=[^`]*)?`', docs)) - flags
+    pkg_read = set()
+    for path, txt in code.items():
+        if os.sep + 'pianobart_amd' + os.sep in path:
+            pkg_read |= set(re.findall(r"environ(?:\.get\(|\[)\s*'(PB_[A-Z0-9_]+)'", txt))
+    assert documented <= read, sorted(documented - read)
+    assert pkg_read <= set(re.findall(r'PB_[A-Z0-9_]+', docs)), sorted(pkg_read - set(re.findall(r'PB_[A-Z0-9_]+', docs)))

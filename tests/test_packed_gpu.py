@@ -410,3 +410,63 @@ def test_packed_step_with_an_empty_sequence(ops, monkeypatch):
     for name, sl in eng.slots.items():
         a, b_ = g0[sl.off:sl.off + sl.numel], g1[sl.off:sl.off + sl.numel]
         assert float((a - b_).norm()) <= 2e-2 * float(a.norm()) + 1e-6, name
+
+
+def test_packed_step_against_the_oracle_directly(ops, monkeypatch):
+    """The step the bench times (bf16, dead rows dropped, last decoder layer on the loss rows) against the CPU oracle on the PADDED
+    batch -- no dense HIP step in between. 2L / 256d / 4 heads, B = 6, S = 256, ragged PAD tails on both sides, sparse loss mask,
+    dropout 0. Follows pretrain.py:112-118 (masked CE, sum / sum per head, e2w-order weights) and :159-196 (forward, backward).
+    Bounds are ~2x the measured bf16-vs-f32 differences of this case (loss 2e-4, gradient norm 4e-3, named gradients 2-4e-2)."""
+    from oracle import pianobart_oracle as O
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab, randomize_params, synth_octuple_batch
+    e2w, w2e = load_vocab()
+    B, S, d = 6, 256, 256
+    kw = dict(max_position_embeddings=S, d_model=d, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+              encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.0)
+    m = PianoBartLM(PianoBart(BartConfig(**kw), e2w, w2e, precision='bf16')).train()
+    randomize_params(m, 11)
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(**kw), e2w, w2e)).train()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(B, S, seed=9)
+    rng = np.random.default_rng(3)
+    Le, Ld = rng.integers(40, S + 1, size=B), rng.integers(40, S + 1, size=B)
+    Le[0], Ld[1] = S, S
+    emask, dmask, loss_mask = emask.clone().float(), dmask.clone().float(), loss_mask.clone().float()
+    for b in range(B):
+        emask[b, :Le[b]] = 1; emask[b, Le[b]:] = 0
+        dmask[b, :Ld[b]] = 1; dmask[b, Ld[b]:] = 0
+        loss_mask[b] = 0
+        loss_mask[b, :Ld[b]] = torch.from_numpy((rng.random((Ld[b], 8)) < 0.15).astype(np.float32))
+        loss_mask[b, 1, :] = 1
+    # the oracle on the padded batch (CPU, seconds)
+    yo = o(enc, dec, emask, dmask)
+    total_o, *_ = O.pretrain_loss(yo, target, loss_mask, e2w)
+    total_o.backward()
+    go = {k: p.grad.double() for k, p in o.named_parameters() if p.grad is not None}
+    gn_o = float(torch.sqrt(sum((g ** 2).sum() for g in go.values())))
+    # the packed HIP step
+    dev = lambda t: t.cuda()
+    args = (ops.ids_to_i16(dev(enc)), ops.ids_to_i16(dev(dec)), ops.ids_to_i16(dev(target)), dev(loss_mask).contiguous(), dev(emask), dev(dmask))
+    sums, G, rows = _step(eng, args, True, monkeypatch)
+    Te, Td, T, Ts = rows
+    assert Te < T and Td < T and Ts < Td, rows                          # it really packed, and the last layer ran on the loss rows only
+    s = sums.double().cpu()
+    w = torch.tensor([262, 134, 262, 134, 38, 135, 55, 260], dtype=torch.double)
+    loss = float(((s[0:8] / s[8:16]) * w).sum() / w.sum())
+    assert torch.equal(s[8:16], loss_mask.double().sum((0, 1)))
+    assert abs(loss - float(total_o)) / float(total_o) < 5e-4, (loss, float(total_o))
+    views = {id(p): g for p, g in zip(eng.params, eng.grad_views_of(G))}
+    named = {k: views[id(p)].double().cpu() for k, p in m.named_parameters() if id(p) in views}
+    gn = float(torch.sqrt(sum((g ** 2).sum() for k, g in named.items() if k in go)))
+    print('packed bf16 step vs oracle: loss %.6f / %.6f, grad norm %.5f / %.5f, rows %s' % (loss, float(total_o), gn, gn_o, rows))
+    assert abs(gn - gn_o) / gn_o < 1e-2
+    for k in ('pianobart.bart.encoder.layers.0.fc1.weight', 'pianobart.bart.decoder.layers.1.encoder_attn.q_proj.weight',
+              'pianobart.bart.decoder.layers.1.fc2.weight', 'pianobart.bart.decoder.layers.0.self_attn.v_proj.weight', 'mask_lm.proj.3.weight',
+              'pianobart.word_emb.3.lut.weight', 'pianobart.bart.decoder.layers.1.final_layer_norm.weight'):
+        e = float((named[k] - go[k]).norm() / go[k].norm())
+        print('   %-70s rel %.3e' % (k, e))
+        assert e < 8e-2, (k, e)
