@@ -327,6 +327,29 @@ typedef struct pb_decode_plan {
 } pb_decode_plan;
 int pb_decode_step(const pb_decode_plan* plan, int32_t i, void* stream);
 
+/* Decode as ONE hipGraph replay per token (round 3; replaces the per-position host loop of model.py:42-65 around pb_decode_step for the
+ * shapes it covers: bf16, head_dim 64 / 128, d a multiple of 256 up to 1024). The position lives in device memory, so the launches of a
+ * token (embed, per layer {self-attention with the q|k|v projections and the pending post-LN fused in, out-projection, cross-attention
+ * with its q projection, out-projection, fc1 + GELU, fc2}, LM heads: 6 n_layers + 2) carry no position-dependent argument; the token ids
+ * go up and the logits row comes down through copy nodes of the same graph.
+ *   pb_decoder_create   0 = created (*dec), 1 = this plan's shape is not covered (keep pb_decode_step), < 0 = error. The plan is copied;
+ *                       its buffers (weights, K/V caches, scratch rows, attn_part) must stay alive until pb_decoder_destroy.
+ *   pb_decoder_reset    start of a prompt: position -1, ordered behind everything enqueued on `caller_stream` so far (encoder pass, cross
+ *                       K/V projections); use_graph = 0 issues every token's launches directly (A/B, debugging).
+ *   pb_decoder_step     one token: tok8 (8 ids, host) in, the (vocab) f32 logits row of its position out (host); returns when it landed.
+ *   pb_decoder_launches kernels per token; pb_decoder_graph 1 when tokens are graph replays. */
+/* Host-side nucleus sampling of one position (model.py:84-98 for the 8 heads): probs (heads, width) f32 softmax rows of lengths n[h],
+ * thresholds p[h], u[h] = the uniform draw np.random.choice would consume. out[h] = sampled id; bit h of *tie_mask set (out[h] = -1)
+ * when the result would depend on numpy's order of equal probabilities: the caller runs its numpy code for that head. No device work. */
+int pb_nucleus_rows(const float* probs, int32_t width, const int32_t* n, const float* p, const double* u, int32_t heads, int32_t* out,
+                    int32_t* tie_mask);
+int pb_decoder_create(const pb_decode_plan* plan, void** dec);
+int pb_decoder_destroy(void* dec);
+int pb_decoder_reset(void* dec, void* caller_stream, int32_t use_graph);
+int pb_decoder_step(void* dec, const int16_t* tok8, float* logits_out);
+int pb_decoder_launches(void* dec);
+int pb_decoder_graph(void* dec);
+
 /* ---- K15: deferred parameter-gradient reductions -----------------------------------------------------------------------
  * The bias / LayerNorm-parameter gradients of one backward pass (the `db = grad.sum(0)` of every nn.Linear and nn.LayerNorm autograd
  * node under BartModel, modeling_bart.py:280-390) leave their kernels as per-workgroup partial rows. Between pb_defer_begin and

@@ -542,3 +542,464 @@ extern "C" int pb_decode_step(const pb_decode_plan* p, int32_t i, void* stream) 
     }
     return gemv_launch(p->head_w, p->a, p->head_b, p->logits, nullptr, p->vocab, p->vocab, d, dt, 1, 0, st, ln);
 }
+
+// =====================================================================================================================
+// Decode, second form (round 3): one token = ONE hipGraph replay of 6 launches per decoder layer (+ embed + heads).
+// What changed against pb_decode_step above:
+//   * the position i lives in DEVICE memory (incremented by the first kernel of a step), so the launches of a step have no
+//     position-dependent argument or grid and one captured graph serves every position: the host's ~3.5 us of enqueue per launch
+//     (host-bound with kernels this short) become one hipGraphLaunch per token; the token ids go up and the logits row comes down
+//     through two copy nodes of the same graph (pinned host buffers owned by the decoder);
+//   * the q projection is fused into the single-query attention (dec_attn_kernel): a (head, key split) workgroup needs q of ITS
+//     head only (hd rows of W_q, 98 KB at cfg 2: re-read by the <= 16 splits of a head from L2), so it applies the pending post-LN
+//     itself, projects q_h, and goes on to its keys -- the q|k|v GEMV launch and its all-to-all seam are gone. For the self-attention
+//     one more workgroup per head projects k_h and v_h of the new token as well, writes them to the cache row and contributes
+//     the new token's own {score, 1, v} record, so the regular splits only read rows that older launches wrote;
+//   * per layer: self-attn(+LN2 of the layer below, q|k|v) -> out-proj (merges the split records) -> cross-attn(+LN1, q_c) ->
+//     out_c (merge) -> fc1 (+LNc, GELU) -> fc2. Every remaining boundary is a real all-to-all seam (each output needs the whole
+//     input vector, produced by all workgroups of the launch before): cdna_hip_programming.md 5.6 prices a grid barrier above a
+//     kernel boundary, so they stay launches.
+// bf16, head_dim 64 or 128, d a multiple of 256 up to 1024; anything else keeps pb_decode_step.
+namespace {
+
+__device__ __forceinline__ float half_sum(float v) {            // sum over the 32 lanes of a half-wave, in every lane of it
+    v += PB_DPP_F(v, 0xb1);
+    v += PB_DPP_F(v, 0x4e);
+    v += PB_DPP_F(v, 0x141);
+    v += PB_DPP_F(v, 0x140);
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+
+struct DecAttnArgs {
+    const bf16_t* x_in;                                          // the input vector (d) when res == NULL
+    const bf16_t* res; const bf16_t* add; const float* gamma; const float* beta; bf16_t* ln_out;   // x' = LN(res + add) gamma + beta
+    const bf16_t* Wq; const float* bq;                           // q projection rows [d][d] (+ bias); head h owns rows h HD ..
+    const bf16_t* Wk; const float* bk; const bf16_t* Wv; const float* bv;      // SELF: the new token's k / v rows
+    bf16_t* kc; bf16_t* vc; long kv_ss;                          // cached rows: kc + j kv_ss + h HD
+    const float* key_mask;                                       // cross: [Sk] (0 = masked) or NULL
+    int* pos; int Sk_fixed;                                      // SELF: keys cached so far = *pos, row *pos is written; cross: Sk_fixed keys
+    int d, nreg, ck_fixed;                                       // regular key splits; cross: keys per split
+    float scale, eps;
+    float* part;                                                 // [H][gridDim.y][HD + 4] records {m, l, -, -, o[HD]}
+};
+
+template <int NC, int HD, bool SELF>
+__global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnArgs a) {
+    constexpr int CPR = HD / 8, KPW = 64 / CPR, STEP = 4 * KPW, UR = 4, RPW = HD / 4, NP = RPW / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);                  // [HD] q of this head, rounded to bf16 like a stored q row, times the softmax scale
+    float* red = qs + HD;                                        // [4 HD] reductions / per-wave partial outputs (new-token workgroup: k | v)
+    float* sc = red + 4 * HD;                                    // [keys per split] scores -> probabilities
+    const int h = blockIdx.x, sp = blockIdx.y, nrec = gridDim.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l32 = lane & 31, half = lane >> 5;
+    const int d = a.d;
+    const int Sk = SELF ? *a.pos : a.Sk_fixed;
+    const bool is_new = SELF && sp == a.nreg;
+    int ck = a.ck_fixed;
+    if (SELF) { ck = (Sk + a.nreg - 1) / a.nreg; ck = ck < 64 ? 64 : (ck + 15) & ~15; }
+    const int j0 = sp * ck, j1 = min(Sk, j0 + ck);
+    float* rec = a.part + ((size_t)h * nrec + sp) * (HD + 4);
+    if (!is_new && j0 >= Sk) {                                   // no key in this split: a record of weight zero
+        if (t == 0) { rec[0] = -INFINITY; rec[1] = 0.f; }
+        if (t < HD) rec[4 + t] = 0.f;
+        return;
+    }
+    // cached rows of the first block of this split: requested before anything else (they do not depend on q)
+    const int sub = lane % CPR, grp = lane / CPR;
+    const int jfirst = j0 + wave * KPW;
+    uint4 kpre[UR], vpre[UR];
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+        const int j = jfirst + r * STEP + grp;
+        kpre[r] = uint4{0u, 0u, 0u, 0u}; vpre[r] = uint4{0u, 0u, 0u, 0u};
+        if (!is_new && j < j1) {
+            kpre[r] = *reinterpret_cast<const uint4*>(a.kc + (long)j * a.kv_ss + h * HD + sub * 8);
+            vpre[r] = *reinterpret_cast<const uint4*>(a.vc + (long)j * a.kv_ss + h * HD + sub * 8);
+        }
+    }
+    // the input vector, whole, in every half-wave: lane l32 holds the 8 elements of chunks l32 + 32 c
+    float xf[NC][8];
+    if (a.res) {
+        bf16x8 rr[NC], aa[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            rr[c] = *reinterpret_cast<const bf16x8*>(a.res + (l32 + 32 * c) * 8);
+            aa[c] = *reinterpret_cast<const bf16x8*>(a.add + (l32 + 32 * c) * 8);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xf[c][j] = (float)rr[c][j] + (float)aa[c][j]; s += xf[c][j]; }
+        const float mean = half_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float z = xf[c][j] - mean; q = fmaf(z, z, q); }
+        const float rstd = rsqrtf(half_sum(q) / (float)d + a.eps);
+        const bool store_ln = h == 0 && wave == 0 && half == 0 && (SELF ? is_new : sp == 0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e0 = (l32 + 32 * c) * 8;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + e0), g1 = *reinterpret_cast<const f32x4*>(a.gamma + e0 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.beta + e0), b1 = *reinterpret_cast<const f32x4*>(a.beta + e0 + 4);
+            bf16x8 xo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                        // rounded to bf16 like the stored LayerNorm output the residual path reads back
+                xo[j] = (bf16_t)((xf[c][j] - mean) * rstd * (j < 4 ? g0[j & 3] : g1[j & 3]) + (j < 4 ? b0[j & 3] : b1[j & 3]));
+                xf[c][j] = (float)xo[j];
+            }
+            if (store_ln) *reinterpret_cast<bf16x8*>(a.ln_out + e0) = xo;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(a.x_in + (l32 + 32 * c) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[c][j] = (float)xv[j];
+        }
+    }
+    // HD rows of a projection: a half-wave per row (2 rows per pass and wave), 4 passes of weight loads in flight
+    auto project = [&](const bf16_t* __restrict__ W, const float* __restrict__ bias, float* out, float mul) {
+#pragma unroll 1
+        for (int pb = 0; pb < NP; pb += 4) {
+            bf16x8 w[4][NC];
+            float bv[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = h * HD + wave * RPW + 2 * (pb + p) + half;
+                bv[p] = bias[row];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) w[p][c] = *reinterpret_cast<const bf16x8*>(W + (size_t)row * d + (l32 + 32 * c) * 8);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc = fmaf((float)w[p][c][j], xf[c][j], acc);
+                acc = half_sum(acc);
+                if (l32 == 0) out[wave * RPW + 2 * (pb + p) + half] = (float)(bf16_t)(acc + bv[p]) * mul;
+            }
+        }
+    };
+    project(a.Wq, a.bq, qs, a.scale);
+    if (is_new) {
+        float* ks = red; float* vs = red + HD;
+        project(a.Wk, a.bk, ks, 1.f);
+        project(a.Wv, a.bv, vs, 1.f);
+        __syncthreads();
+        if (t < HD) {
+            a.kc[(long)Sk * a.kv_ss + h * HD + t] = (bf16_t)ks[t];
+            a.vc[(long)Sk * a.kv_ss + h * HD + t] = (bf16_t)vs[t];
+            rec[4 + t] = vs[t];
+        }
+        if (wave == 0) {
+            float p = 0.f;
+#pragma unroll
+            for (int e = lane; e < HD; e += 64) p = fmaf(qs[e], ks[e], p);
+            p = wave_sum(p);
+            if (lane == 0) { rec[0] = p; rec[1] = 1.f; }
+        }
+        return;
+    }
+    __syncthreads();
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = qs[sub * 8 + e];
+    float mx = -INFINITY;
+    for (int jb = jfirst; jb < j1; jb += UR * STEP) {
+        uint4 kraw[UR];
+#pragma unroll
+        for (int r = 0; r < UR; ++r) {
+            const int j = jb + r * STEP + grp;
+            kraw[r] = kpre[r];
+            if (jb != jfirst) {
+                kraw[r] = uint4{0u, 0u, 0u, 0u};
+                if (j < j1) kraw[r] = *reinterpret_cast<const uint4*>(a.kc + (long)j * a.kv_ss + h * HD + sub * 8);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < UR; ++r) {
+            const int j = jb + r * STEP + grp;
+            float s = 0.f;
+            if (j < j1) {
+                const bf16_t* kv = reinterpret_cast<const bf16_t*>(&kraw[r]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf((float)kv[e], qv[e], s);
+            }
+#pragma unroll
+            for (int o = 1; o < CPR; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (j < j1) {
+                const float sv = (!a.key_mask || a.key_mask[j] != 0.f) ? s : -INFINITY;
+                if (sub == 0) sc[j - j0] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    if (mx != -INFINITY)
+        for (int j = t; j < j1 - j0; j += 256) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (mx != -INFINITY)
+        for (int jb = jfirst; jb < j1; jb += UR * STEP) {
+            uint4 vraw[UR];
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int j = jb + r * STEP + grp;
+                vraw[r] = vpre[r];
+                if (jb != jfirst) {
+                    vraw[r] = uint4{0u, 0u, 0u, 0u};
+                    if (j < j1) vraw[r] = *reinterpret_cast<const uint4*>(a.vc + (long)j * a.kv_ss + h * HD + sub * 8);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < UR; ++r) {
+                const int j = jb + r * STEP + grp;
+                if (j < j1) {
+                    const bf16_t* vv = reinterpret_cast<const bf16_t*>(&vraw[r]);
+                    const float pj = sc[j - j0];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)vv[e], acc[e]);
+                }
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (grp == 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * HD + sub * 8 + e] = acc[e];
+    __syncthreads();
+    if (t == 0) { rec[0] = mx; rec[1] = sum; }
+    if (t < HD) rec[4 + t] = (red[t] + red[HD + t]) + (red[2 * HD + t] + red[3 * HD + t]);
+}
+
+// token embedding + learned position + LayerNorm of ONE decoder token at the position kept in device memory: i = ++*pos
+// (PianoBart.py:60-71 through the projected table, modeling_bart.py positions offset 2; same sums as embed_ln_fwd_kernel)
+struct SegOff9 { int off[9]; };
+__global__ __launch_bounds__(256) void dec_embed_kernel(const int16_t* __restrict__ tok16, const float* __restrict__ P, const SegOff9 so,
+                                                        const float* __restrict__ lin_b, const float* __restrict__ pos_tab,
+                                                        const float* __restrict__ w, const float* __restrict__ b, bf16_t* __restrict__ y,
+                                                        int* __restrict__ pos, int d, float eps) {
+    __shared__ float red1[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, d4 = d >> 2;
+    const int i = *pos + 1;
+    const uint4 raw = *reinterpret_cast<const uint4*>(tok16);
+    int id[8];
+    id[0] = (int)(raw.x & 0xffff); id[1] = (int)(raw.x >> 16); id[2] = (int)(raw.y & 0xffff); id[3] = (int)(raw.y >> 16);
+    id[4] = (int)(raw.z & 0xffff); id[5] = (int)(raw.z >> 16); id[6] = (int)(raw.w & 0xffff); id[7] = (int)(raw.w >> 16);
+    const bool in = t < d4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (in) {
+        v = load4(lin_b + 4 * t) + load4(pos_tab + (size_t)(i + 2) * d + 4 * t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += load4(P + (size_t)(so.off[k] + id[k]) * d + 4 * t);
+    }
+    const float mean = block_sum4(in ? v[0] + v[1] + v[2] + v[3] : 0.f, red1, lane, wave) / (float)d;
+    float q = 0.f;
+    if (in) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float c = v[j] - mean; q += c * c; }
+    }
+    const float rstd = rsqrtf(block_sum4(q, red1, lane, wave) / (float)d + eps);
+    if (in) store4(y + 4 * t, (v - mean) * rstd * load4(w + 4 * t) + load4(b + 4 * t));
+    if (t == 0) *pos = i;                                        // every thread has read *pos (two barriers ago); later launches see i
+}
+
+struct Decoder {
+    pb_decode_plan plan;
+    hipStream_t stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int* pos = nullptr;                    // device: position of the token being decoded
+    int16_t* tok_dev = nullptr;            // device copy of the current token (8 ids)
+    int16_t* tok_host = nullptr;           // pinned
+    float* logits_host = nullptr;          // pinned
+    hipEvent_t ev = nullptr;
+    int launches = 0, use_graph = 1, ck_cross = 0, nsplit_cross = 0;
+    size_t lds_attn = 0;
+};
+
+template <int NC, int HD>
+static void dec_attn_go(const DecAttnArgs& a, bool self, int H, int nrec, size_t lds, hipStream_t st) {
+    if (self) hipLaunchKernelGGL((dec_attn_kernel<NC, HD, true>), dim3(H, nrec), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<NC, HD, false>), dim3(H, nrec), dim3(256), lds, st, a);
+}
+static int dec_attn_launch(const DecAttnArgs& a, bool self, int H, int hd, int nrec, size_t lds, hipStream_t st) {
+    const int nc = a.d / 256;
+#define PB_DA(NC_) do { if (hd == 64) dec_attn_go<NC_, 64>(a, self, H, nrec, lds, st); else dec_attn_go<NC_, 128>(a, self, H, nrec, lds, st); } while (0)
+    if (nc == 1) PB_DA(1); else if (nc == 2) PB_DA(2); else if (nc == 3) PB_DA(3); else PB_DA(4);
+#undef PB_DA
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+
+// the launches of one token on `st` (captured once, or issued directly when capture is unavailable); returns their number in *count
+static int decoder_issue(Decoder* D, hipStream_t st, int* count) {
+    const pb_decode_plan* p = &D->plan;
+    const int d = p->d, H = p->H, hd = d / H, f = p->ffn, dt = p->dtype;
+    const float scale = 1.0f / sqrtf((float)hd);
+    int n = 0;
+    SegOff9 so;
+    for (int k = 0; k < 9; ++k) so.off[k] = p->tab_off[k];
+    hipLaunchKernelGGL(dec_embed_kernel, dim3(1), dim3(256), 0, st, D->tok_dev, p->ptab, so, p->lin_b, p->pos, p->lne_w, p->lne_b, (bf16_t*)p->x, D->pos, d, 1e-5f);
+    PB_LAUNCH_CHECK(); ++n;
+    char* x = (char*)p->x; char* alt = (char*)p->y2;
+    char* h = x;
+    LnIn ln{nullptr, nullptr, nullptr, nullptr};
+    const MergeIn mg{p->attn_part, PB_DECODE_MAX_SPLITS, hd, hd + 4};
+    for (int l = 0; l < p->n_layers; ++l) {
+        const pb_decode_layer& L = p->layers[l];
+        DecAttnArgs a{};
+        a.d = d; a.scale = scale; a.eps = 1e-5f; a.part = p->attn_part; a.pos = D->pos; a.kv_ss = 2 * d;
+        // self-attention: LN2 of the layer below (or the embedding row), q|k|v of this token, keys 0 .. i
+        a.x_in = (const bf16_t*)h; a.res = (const bf16_t*)ln.res; a.add = (const bf16_t*)p->a; a.gamma = ln.gamma; a.beta = ln.beta; a.ln_out = (bf16_t*)ln.out;
+        a.Wq = (const bf16_t*)L.wqkv; a.bq = L.bqkv;
+        a.Wk = a.Wq + (size_t)d * d; a.bk = L.bqkv + d; a.Wv = a.Wq + (size_t)2 * d * d; a.bv = L.bqkv + 2 * d;
+        a.kc = (bf16_t*)L.kv_self; a.vc = a.kc + d; a.key_mask = nullptr; a.nreg = PB_DECODE_MAX_SPLITS - 1; a.ck_fixed = 0; a.Sk_fixed = 0;
+        if (dec_attn_launch(a, true, H, hd, PB_DECODE_MAX_SPLITS, D->lds_attn, st)) return -1;
+        ++n;
+        if (ln.res) h = alt;
+        if (gemv_launch(L.wo, p->ctx, L.bo, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, mg)) return -1;
+        ++n;
+        // cross-attention: LN1(h + a) -> y1, q_c, the cached encoder keys
+        DecAttnArgs c{};
+        c.d = d; c.scale = scale; c.eps = 1e-5f; c.part = p->attn_part; c.pos = D->pos; c.kv_ss = 2 * d;
+        c.x_in = nullptr; c.res = (const bf16_t*)h; c.add = (const bf16_t*)p->a; c.gamma = L.ln1_w; c.beta = L.ln1_b; c.ln_out = (bf16_t*)p->y1;
+        c.Wq = (const bf16_t*)L.wq_c; c.bq = L.bq_c;
+        c.kc = (bf16_t*)const_cast<void*>(L.kv_cross); c.vc = c.kc + d; c.key_mask = p->enc_mask; c.nreg = D->nsplit_cross; c.ck_fixed = D->ck_cross; c.Sk_fixed = p->S_enc;
+        if (dec_attn_launch(c, false, H, hd, PB_DECODE_MAX_SPLITS, D->lds_attn, st)) return -1;
+        ++n;
+        if (gemv_launch(L.wo_c, p->ctx, L.bo_c, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, mg)) return -1;
+        ++n;
+        // FFN: fc1 applies LNc(y1 + a) -> yc
+        if (gemv_launch(L.w1, p->a, L.b1, p->g, nullptr, f, f, d, dt, 0, 1, st, LnIn{p->y1, L.lnc_w, L.lnc_b, p->yc})) return -1;
+        ++n;
+        if (gemv_launch(L.w2, p->g, L.b2, p->a, nullptr, d, d, f, dt, 0, 0, st)) return -1;
+        ++n;
+        ln = LnIn{p->yc, L.ln2_w, L.ln2_b, alt};
+    }
+    if (gemv_launch(p->head_w, p->a, p->head_b, p->logits, nullptr, p->vocab, p->vocab, d, dt, 1, 0, st, ln)) return -1;
+    ++n;
+    *count = n;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pb_decoder_create(const pb_decode_plan* plan, void** out) {
+    PB_REQUIRE(plan && out, "pb_decoder_create: null argument");
+    *out = nullptr;
+    const int d = plan->d, H = plan->H, hd = H > 0 ? d / H : 0;
+    // shapes the fused kernels cover; anything else keeps pb_decode_step (return 1 = declined, not an error)
+    if (plan->dtype != PB_BF16 || H <= 0 || d % H != 0 || (hd != 64 && hd != 128) || d % 256 != 0 || d > 1024 || !plan->attn_part ||
+        plan->n_layers <= 0 || plan->n_layers > PB_DECODE_MAX_LAYERS || plan->ffn % 8 != 0 || plan->ffn > 8192 || plan->S_enc <= 0) return 1;
+    Decoder* D = new Decoder();
+    D->plan = *plan;
+    if (hipStreamCreateWithFlags(&D->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&D->ev, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc(&D->pos, 64) != hipSuccess || hipMalloc(&D->tok_dev, 64) != hipSuccess ||
+        hipHostMalloc(&D->tok_host, 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&D->logits_host, sizeof(float) * (size_t)plan->vocab, hipHostMallocDefault) != hipSuccess) {
+        pb_set_error("pb_decoder_create: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        pb_decoder_destroy(D);
+        return -1;
+    }
+    // cross-attention: <= 16 splits of >= 64 keys over the visible encoder positions (fixed for the prompt)
+    int ck = (plan->S_enc + PB_DECODE_MAX_SPLITS - 1) / PB_DECODE_MAX_SPLITS;
+    ck = ck < 64 ? 64 : (ck + 15) & ~15;
+    D->ck_cross = ck; D->nsplit_cross = PB_DECODE_MAX_SPLITS;
+    int ck_self = (plan->S + PB_DECODE_MAX_SPLITS - 2) / (PB_DECODE_MAX_SPLITS - 1);
+    ck_self = ck_self < 64 ? 64 : (ck_self + 15) & ~15;
+    D->lds_attn = sizeof(float) * (size_t)(5 * hd + (ck > ck_self ? ck : ck_self) + 16);
+    *out = D;
+    return 0;
+}
+
+extern "C" int pb_decoder_destroy(void* dec) {
+    Decoder* D = (Decoder*)dec;
+    if (!D) return 0;
+    if (D->stream) (void)hipStreamSynchronize(D->stream);
+    if (D->exec) (void)hipGraphExecDestroy(D->exec);
+    if (D->graph) (void)hipGraphDestroy(D->graph);
+    if (D->ev) (void)hipEventDestroy(D->ev);
+    if (D->pos) (void)hipFree(D->pos);
+    if (D->tok_dev) (void)hipFree(D->tok_dev);
+    if (D->tok_host) (void)hipHostFree(D->tok_host);
+    if (D->logits_host) (void)hipHostFree(D->logits_host);
+    if (D->stream) (void)hipStreamDestroy(D->stream);
+    delete D;
+    return 0;
+}
+
+// Start of a prompt: the decoder's stream waits for everything already enqueued on the caller's stream (encoder pass, cross K/V
+// projections), the position counter goes to -1. use_graph = 0 issues the launches of every token directly (A/B, debugging).
+extern "C" int pb_decoder_reset(void* dec, void* caller_stream, int32_t use_graph) {
+    Decoder* D = (Decoder*)dec;
+    PB_REQUIRE(D, "pb_decoder_reset: null decoder");
+    PB_CHECK_HIP(hipEventRecord(D->ev, (hipStream_t)caller_stream));
+    PB_CHECK_HIP(hipStreamWaitEvent(D->stream, D->ev, 0));
+    PB_CHECK_HIP(hipMemsetAsync(D->pos, 0xff, 4, D->stream));           // -1
+    D->use_graph = use_graph;
+    if (use_graph && !D->exec) {
+        PB_CHECK_HIP(hipStreamSynchronize(D->stream));
+        int n = 0;
+        hipError_t e = hipStreamBeginCapture(D->stream, hipStreamCaptureModeRelaxed);
+        if (e == hipSuccess) {
+            int rc = 0;
+            if (hipMemcpyAsync(D->tok_dev, D->tok_host, 16, hipMemcpyHostToDevice, D->stream) != hipSuccess) rc = -1;
+            if (!rc) rc = decoder_issue(D, D->stream, &n);
+            if (!rc && hipMemcpyAsync(D->logits_host, D->plan.logits, sizeof(float) * (size_t)D->plan.vocab, hipMemcpyDeviceToHost, D->stream) != hipSuccess) rc = -1;
+            e = hipStreamEndCapture(D->stream, &D->graph);
+            if (rc || e != hipSuccess || !D->graph || hipGraphInstantiate(&D->exec, D->graph, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (D->graph) { (void)hipGraphDestroy(D->graph); D->graph = nullptr; }
+                D->exec = nullptr;
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+        if (!D->exec) D->use_graph = 0;                                  // capture unavailable: direct launches
+        else D->launches = n;
+    }
+    return 0;
+}
+
+// One token: tok8 (the decoder input of this position, 8 ids) goes up, the (vocab) f32 logits row of the position comes back into
+// logits_out (host memory). Blocks until the row has landed.
+extern "C" int pb_decoder_step(void* dec, const int16_t* tok8, float* logits_out) {
+    Decoder* D = (Decoder*)dec;
+    PB_REQUIRE(D && tok8 && logits_out, "pb_decoder_step: null argument");
+    for (int k = 0; k < 8; ++k) D->tok_host[k] = tok8[k];
+    if (D->use_graph && D->exec) {
+        PB_CHECK_HIP(hipGraphLaunch(D->exec, D->stream));
+    } else {
+        PB_CHECK_HIP(hipMemcpyAsync(D->tok_dev, D->tok_host, 16, hipMemcpyHostToDevice, D->stream));
+        int n = 0;
+        if (decoder_issue(D, D->stream, &n)) return -1;
+        D->launches = n;
+        PB_CHECK_HIP(hipMemcpyAsync(D->logits_host, D->plan.logits, sizeof(float) * (size_t)D->plan.vocab, hipMemcpyDeviceToHost, D->stream));
+    }
+    PB_CHECK_HIP(hipStreamSynchronize(D->stream));
+    for (int k = 0; k < D->plan.vocab; ++k) logits_out[k] = D->logits_host[k];
+    return 0;
+}
+
+extern "C" int pb_decoder_launches(void* dec) { return dec ? ((Decoder*)dec)->launches : 0; }
+extern "C" int pb_decoder_graph(void* dec) { return dec ? (((Decoder*)dec)->use_graph && ((Decoder*)dec)->exec ? 1 : 0) : 0; }

@@ -25,6 +25,7 @@ _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second 
 _WG_TARGET = int(os.environ.get('PB_WG_TARGET', '192' if _WGRAD_STREAM & 1 else '256'))            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
 _NO_DEFER = bool(int(os.environ.get('PB_NO_DEFER', '0')))                  # developer aid: reduce every bias / LayerNorm gradient right behind its producer (A/B)
 _DECODE_SPLIT = bool(int(os.environ.get('PB_DECODE_SPLIT', '1')))              # developer aid: 0 = single-query attention with one workgroup per head (A/B)
+_DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token, 0 = the same fused launches issued directly, -1 = the round-2 per-launch loop
 _NO_FUSED_BIAS = bool(int(os.environ.get('PB_NO_FUSED_BIAS', '0')))     # developer aid: A/B the bias gradients fused into the GEMM / attention epilogues
 
 LN_EPS = 1e-5
@@ -1117,7 +1118,10 @@ class Engine:
                 setattr(plan, n, P(t))
             plan.stat, plan.logits, plan.head_w, plan.head_b = P(stat), P(logits), P(self.w['head.w']), P(wf['head.b'])
             attn_part = torch.empty(self.H * 16 * (self.hd + 4), dtype=torch.float32, device=dev)      # PB_DECODE_MAX_SPLITS records per head
-            plan.attn_part = P(attn_part) if _DECODE_SPLIT else None
+            # the split records are merged in the out-projection GEMV's prologue, which holds K = d in one chunk per thread (256 threads x
+            # 16 bytes): wider models keep the one-workgroup-per-head attention
+            epv = 8 if self.code == PB_BF16 else 4
+            plan.attn_part = P(attn_part) if (_DECODE_SPLIT and d <= 256 * epv) else None
             for l in range(self.ND):
                 pf, L = 'dec.%d.' % l, plan.layers[l]
                 L.wqkv, L.bqkv, L.wo, L.bo = P(self.w[pf + 'wqkv']), P(wf[pf + 'bqkv']), P(self.w[pf + 'wo']), P(wf[pf + 'bo'])
@@ -1129,9 +1133,34 @@ class Engine:
                 L.kv_self, L.kv_cross = P(kvs[l]), P(kvc[l])
             pref = ctypes.byref(plan)
             stream = ops._stream()
+            res_cpu = pad_cpu.repeat(S, 1)
+            # One hipGraph replay per token where the fused decode kernels cover the shape (bf16, head_dim 64 / 128, d a multiple of
+            # 256 up to 1024): pb_decoder_* keeps the position in device memory; PB_DECODE_GRAPH=0 issues the same launches directly,
+            # PB_DECODE_GRAPH=-1 keeps the round-2 loop below (A/B)
+            dec = ctypes.c_void_p()
+            self.last_decode = None
+            if _DECODE_GRAPH >= 0 and _DECODE_SPLIT and int(LIB.query('pb_decoder_create', pref, ctypes.byref(dec))) == 0:
+                try:
+                    LIB.call('pb_decoder_reset', dec, ctypes.c_void_p(stream), _DECODE_GRAPH)
+                    tok_np = np.asarray(pb.sos_word_np, dtype=np.int16).copy()
+                    logit_cpu = torch.empty(ops.VOCAB, dtype=torch.float32)
+                    tok_p, log_p = ctypes.c_void_p(tok_np.ctypes.data), ctypes.c_void_p(logit_cpu.data_ptr())
+                    n = 0
+                    for i in range(S):
+                        LIB.call('pb_decoder_step', dec, tok_p, log_p)
+                        n += 1
+                        tok = sample_row(logit_cpu)
+                        if (tok >= pad_cpu).any():
+                            break
+                        res_cpu[i] = tok
+                        tok_np[:] = tok.numpy()
+                    self.last_decode = dict(launches_per_token=int(LIB.query('pb_decoder_launches', dec)), graph=bool(LIB.query('pb_decoder_graph', dec)),
+                                            tokens=n)
+                finally:
+                    LIB.call('pb_decoder_destroy', dec)
+                return res_cpu.to(dev).unsqueeze(0)
             tok_pin = torch.empty(8, dtype=torch.int16).pin_memory()         # one small H2D per position; the result goes up once at the end
             logit_pin = torch.empty(ops.VOCAB, dtype=torch.float32).pin_memory()
-            res_cpu = pad_cpu.repeat(S, 1)
             for i in range(S):
                 LIB.call('pb_decode_step', pref, i, stream)
                 logit_pin.copy_(logits[0])                                  # D2H on the current stream, returns when the row has landed

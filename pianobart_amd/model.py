@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import PBError
+from ._lib import LIB, PBError
 
 CLASSES = ['Bar', 'Position', 'Instrument', 'Pitch', 'Duration', 'Velocity', 'TimeSig', 'Tempo']
 
@@ -248,6 +248,37 @@ def nucleus(probs, p):
     return word
 
 
+_SAMPLE_TAB = {}
+
+
+def _sample_tables():
+    """Constants of PianoBartLM.sample_row: per-element temperatures, the (8, 272) gather index (1280 = the appended -inf)."""
+    if not _SAMPLE_TAB:
+        n = [ops.SEG_OFF[j + 1] - ops.SEG_OFF[j] for j in range(8)]
+        width = (max(n) + 15) // 16 * 16                                    # whole vectors for 8- and 16-lane CPUs
+        idx = torch.full((8, width), ops.VOCAB, dtype=torch.long)
+        for j in range(8):
+            idx[j, :n[j]] = torch.arange(ops.SEG_OFF[j], ops.SEG_OFF[j + 1])
+        n_a, p_a = np.asarray(n, dtype=np.int32), np.asarray(PianoBartLM.SAMPLE_P, dtype=np.float32)
+        _SAMPLE_TAB.update(n_a=n_a, p_a=p_a, n_p=n_a.ctypes.data, p_p=p_a.ctypes.data, out=np.zeros(8, dtype=np.int32), tie=np.zeros(1, dtype=np.int32))
+        _SAMPLE_TAB.update(n=n, idx=idx, ninf=torch.tensor([float('-inf')]),
+                           tvec=torch.cat([torch.full((n[j],), float(PianoBartLM.SAMPLE_T[j]), dtype=torch.float32) for j in range(8)]))
+    return _SAMPLE_TAB
+
+
+def _nucleus_with_draw(probs, p, u):
+    """_nucleus_fast with the uniform draw handed in (PianoBartLM.sample_row draws the 8 of a position at once)."""
+    probs = probs / (np.cumsum(probs)[-1] + 1e-5)
+    order = np.argsort(probs)[::-1]
+    after = np.cumsum(probs[order]) > p
+    cand = order[:int(np.argmax(after)) + 1] if after.any() else order[0:1]
+    q = probs[cand]
+    q = q / np.cumsum(q)[-1]
+    cdf = q.astype(np.float64).cumsum()
+    cdf /= cdf[-1]
+    return int(cand[int(cdf.searchsorted(u, side='right'))])
+
+
 def _nucleus_fast(probs, p):
     """The same draw as nucleus() for the same probs / global np.random state, without its Python-level loops: builtin sum() over a
     float32 array is a left-to-right float32 accumulation = np.cumsum(..)[-1]; np.random.choice(c, size=1, p=q) is, in RandomState,
@@ -310,13 +341,25 @@ class PianoBartLM(nn.Module):
     SAMPLE_P = [1, 1, 1, 0.9, 0.9, 1, 1, 0.9]
 
     def sample_row(self, row_logits):
-        """row_logits: (1280,) f32 tensor of one position; returns the 8 sampled ids (model.py:68-78)."""
-        out = []
-        for j in range(8):
-            y = row_logits[ops.SEG_OFF[j]:ops.SEG_OFF[j + 1]]
-            probs = torch.softmax(y / self.SAMPLE_T[j], dim=-1).numpy()              # sampling()'s own two tensor ops, on the host row
-            out.append(_nucleus_fast(probs, self.SAMPLE_P[j]))
-        return torch.tensor(out)
+        """row_logits: (1280,) f32 CPU tensor of one position; returns the 8 sampled ids (model.py:68-78). sampling()'s two tensor ops
+        (divide by the temperature, softmax) run once for all 8 heads: the row divided by a per-element temperature vector, gathered
+        into an (8, 272) matrix whose padding is -inf (exp -> exact zeros in lanes that the shorter rows' own vector tail leaves
+        empty), one softmax over the last axis -- the same elementwise quotients, maxima, exponentials and lane-wise sums as the
+        eight separate calls (checked bit for bit and draw for draw in tests/test_model_cpu.py). 0.31 -> 0.09 ms of host time per
+        generated position, which sits in series with the GPU's ~0.3 ms."""
+        tab = _sample_tables()
+        y = torch.cat([row_logits / tab['tvec'], tab['ninf']])
+        probs = torch.softmax(y[tab['idx']], dim=-1)
+        # the 8 draws np.random.choice would make, in head order (RandomState fills a request sequentially: the same stream as 8 calls)
+        u = np.random.random_sample(8)
+        out, tie = tab['out'], tab['tie']
+        LIB.call('pb_nucleus_rows', probs.data_ptr(), probs.shape[1], tab['n_p'], tab['p_p'], u.ctypes.data, 8, out.ctypes.data, tie.ctypes.data)
+        if tie[0]:                                                   # equal probabilities among a head's candidates: numpy's own order decides
+            pn = probs.numpy()
+            for j in range(8):
+                if tie[0] >> j & 1:
+                    out[j] = _nucleus_with_draw(pn[j, :tab['n'][j]], self.SAMPLE_P[j], u[j])
+        return torch.from_numpy(out.astype(np.int64))
 
     def sample(self, x, index):
         t, p = self.SAMPLE_T, self.SAMPLE_P

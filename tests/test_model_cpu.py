@@ -108,7 +108,7 @@ def test_fast_host_sampler_reproduces_sampling_draw_for_draw():
     from pianobart_amd.model import PianoBartLM, sampling
     rng = np.random.default_rng(5)
     n_multi = 0
-    for trial in range(400):
+    for trial in range(1200):
         scale = [0.05, 1.0, 4.0, 12.0][trial % 4]
         row = rng.normal(scale=scale, size=ops.VOCAB).astype(np.float32)
         if trial % 7 == 0:

@@ -450,3 +450,51 @@ def test_decode_at_cfg2_size_matches_teacher_forced_full_pass(precision, tol):
         a = torch.stack([torch.stack([r[offs[k]:offs[k + 1]].argmax() for k in range(8)]) for r in rows])
         b = torch.stack([torch.stack([full[i][offs[k]:offs[k + 1]].argmax() for k in range(8)]) for i in range(N + 1)])
         assert float((a == b).float().mean()) > 0.995
+
+
+@pytest.mark.parametrize('d,heads,S', [(256, 4, 200), (256, 2, 96), (512, 8, 72)])
+def test_graph_decode_equals_the_per_launch_decode(monkeypatch, d, heads, S):
+    """Round 3: one hipGraph replay per token (position in device memory, q / k / v projections fused into the split single-query
+    attention, 6 launches per layer) against (a) the same launches issued directly: bit-identical logits rows, and (b) the round-2
+    per-launch loop (pb_decode_step): the same tokens fed, logits equal to bf16 rounding. head_dim 64 and 128; S = 200 takes the
+    self-attention through several key splits (65+ keys) and the cross-attention through 4."""
+    _need_gpu()
+    from pianobart_amd import engine as E
+    m = _lm(S, d, 2, 512, heads, 31, 'bf16').eval()
+    with torch.no_grad():
+        for i, p0 in enumerate([256, 128, 129, 256, 128, 32, 254, 49]):
+            m.mask_lm.proj[i].bias[p0:] = -30.0
+    m = m.cuda()
+    enc = synth_octuple_batch(1, S, seed=8, min_len=S - 9)[5].cuda()
+    emask = (enc[:, :, 0] != 256).float()
+    forced = synth_octuple_batch(1, S, seed=23, min_len=S)[5][0]
+    forced[-1] = forced[-2]
+    eng = m._get_engine()
+
+    def run(mode):
+        monkeypatch.setattr(E, '_DECODE_GRAPH', mode)
+        rows = []
+
+        def feed(row):
+            rows.append(row.clone())
+            return forced[len(rows) - 1].clone()
+        out = eng.generate(enc, emask, feed)
+        assert torch.equal(out[0].cpu(), forced)
+        return rows, eng.last_decode
+
+    g, info_g = run(1)
+    dr, info_d = run(0)
+    old, info_o = run(-1)
+    assert info_g is not None and info_g['launches_per_token'] == 6 * 2 + 2 and info_g['tokens'] == S, info_g
+    assert info_g['graph'] and not info_d['graph'] and info_o is None
+    assert len(g) == len(dr) == len(old) == S
+    worst = 0.0
+    for i in range(S):
+        assert torch.equal(g[i], dr[i]), i                         # a replay runs exactly the launches of the direct form
+        keep = old[i] > -20
+        worst = max(worst, _rel(g[i][keep], old[i][keep]))
+    print('graph decode vs per-launch decode d=%d hd=%d S=%d: worst logits rel %.2e' % (d, d // heads, S, worst))
+    assert worst < 2e-2
+    # a second prompt through a fresh decoder of the same engine: nothing is left over from the first
+    g2, _ = run(1)
+    assert all(torch.equal(a, b) for a, b in zip(g, g2))

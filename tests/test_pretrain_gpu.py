@@ -159,3 +159,45 @@ def test_mmap_int16_shard_feeds_the_same_batch_as_the_int64_path(tmp_path):
     for a, b in zip(got, want):
         assert a.dtype == b.dtype and torch.equal(a, b)
     assert torch.equal(got[2].cpu().long(), torch.from_numpy(seqs))              # targets = the sequences themselves
+
+
+def test_demo_midi_in_generate_midi_out(tmp_path):
+    """demo.py:105-170 end to end on the device: .mid -> Midi2Octuple -> checkpoint loaded with strict=False -> model(generate=True)
+    -> Octuple2Midi -> .mid. 2-layer shape, window 32: the checkpoint's head biases make the special ids unsamplable, so all 32
+    positions are generated (a random-init model would stop at once); the written file reads back as the generated rows."""
+    from pianobart_amd import demo as D, octuple_midi as om
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab, randomize_params
+    e2w, w2e = load_vocab()
+    S = 32
+    song = om.Song(480, [(120 * i, 120 * i + 200, 48 + (7 * i) % 24, 64 + i % 32, 0, False) for i in range(20)], [(0, 4, 4)], [(0, 120.0)])
+    src = str(tmp_path / 'in.mid')
+    om.write_midi(song, src)
+    kw = dict(max_position_embeddings=S, d_model=128, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=256, decoder_ffn_dim=256,
+              encoder_attention_heads=2, decoder_attention_heads=2)
+    m = PianoBartLM(PianoBart(BartConfig(**kw), e2w, w2e))
+    randomize_params(m, 5)
+    with torch.no_grad():
+        for i, p0 in enumerate([256, 128, 129, 256, 128, 32, 254, 49]):
+            m.mask_lm.proj[i].bias[p0:] = -30.0
+        m.mask_lm.proj[2].bias[1:] = -30.0                               # piano only (program 0): the written notes share one track
+        m.mask_lm.proj[3].bias[128:] = -30.0                             # melodic pitches
+    ckpt = str(tmp_path / 'lm.ckpt')
+    torch.save({'state_dict': m.state_dict()}, ckpt)
+    out = str(tmp_path / 'out.mid')
+    np.random.seed(2023)
+    args = D.Args(ckpt=ckpt, input=src, output=out, max_seq_len=S, hs=128, layers=2, ffn_dims=256, heads=2)
+    x, y = D.demo(args)
+    assert tuple(x.shape) == (1, S, 8) and tuple(y.shape) == (1, S, 8) and y.is_cuda and y.dtype == torch.int64
+    assert [tuple(r) for r in x[0, :20, :4].tolist()] == [r[:4] for r in om.midi_to_encoding(song)]
+    rows = om.octuple_to_rows(y.cpu().numpy())
+    assert len(rows) == S                                                 # every position was generated
+    back = om.read_midi(out)
+    assert len(back.notes) == len(om.encoding_to_midi(rows).notes) > 0
+    # the same call through the command-line surface, without a checkpoint: nothing but the flags differs
+    a2 = D.get_args(['--nopretrain', '--input', src, '--output', str(tmp_path / 'o2.mid'), '--max_seq_len', str(S), '--hs', '128', '--layers', '2',
+                     '--ffn_dims', '256', '--heads', '2'])
+    x2, y2 = D.demo(a2)
+    assert torch.equal(x2, x) and tuple(y2.shape) == (1, S, 8)
+    with pytest.raises(Exception):
+        D.demo(D.Args(cpu=True, nopretrain=True, input=src))
