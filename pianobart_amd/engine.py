@@ -13,6 +13,7 @@ Reference semantics followed (file:line into /root/reference; tf: = transformers
 """
 import math
 import os
+import time
 
 import numpy as np
 import torch
@@ -1146,6 +1147,8 @@ class Engine:
                     logit_cpu = torch.empty(ops.VOCAB, dtype=torch.float32)
                     tok_p, log_p = ctypes.c_void_p(tok_np.ctypes.data), ctypes.c_void_p(logit_cpu.data_ptr())
                     n = 0
+                    torch.cuda.current_stream().synchronize()           # the prompt's encoder pass: not part of the per-token time below
+                    t_loop = time.perf_counter()
                     for i in range(S):
                         LIB.call('pb_decoder_step', dec, tok_p, log_p)
                         n += 1
@@ -1155,7 +1158,7 @@ class Engine:
                         res_cpu[i] = tok
                         tok_np[:] = tok.numpy()
                     self.last_decode = dict(launches_per_token=int(LIB.query('pb_decoder_launches', dec)), graph=bool(LIB.query('pb_decoder_graph', dec)),
-                                            tokens=n)
+                                            tokens=n, loop_ms=(time.perf_counter() - t_loop) * 1e3, s_enc=s_enc)
                 finally:
                     LIB.call('pb_decoder_destroy', dec)
                 return res_cpu.to(dev).unsqueeze(0)
