@@ -402,7 +402,15 @@ def main():
     reducer = GradReducer(eng, world) if (world > 1 or args.force_reducer) else None
     eng.pipeline_updates = not os.environ.get('PB_NO_PIPELINE_UPDATES')     # the parameter update runs beside the next step's forward (Engine.optimizer_step)
 
+    prefetch = not os.environ.get('PB_NO_PACK_PREFETCH')
+    if prefetch:
+        eng.prefetch_pack(loss_mask, emask, dmask)                  # the first step's own request
+
     def step():
+        # the data pipeline knows the next batch while this one is being enqueued (here: the same resident tensors): its row counts are
+        # requested now, so the next step's packing plan does not wait for this step to drain (Engine.prefetch_pack)
+        if prefetch:
+            eng.prefetch_pack(loss_mask, emask, dmask)              # for the step AFTER this one (this one's request went out a step ago)
         sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=True,
                                   count_hook=reducer.reduce_counts if reducer else None)
         if reducer:

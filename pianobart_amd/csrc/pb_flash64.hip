@@ -220,6 +220,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args pin) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
     block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b);
+    if (pin.causal) rb = (pin.Sq + 127) / 128 - 1 - rb;        // causal: a later row block visits more keys -- the long blocks of a (batch, head) are dispatched first
     const int q0 = rb * 128;
     Fa64Args p = pin;
     varlen_localize(p, b);
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args pin) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
     block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b);
+    if (pin.causal) rb = (pin.Sq + 127) / 128 - 1 - rb;        // causal: a later row block visits more keys -- the long blocks of a (batch, head) are dispatched first
     const int q0 = rb * 128;
     Fa64Args p = pin;
     varlen_localize(p, b);

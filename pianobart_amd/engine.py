@@ -109,6 +109,7 @@ class Engine:
         self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 96, 128))
         self._slabs = None
         self._pack_state = None
+        self._pack_prefetch, self._pack_pf_state = [], None     # rowpack.prefetch_counts: requests in flight (oldest first)
         self._ev_pool = None
         self._slabs_oh = [None, None]
         self.pipeline_updates = False       # optimizer_step may leave the parameter update running on the second stream (see there)
@@ -1007,6 +1008,11 @@ class Engine:
     def _pack_batch(self, enc16, dec16, tgt16, loss_mask, emask, dmask):
         return rowpack.pack_batch(self, enc16, dec16, tgt16, loss_mask, emask, dmask)
 
+    def prefetch_pack(self, loss_mask, emask, dmask, stream=None):
+        """Optional pipeline hint: the batch with these masks is the NEXT one handed to loss_and_grads (rowpack.prefetch_counts)."""
+        if _PACK_ROWS:
+            rowpack.prefetch_counts(self, loss_mask, emask, dmask, stream)
+
     def optimizer_step(self, lr=2e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=3.0, gscale=1.0):
         """clip_grad_norm_(3.0) + HF AdamW on the flat buffers, refreshing the bf16 shadow (pretrain.py:195-196)."""
         if self.opt_m is None:
@@ -1142,7 +1148,7 @@ class Engine:
             self.last_decode = None
             if _DECODE_GRAPH >= 0 and _DECODE_SPLIT and int(LIB.query('pb_decoder_create', pref, ctypes.byref(dec))) == 0:
                 try:
-                    LIB.call('pb_decoder_reset', dec, ctypes.c_void_p(stream), _DECODE_GRAPH)
+                    LIB.call('pb_decoder_reset', dec, stream, _DECODE_GRAPH)
                     tok_np = np.asarray(pb.sos_word_np, dtype=np.int16).copy()
                     logit_cpu = torch.empty(ops.VOCAB, dtype=torch.float32)
                     tok_p, log_p = ctypes.c_void_p(tok_np.ctypes.data), ctypes.c_void_p(logit_cpu.data_ptr())

@@ -39,6 +39,40 @@ class RowPack:
 
 
 
+def _mask_key(loss_mask, emask, dmask):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (loss_mask, emask, dmask))
+
+
+def prefetch_counts(eng, loss_mask, emask, dmask, stream=None):
+    """Ask for the per-sequence row counts of a batch the caller will hand to Engine.loss_and_grads NEXT, so that pack_batch finds them on
+    the host instead of draining the step's stream for them (one kernel over the masks + a 1 KiB copy). `stream`: a stream on which the
+    three mask tensors are ready (e.g. the one that produced them); default = a private stream that waits for everything the current
+    stream has been given so far. The tensors must not be modified between this call and the step (checked by their version counters:
+    a mismatch just falls back to the synchronous path)."""
+    B, S = emask.shape[:2]
+    if not (eng.use_flash and eng.hd in (64, 96, 128) and eng.code == PB_BF16 and (B * S) % PACK_TILE == 0 and eng.mlm is not None):
+        return
+    pf = eng._pack_pf_state
+    if pf is None or pf['shape'] != (B, S):
+        pf = eng._pack_pf_state = dict(shape=(B, S), stream=torch.cuda.Stream(device=eng.device), turn=0,
+                                       counts=[torch.empty(B, 8, dtype=torch.int32, device=eng.device) for _ in range(2)],
+                                       counts_h=[torch.empty(B, 8, dtype=torch.int32).pin_memory() for _ in range(2)])
+        eng._pack_prefetch.clear()
+    if len(eng._pack_prefetch) >= 2:                     # two requests in flight at most (two buffers): the older one is dropped
+        eng._pack_prefetch.pop(0)
+    k = pf['turn'] = pf['turn'] ^ 1
+    st = stream
+    if st is None:
+        st = pf['stream']
+        st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ops.rowmap_count(emask, dmask, loss_mask.reshape(B, S, 8), pf['counts'][k])
+        pf['counts_h'][k].copy_(pf['counts'][k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(st)
+    eng._pack_prefetch.append(dict(key=_mask_key(loss_mask, emask, dmask), event=ev, counts_h=pf['counts_h'][k]))
+
+
 def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
     """Dead-row compaction of one batch (csrc/pb_rowmap.hip has the argument why it changes no result): returns a RowPack with
     the packed inputs and the row descriptors of the three attention forms, or None when the step must stay dense (unsupported
@@ -54,22 +88,36 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
         dev = eng.device
         i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
         st = eng._pack_state = dict(key=(B, S), counts=i32(B, 8), counts_h=torch.empty(B, 8, dtype=torch.int32).pin_memory(),
-                                     desc=i32(8, B), desc_h=torch.empty(8, B, dtype=torch.int32).pin_memory(),
+                                     desc=i32(8, B), desc_h=[torch.empty(8, B, dtype=torch.int32).pin_memory() for _ in range(4)], desc_turn=0,
                                      src_e=i32(T), pos_e=i32(T), inv_e=i32(T), src_d=i32(T), pos_d=i32(T), inv_d=i32(T), src_s=i32(T), idx_s=i32(T),
                                      tgt16_s=torch.empty(T, 8, dtype=torch.int16, device=dev), lm_s=torch.empty(T, 8, dtype=torch.float32, device=dev),
                                      enc16=torch.empty(T, 8, dtype=torch.int16, device=dev), dec16=torch.empty(T, 8, dtype=torch.int16, device=dev),
                                      tgt16=torch.empty(T, 8, dtype=torch.int16, device=dev), lm=torch.empty(T, 8, dtype=torch.float32, device=dev))
     lm3 = loss_mask.reshape(B, S, 8)
-    ops.rowmap_count(emask, dmask, lm3, st['counts'])
-    st['counts_h'].copy_(st['counts'], non_blocking=True)
-    # work of the step that does not depend on the row counts goes in front of the wait: the GPU projects the Octuple table while the
-    # host plans the packing
-    eng._await_updates(0)
-    eng.refresh_shadow()
-    eng.build_ptab()
-    eng._tables_ready = True
-    torch.cuda.current_stream().synchronize()
-    c = st['counts_h'].numpy().astype(np.int64)
+    pf = eng._pack_prefetch.pop(0) if eng._pack_prefetch else None
+    if pf is not None and pf['key'] != _mask_key(loss_mask, emask, dmask):
+        pf = None
+        eng._pack_prefetch.clear()                       # requests for some other batch: the caller changed its mind
+    if pf is not None:
+        # the per-sequence counts of this batch were requested ahead of time (prefetch_counts): the host has them, or waits for that one
+        # small copy only -- the step's stream is never drained, so the launches of this step queue up behind the previous one
+        pf['event'].synchronize()
+        c = pf['counts_h'].numpy().astype(np.int64)
+        eng._await_updates(0)
+        eng.refresh_shadow()
+        eng.build_ptab()
+        eng._tables_ready = True
+    else:
+        ops.rowmap_count(emask, dmask, lm3, st['counts'])
+        st['counts_h'].copy_(st['counts'], non_blocking=True)
+        # work of the step that does not depend on the row counts goes in front of the wait: the GPU projects the Octuple table while the
+        # host plans the packing
+        eng._await_updates(0)
+        eng.refresh_shadow()
+        eng.build_ptab()
+        eng._tables_ready = True
+        torch.cuda.current_stream().synchronize()
+        c = st['counts_h'].numpy().astype(np.int64)
     if not c[:, 3].all():
         return None
     (Te, off_e, len_e), (Td, off_d, len_d) = plan_packed_rows(c[:, 0], S), plan_packed_rows(c[:, 2], S)
@@ -81,9 +129,14 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
     sub = SUB_LAST and eng.ND > 0 and Ts <= SUB_MIN_GAIN * Td
     if not sub:
         off_s, len_s = off_d, len_d
-    st['desc_h'].copy_(torch.from_numpy(np.stack([off_e, len_e, c[:, 0], off_d, len_d, c[:, 1], off_s, len_s]).astype(np.int32)))
+    # the host may run a step ahead of the device (prefetch_counts): the pinned staging of the offsets is a ring, so that this step's
+    # values are not overwritten before their stream-ordered copy has run (a slot comes round again after three more steps, and the
+    # host never gets further than two steps ahead: a prefetched count waits for the step before the previous one)
+    st['desc_turn'] = (st['desc_turn'] + 1) % len(st['desc_h'])
+    desc_h = st['desc_h'][st['desc_turn']]
+    desc_h.copy_(torch.from_numpy(np.stack([off_e, len_e, c[:, 0], off_d, len_d, c[:, 1], off_s, len_s]).astype(np.int32)))
     desc = st['desc']
-    desc.copy_(st['desc_h'], non_blocking=True)
+    desc.copy_(desc_h, non_blocking=True)
     ops.rowmap_build(emask, None, desc[0], desc[1], st['src_e'], st['pos_e'], st['inv_e'])
     ops.rowmap_build(dmask, lm3, desc[3], desc[4], st['src_d'], st['pos_d'], st['inv_d'])
     pk = RowPack()

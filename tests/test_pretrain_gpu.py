@@ -191,7 +191,7 @@ def test_demo_midi_in_generate_midi_out(tmp_path):
     assert tuple(x.shape) == (1, S, 8) and tuple(y.shape) == (1, S, 8) and y.is_cuda and y.dtype == torch.int64
     assert [tuple(r) for r in x[0, :20, :4].tolist()] == [r[:4] for r in om.midi_to_encoding(song)]
     rows = om.octuple_to_rows(y.cpu().numpy())
-    assert len(rows) == S                                                 # every position was generated
+    assert len(rows) == S - 1 and int((y[0, :, 0] < 256).sum()) == S      # every position was generated; the last row becomes the EOS (demo.py:88-89)
     back = om.read_midi(out)
     assert len(back.notes) == len(om.encoding_to_midi(rows).notes) > 0
     # the same call through the command-line surface, without a checkpoint: nothing but the flags differs
