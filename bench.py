@@ -242,7 +242,8 @@ def decode_bench(args, model, eng, dev, rank):
         print(json.dumps({"metric": "generate tokens/s (KV-cached decode, B=1, S=%d)" % S, "value": nsteps / dt, "unit": "tokens/s", "n_gpus": 1,
                           "steps": nsteps, "warmup": 1, "ms_per_step": dt / nsteps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-                          "config": {"workload": "decode %dL/%dd S=%d B=1, encoder + cross-K/V once (included in the time)" % (args.layers, args.hs, S)}}), flush=True)
+                          "config": {"workload": "decode %dL/%dd S=%d B=1, encoder + cross-K/V once (included in the time)" % (args.layers, args.hs, S)},
+                          "decode_info": eng.last_decode}), flush=True)
 
 
 def extra_measurements(args, model, eng, ops, step, peak, dev):

@@ -250,7 +250,7 @@ class Pretrainer:
         def report(sums):
             """The log lines of one step (pretrain.py:198-207) from its 24 sums: the one device -> host read of the step."""
             nonlocal total_acc, total_losses, nb
-            s = sums.double().cpu().numpy()
+            s = sums.double().numpy()
             losses = s[0:8] / s[8:16]
             accs = s[16:24] / s[8:16]
             total_loss = float((losses * self._w).sum() / self._w.sum())
@@ -261,25 +261,62 @@ class Pretrainer:
             total_losses += total_loss
             nb += 1
 
-        # The sums of step i are read (and its lines written) after step i + 1 has been handed to the GPU: fetching and preparing
-        # the next batch on the host then runs beside the device step instead of between two of them.
-        pending = None
-        for ori_seq_batch in training_data:
-            enc16, dec16, tgt16, loss_mask, emask, dmask = self.prepare_batch(ori_seq_batch)
+        # Software pipeline over the batches. Batch i + 1 is corrupted, shifted and masked on a side stream while step i runs, and its
+        # packing counts are requested there too (Engine.prefetch_pack): step i + 1 then starts without draining the device. The 24 sums
+        # of step i go to a pinned buffer by a stream-ordered copy behind an event; they are read (and the log lines written) after
+        # step i + 1 has been handed to the GPU, so neither the read nor the batch preparation sits between two device steps.
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, '_prep_stream', None) is None:
+            self._prep_stream = torch.cuda.Stream(device=self.device)
+            self._sum_pins = [torch.empty(24, dtype=torch.float32).pin_memory() for _ in range(3)]
+        prep = self._prep_stream
+
+        def stage(batch):
+            prep.wait_stream(main)                                      # everything the previous batches were given (their buffers may be recycled)
+            with torch.cuda.stream(prep):
+                tensors = self.prepare_batch(batch)
+                eng.prefetch_pack(tensors[3], tensors[4], tensors[5], stream=prep)
+                ev = torch.cuda.Event()
+                ev.record(prep)
+            for t in tensors:
+                t.record_stream(main)
+            return tensors, ev
+
+        def enqueue_read(sums, k):
+            """24 floats device -> pinned host behind an event on the launch stream; nothing waits here."""
+            pin = self._sum_pins[k % len(self._sum_pins)]
+            pin.copy_(sums, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            return pin, ev
+
+        it = iter(training_data)
+        first = next(it, None)
+        staged = stage(first) if first is not None else None
+        pending, k = None, 0
+        while staged is not None:
+            (enc16, dec16, tgt16, loss_mask, emask, dmask), ready = staged
+            main.wait_event(ready)
+            nxt = next(it, None)
+            staged = stage(nxt) if nxt is not None else None            # on the side stream, beside the step below
             sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=train,
                                       count_hook=self.reducer.reduce_counts if self.reducer else None)
             if train:
                 if self.reducer:
                     self.reducer.all_reduce_grads()
                 eng.optimizer_step(lr=self.lr)
-            sums = sums.clone()                                     # the engine reuses its scalar buffer in the next step
             if self.reducer:
+                sums = sums.clone()                                     # the engine reuses its scalar buffer in the next step
                 self.reducer.reduce_sums(sums)
+            cur = enqueue_read(sums, k)
+            k += 1
             if pending is not None:
-                report(pending)
-            pending = sums
+                pending[1].synchronize()
+                report(pending[0])
+            pending = cur
         if pending is not None:
-            report(pending)
+            pending[1].synchronize()
+            report(pending[0])
         n = max(1, len(training_data))
         return round(total_losses / n, 3), [round(float(x) / n, 3) for x in total_acc]
 

@@ -139,3 +139,94 @@ def test_finetune_trainer_data_parallel_path_equals_plain(pg):
     assert all(abs(a - b) < 2e-4 for a, b in zip(l0, l1)) and l0[-1] < l0[0]
     # the exchange rounds the gradients to bf16 once (default mode): three Adam steps of 1e-3 move a parameter by <= 3e-3
     assert float((p0 - p1).abs().max()) < 1e-4 and float((h0 - h1).abs().max()) < 1e-4
+
+
+def test_exchange_is_independent_of_the_packed_shape(pg, monkeypatch):
+    """Under data parallelism every rank packs ITS OWN samples: the rows a rank keeps (Te, Td, loss rows) differ from rank to rank and
+    from step to step, while the exchange must see the same flat ranges, in the same order, with the same sizes on every rank (the
+    collectives pair up by issue order). Two batches with different packing (and one that stays dense) through one reducer: the
+    announced (lo, hi) sequences are identical, each tiles [0, n_total) once, reduce_counts moves the same 8 floats, and every step's
+    gradients equal the plain step's rounded to bf16 (pretrain.py:63-65 semantics: a sum over replicas of per-rank gradients)."""
+    from pianobart_amd import engine as E, ops
+    from pianobart_amd.parallel import GradReducer
+    m, eng = _engine('bf16')
+    batches = []
+    for seed, min_len in ((3, None), (11, 40), (12, 250)):
+        kw = {} if min_len is None else {'min_len': min_len}
+        enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(4, 256, seed=seed, **kw)]
+        batches.append((ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask))
+    plain, shapes = [], []
+    for it, args in enumerate(batches):
+        eng._seed = 900 + it
+        eng.loss_and_grads(*args, train=True)
+        torch.cuda.synchronize()
+        plain.append(eng.G32.clone())
+        shapes.append(eng.last_rows)
+    assert len(set(shapes)) == len(shapes), shapes                     # three different row layouts (the third keeps (almost) every row)
+    red = GradReducer(eng, 1, mode='bf16')
+    seen, counts_seen = [], []
+    inner = red._on_ready
+    eng.grad_hook = lambda lo, hi: (seen.append((lo, hi)), inner(lo, hi))[1]
+    hook = lambda c: (counts_seen.append(tuple(c.shape)), red.reduce_counts(c))[1]
+    try:
+        seqs = []
+        for it, args in enumerate(batches):
+            seen.clear()
+            eng._seed = 900 + it
+            eng.loss_and_grads(*args, train=True, count_hook=hook)
+            red.all_reduce_grads()
+            torch.cuda.synchronize()
+            assert eng.last_rows == shapes[it]
+            seqs.append(list(seen))
+            cover = np.zeros(eng.n_total, dtype=np.int32)
+            for lo, hi in seen:
+                cover[lo:hi] += 1
+            assert (cover == 1).all()
+            want = plain[it].to(torch.bfloat16).float()
+            assert torch.equal(want, eng.G32), (it, float((want - eng.G32).abs().max()))
+        assert seqs[0] == seqs[1] == seqs[2]                              # same ranges, same order, whatever was packed
+        assert counts_seen == [(8,)] * 3
+    finally:
+        eng.grad_hook = None
+
+
+def test_reducer_step_at_the_bench_shape(pg):
+    """configs[1] model and batch (12L / 768 / S = 1024, B = 32) with the reducer installed at world size 1: the ranges tile the flat
+    buffer once and the bf16-exchange step equals the plain step rounded to bf16 (packed rows, ordinary-grid backward GEMMs, the
+    communication stream)."""
+    from pianobart_amd import ops
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from pianobart_amd.parallel import GradReducer
+    cfg = BartConfig(max_position_embeddings=1024, d_model=768, encoder_layers=12, decoder_layers=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072,
+                     encoder_attention_heads=12, decoder_attention_heads=12, dropout=0.1)
+    m = PianoBartLM(PianoBart(cfg, E2W, W2E, precision='bf16'))
+    randomize_params(m, 41)
+    m = m.train().cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(32, 1024, seed=1234)]
+    args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+    eng._seed = 77
+    s0 = eng.loss_and_grads(*args, train=True).clone()
+    torch.cuda.synchronize()
+    want = eng.G32.to(torch.bfloat16).float()
+    Te, Td, T, Ts = eng.last_rows
+    assert T == 32768 and Te < T and Td < T
+    red = GradReducer(eng, 1, mode='bf16')
+    seen = []
+    inner = red._on_ready
+    eng.grad_hook = lambda lo, hi: (seen.append((lo, hi)), inner(lo, hi))[1]
+    try:
+        eng._seed = 77
+        s1 = eng.loss_and_grads(*args, train=True, count_hook=red.reduce_counts)
+        red.all_reduce_grads()
+        torch.cuda.synchronize()
+        cover = np.zeros(eng.n_total, dtype=np.int32)
+        for lo, hi in seen:
+            cover[lo:hi] += 1
+        assert (cover == 1).all()
+        assert torch.equal(s0, s1)
+        # the ordinary-grid backward GEMMs sum their K range in the persistent grid's order (same tiles, same splits): identical bits
+        assert torch.equal(want, eng.G32), float((want - eng.G32).abs().max() / want.abs().max())
+    finally:
+        eng.grad_hook = None
