@@ -584,18 +584,25 @@ struct DecAttnArgs {
     float* part;                                                 // [H][gridDim.y][HD + 4] records {m, l, -, -, o[HD]}
 };
 
+// Threads: 256; the self-attention form launches 768 so that the new token's workgroup projects q, k and v side by side (wave
+// groups 0 / 1 / 2, every weight load of a group in flight at once: ONE memory round trip instead of six dependent ones -- these
+// kernels are pure latency); in the other workgroups of that launch waves 4 .. 11 leave at once.
 template <int NC, int HD, bool SELF>
-__global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnArgs a) {
+__global__ __launch_bounds__(SELF ? 768 : 256) void dec_attn_kernel(const DecAttnArgs a) {
     constexpr int CPR = HD / 8, KPW = 64 / CPR, STEP = 4 * KPW, UR = 4, RPW = HD / 4, NP = RPW / 2;
+    constexpr int PBATCH = (NC <= 3 && !SELF) || NC <= 2 ? (NP < 8 ? NP : 8) : 4;       // passes of weight rows in flight per lane (registers)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = reinterpret_cast<float*>(smem);                  // [HD] q of this head, rounded to bf16 like a stored q row, times the softmax scale
     float* red = qs + HD;                                        // [4 HD] reductions / per-wave partial outputs (new-token workgroup: k | v)
     float* sc = red + 4 * HD;                                    // [keys per split] scores -> probabilities
     const int h = blockIdx.x, sp = blockIdx.y, nrec = gridDim.y;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l32 = lane & 31, half = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, l32 = lane & 31, half = lane >> 5;
+    const int wgrp = SELF ? (int)(t >> 8) : 0;                   // 0: q (and the attention), 1: k, 2: v of the new token
+    const int wave = (t >> 6) & 3;
     const int d = a.d;
     const int Sk = SELF ? *a.pos : a.Sk_fixed;
     const bool is_new = SELF && sp == a.nreg;
+    if (SELF && wgrp > 0 && !is_new) return;                     // only the new token's workgroup uses the other two wave groups
     int ck = a.ck_fixed;
     if (SELF) { ck = (Sk + a.nreg - 1) / a.nreg; ck = ck < 64 ? 64 : (ck + 15) & ~15; }
     const int j0 = sp * ck, j1 = min(Sk, j0 + ck);
@@ -605,6 +612,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnArgs a) {
         if (t < HD) rec[4 + t] = 0.f;
         return;
     }
+    const int tq = t & 255;                                       // thread index inside its wave group
     // cached rows of the first block of this split: requested before anything else (they do not depend on q)
     const int sub = lane % CPR, grp = lane / CPR;
     const int jfirst = j0 + wave * KPW;
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float z = xf[c][j] - mean; q = fmaf(z, z, q); }
         const float rstd = rsqrtf(half_sum(q) / (float)d + a.eps);
-        const bool store_ln = h == 0 && wave == 0 && half == 0 && (SELF ? is_new : sp == 0);
+        const bool store_ln = h == 0 && wgrp == 0 && wave == 0 && half == 0 && (SELF ? is_new : sp == 0);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int e0 = (l32 + 32 * c) * 8;
@@ -664,18 +672,18 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnArgs a) {
     // HD rows of a projection: a half-wave per row (2 rows per pass and wave), 4 passes of weight loads in flight
     auto project = [&](const bf16_t* __restrict__ W, const float* __restrict__ bias, float* out, float mul) {
 #pragma unroll 1
-        for (int pb = 0; pb < NP; pb += 4) {
-            bf16x8 w[4][NC];
-            float bv[4];
+        for (int pb = 0; pb < NP; pb += PBATCH) {
+            bf16x8 w[PBATCH][NC];
+            float bv[PBATCH];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < PBATCH; ++p) {
                 const int row = h * HD + wave * RPW + 2 * (pb + p) + half;
                 bv[p] = bias[row];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) w[p][c] = *reinterpret_cast<const bf16x8*>(W + (size_t)row * d + (l32 + 32 * c) * 8);
             }
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < PBATCH; ++p) {
                 float acc = 0.f;
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
@@ -686,18 +694,18 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnArgs a) {
             }
         }
     };
-    project(a.Wq, a.bq, qs, a.scale);
     if (is_new) {
         float* ks = red; float* vs = red + HD;
-        project(a.Wk, a.bk, ks, 1.f);
-        project(a.Wv, a.bv, vs, 1.f);
+        if (wgrp == 0) project(a.Wq, a.bq, qs, a.scale);
+        else if (wgrp == 1) project(a.Wk, a.bk, ks, 1.f);
+        else project(a.Wv, a.bv, vs, 1.f);
         __syncthreads();
         if (t < HD) {
             a.kc[(long)Sk * a.kv_ss + h * HD + t] = (bf16_t)ks[t];
             a.vc[(long)Sk * a.kv_ss + h * HD + t] = (bf16_t)vs[t];
             rec[4 + t] = vs[t];
         }
-        if (wave == 0) {
+        if (t < 64) {
             float p = 0.f;
 #pragma unroll
             for (int e = lane; e < HD; e += 64) p = fmaf(qs[e], ks[e], p);
@@ -706,6 +714,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnArgs a) {
         }
         return;
     }
+    project(a.Wq, a.bq, qs, a.scale);
     __syncthreads();
     float qv[8];
 #pragma unroll
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnArgs a) {
     __syncthreads();
     float sum = 0.f;
     if (mx != -INFINITY)
-        for (int j = t; j < j1 - j0; j += 256) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
+        for (int j = tq; j < j1 - j0; j += 256) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
@@ -839,7 +848,7 @@ struct Decoder {
 
 template <int NC, int HD>
 static void dec_attn_go(const DecAttnArgs& a, bool self, int H, int nrec, size_t lds, hipStream_t st) {
-    if (self) hipLaunchKernelGGL((dec_attn_kernel<NC, HD, true>), dim3(H, nrec), dim3(256), lds, st, a);
+    if (self) hipLaunchKernelGGL((dec_attn_kernel<NC, HD, true>), dim3(H, nrec), dim3(768), lds, st, a);
     else hipLaunchKernelGGL((dec_attn_kernel<NC, HD, false>), dim3(H, nrec), dim3(256), lds, st, a);
 }
 static int dec_attn_launch(const DecAttnArgs& a, bool self, int H, int hd, int nrec, size_t lds, hipStream_t st) {

@@ -252,16 +252,13 @@ _SAMPLE_TAB = {}
 
 
 def _sample_tables():
-    """Constants of PianoBartLM.sample_row: per-element temperatures, the (8, 272) gather index (1280 = the appended -inf)."""
+    """Constants and scratch of PianoBartLM.sample_row: per-element temperatures, the (8, 272) probability rows, the native call's arrays."""
     if not _SAMPLE_TAB:
         n = [ops.SEG_OFF[j + 1] - ops.SEG_OFF[j] for j in range(8)]
-        width = (max(n) + 15) // 16 * 16                                    # whole vectors for 8- and 16-lane CPUs
-        idx = torch.full((8, width), ops.VOCAB, dtype=torch.long)
-        for j in range(8):
-            idx[j, :n[j]] = torch.arange(ops.SEG_OFF[j], ops.SEG_OFF[j + 1])
+        width = (max(n) + 15) // 16 * 16
         n_a, p_a = np.asarray(n, dtype=np.int32), np.asarray(PianoBartLM.SAMPLE_P, dtype=np.float32)
         _SAMPLE_TAB.update(n_a=n_a, p_a=p_a, n_p=n_a.ctypes.data, p_p=p_a.ctypes.data, out=np.zeros(8, dtype=np.int32), tie=np.zeros(1, dtype=np.int32))
-        _SAMPLE_TAB.update(n=n, idx=idx, ninf=torch.tensor([float('-inf')]),
+        _SAMPLE_TAB.update(n=n, probs=torch.zeros(8, width, dtype=torch.float32),
                            tvec=torch.cat([torch.full((n[j],), float(PianoBartLM.SAMPLE_T[j]), dtype=torch.float32) for j in range(8)]))
     return _SAMPLE_TAB
 
@@ -341,15 +338,17 @@ class PianoBartLM(nn.Module):
     SAMPLE_P = [1, 1, 1, 0.9, 0.9, 1, 1, 0.9]
 
     def sample_row(self, row_logits):
-        """row_logits: (1280,) f32 CPU tensor of one position; returns the 8 sampled ids (model.py:68-78). sampling()'s two tensor ops
-        (divide by the temperature, softmax) run once for all 8 heads: the row divided by a per-element temperature vector, gathered
-        into an (8, 272) matrix whose padding is -inf (exp -> exact zeros in lanes that the shorter rows' own vector tail leaves
-        empty), one softmax over the last axis -- the same elementwise quotients, maxima, exponentials and lane-wise sums as the
-        eight separate calls (checked bit for bit and draw for draw in tests/test_model_cpu.py). 0.31 -> 0.09 ms of host time per
+        """row_logits: (1280,) f32 CPU tensor of one position; returns the 8 sampled ids (model.py:68-78). sampling()'s own tensor ops
+        on the host row -- the division by the temperature (one call with a per-element temperature vector: the same quotients) and a
+        1-D softmax per head -- then nucleus() for all 8 heads in one native call (pb_nucleus_rows: numpy's arithmetic order and
+        precision; ties among candidates go back to the numpy code), fed the 8 uniform draws np.random.choice would have made. Checked
+        draw for draw and RNG state for RNG state against sampling() in tests/test_model_cpu.py. 0.31 -> 0.1 ms of host time per
         generated position, which sits in series with the GPU's ~0.3 ms."""
         tab = _sample_tables()
-        y = torch.cat([row_logits / tab['tvec'], tab['ninf']])
-        probs = torch.softmax(y[tab['idx']], dim=-1)
+        y = row_logits / tab['tvec']
+        probs = tab['probs']
+        for j in range(8):                                           # 1-D calls: a 2-D softmax would open an OpenMP region per position
+            torch.softmax(y[ops.SEG_OFF[j]:ops.SEG_OFF[j + 1]], dim=-1, out=probs[j, :tab['n'][j]])
         # the 8 draws np.random.choice would make, in head order (RandomState fills a request sequentially: the same stream as 8 calls)
         u = np.random.random_sample(8)
         out, tie = tab['out'], tab['tie']
