@@ -769,6 +769,39 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
             }
         }
     }
+    // Row split (round 3). A partly filled last round of the persistent grid costs a whole tile time: N = 768 at 26 624 rows is 312
+    // tiles = 1.22 rounds of 256 CUs, paid as 2. When the K-range split above did not take the case (it moves f32 partials through
+    // HBM and loses at small K), the M tiles of the FULL rounds stay with the 256 x 256 kernel and the remaining rows go to a second
+    // launch of the 128 x 128 kernel (2 workgroups per CU, every tile resident at once): both write C directly, no partials, no
+    // finishing pass. Model in us, from the in-step timings of the N = 768 shapes (profiles/r03_*): a 256 x 256 round costs
+    // 1.53 nk + 6.5, a round of the 128 x 128 kernel 0.75 nk + 4 (one workgroup per CU) or 1.0 nk + 4 (two), a kernel boundary 2.
+    Gemm2Args rest;
+    bool row_split = false;
+    if (big && a.tail_split == 1 && !(d->flags & (2048 | 4096 | PB_GEMM_NO_ROW_SPLIT | 128)) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 &&
+        !d->colsum_out && d->M % 8 == 0) {
+        const int ncu = pb_num_cus(), ntile = a.tiles_m * a.tiles_n, rounds = ntile / ncu, rem = ntile % ncu, nkt = d->K / BK;
+        if (rounds >= 1 && rem > 0) {
+            const int m_main = (rounds * ncu / a.tiles_n) * 256;                      // rows of the M tiles that fill whole rounds
+            const int m_rest = d->M - m_main;
+            const long t2 = (long)((m_rest + 127) / 128) * ((d->N + 127) / 128);
+            const float r256 = 1.53f * nkt + 6.5f;
+            const float r128 = (t2 <= ncu ? 0.75f : 1.0f) * nkt + 4.f;
+            const float now = (rounds + 1) * r256;
+            const float then = rounds * r256 + (float)((t2 + 2 * ncu - 1) / (2 * ncu)) * r128 + 2.f;
+            if (m_main >= 256 && m_rest > 0 && then < 0.92f * now) {
+                row_split = true;
+                rest = a;
+                rest.M = m_rest;
+                rest.A = a_kc ? a.A + (long)m_main * a.lda : a.A + m_main;
+                rest.C = c32 ? (void*)((float*)a.C + (long)m_main * a.ldc) : (void*)((bf16_t*)a.C + (long)m_main * a.ldc);
+                if (a.aux_in) rest.aux_in = a.aux_in + (long)m_main * a.ldaux;
+                if (a.aux_out) rest.aux_out = a.aux_out + (long)m_main * a.ldaux;
+                rest.tiles_m = (m_rest + 127) / 128; rest.tiles_n = (d->N + 127) / 128;
+                a.M = m_main; a.tiles_m = m_main / 256;
+                grid = dim3(a.tiles_m * a.tiles_n, 1, 1);
+            }
+        }
+    }
     if (big && !(d->flags & 2048)) {
         if (d->colsum_out && nsplit == 1 && nb1 * a.nb2 == 1) {
             float* slice = pb_defer_alloc((size_t)2 * a.tiles_m * d->N);          // deferred reduction: the partial rows must outlive this call
@@ -799,6 +832,16 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 2, 2, 4, 4);
         else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 2, 2, 4, 4);
         else PB_G2_LAUNCH(false, false, 2, 2, 4, 4);
+    }
+    if (row_split) {
+        const Gemm2Args main_args = a;
+        a = rest;
+        grid = dim3(a.tiles_m * a.tiles_n, 1, 1);
+        if (a_kc && b_kc) PB_G2_LAUNCH(true, true, 2, 2, 4, 4);
+        else if (a_kc && !b_kc) PB_G2_LAUNCH(true, false, 2, 2, 4, 4);
+        else if (!a_kc && b_kc) PB_G2_LAUNCH(false, true, 2, 2, 4, 4);
+        else PB_G2_LAUNCH(false, false, 2, 2, 4, 4);
+        a = main_args;
     }
 #undef PB_G2_LAUNCH
     if (hipGetLastError() != hipSuccess) { pb_set_error("pb_gemm2 launch failed"); return -1; }

@@ -321,6 +321,48 @@ def test_gemm_tail_split_matches_whole_tiles(ops, M, N, K, lay, epi):
     assert float((outs[0] - outs[1]).abs().max()) <= (1e-5 if c32 else 1.6e-2) * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('M,N,K,lay', [(26624, 768, 768, 'NT'), (26880, 768, 2304, 'NT'), (26624, 768, 3072, 'NN'), (26880, 768, 1536, 'NT'),
+                                       (26624 + 40, 768, 768, 'NT'), (26624, 1536, 768, 'NT')])
+@pytest.mark.parametrize('epi', ['bias', 'accum', 'f32', 'gelu'])
+def test_gemm_row_split_matches_one_launch(ops, M, N, K, lay, epi):
+    """Round 3: the rows of a partly filled last round of the persistent 256x256 grid go to a second launch of the 128x128 kernel
+    (pb_gemm2_try, "Row split"). Against the same GEMM with PB_GEMM_NO_ROW_SPLIT (65536): every output row written exactly once --
+    equal to the order of the f32 sums inside a tile (one bf16 ulp) -- and both against an fp32 matmul; the GELU form also checks
+    the derivative rows the split launch writes through its own aux pointer."""
+    from pianobart_amd._lib import PB_BF16
+    g = torch.Generator(device='cuda').manual_seed(M + K + N)
+    A = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16)
+    Bm = (torch.randn(N, K, device='cuda', generator=g) * K ** -0.5).to(torch.bfloat16)
+    Bop = Bm if lay == 'NT' else Bm.t().contiguous()
+    bias = torch.randn(N, device='cuda', generator=g) if epi in ('bias', 'gelu') else None
+    c32 = epi == 'f32'
+    C0 = torch.randn(M, N, device='cuda', generator=g).to(torch.float32 if c32 else torch.bfloat16)
+    outs, auxs = [], []
+    for flags in (65536, 0):
+        C = C0.clone()
+        aux = torch.full((M, N), 7.0, device='cuda', dtype=torch.bfloat16) if epi == 'gelu' else None
+        ops.gemm(A, Bop, C, M=M, N=N, K=K, dtype=PB_BF16, b_kc=(lay == 'NT'), bias=bias, accum=(epi == 'accum'), c_f32=c32, dbg=flags,
+                 gelu_aux_out=aux)
+        outs.append(C.float()); auxs.append(aux)
+    ref = A.float() @ Bm.float().t()
+    if bias is not None:
+        ref += bias
+    if epi == 'accum':
+        ref += C0.float()
+    if epi == 'gelu':
+        u = ref.double()
+        cdf = 0.5 * (1 + torch.erf(u / 2 ** 0.5))
+        dref = (cdf + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5).float()
+        ref = (u * cdf).float()
+        for a_ in auxs:
+            assert float((a_.float() - dref).abs().max()) < 2e-2
+        assert float((auxs[0].float() - auxs[1].float()).abs().max()) <= 1.6e-2
+    tol = 1e-4 if c32 else 2e-2
+    for o in outs:
+        assert float((o - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) <= (1e-5 if c32 else 1.6e-2) * max(1.0, float(ref.abs().max()))
+
+
 def test_transpose_batch_bf16(ops):
     """The transposed weight copies the backward's dX = dY W reads (Engine._refresh_wT): several matrices of one flat buffer in one launch."""
     g = torch.Generator(device='cuda').manual_seed(4)
