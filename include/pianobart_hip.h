@@ -46,6 +46,7 @@ const char* pb_last_error(void);
                                     occupy the idle CUs (f32 partials, finished by a second small launch); a cost model decides.
                                     Pays for a caller that runs one GEMM at a time (N = 768 at 26 624 rows: +13-17 %): the training
                                     step asks for it in forward; in backward its second stream already fills those CUs     */
+#define PB_GEMM_NO_STREAM 131072   /* A/B runs: every work item of the persistent kernel starts with its own DMA prologue (no look-ahead into the next item) */
 #define PB_GEMM_NO_ROW_SPLIT 65536 /* A/B runs: never hand the rows of a partly filled last round to the 128x128 kernel (see pb_gemm2_try) */
 typedef struct pb_gemm_desc {
     const void* A; const void* B; void* C;
