@@ -46,8 +46,11 @@ const char* pb_last_error(void);
                                     occupy the idle CUs (f32 partials, finished by a second small launch); a cost model decides.
                                     Pays for a caller that runs one GEMM at a time (N = 768 at 26 624 rows: +13-17 %): the training
                                     step asks for it in forward; in backward its second stream already fills those CUs     */
-#define PB_GEMM_NO_STREAM 131072   /* A/B runs: every work item of the persistent kernel starts with its own DMA prologue (no look-ahead into the next item) */
-#define PB_GEMM_NO_ROW_SPLIT 65536 /* A/B runs: never hand the rows of a partly filled last round to the 128x128 kernel (see pb_gemm2_try) */
+#define PB_GEMM_ROW_SPLIT 65536  /* 256x256 kernel: the M tiles of the full rounds of the persistent grid stay with it, the remaining rows go to a
+                                    second launch of the 128x128 kernel (no partials). Measured (round 3): -1.8 % on the one-stream step
+                                    together with nothing else, +-0 on the shipped two-stream step (its second stream already fills the CUs a
+                                    short last round leaves idle, and the forward's K = 768 shapes lose what the split saves to the slower
+                                    128x128 tiles): on request only                                                                   */
 typedef struct pb_gemm_desc {
     const void* A; const void* B; void* C;
     const float* bias;            /* per-n, may be NULL */

@@ -42,7 +42,6 @@ struct Gemm2Args {
     // to tail_slabs (item-major, 256 x BN floats each) and are summed, finished and stored by tail_finish_kernel.
     int n_full, tail_split, tail_kc;
     float* tail_slabs;
-    int cont;                             // gemm3_kernel: request the next item's first K-tiles from the last phases of the current one
 };
 
 __device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
@@ -439,19 +438,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) boff[j] = lds0 + tr_lane_off(wc * 32 + j * 16, lane);
 
-    // K-tile T of the current item (T < nk), or -- continuous stream -- K-tile T - nk of the NEXT item of this workgroup: the DMA ring
-    // does not care about tile boundaries, so the first K-tiles of the next item are requested during the last two K-tiles of this
-    // one and have landed when its epilogue ends (before: 12 pieces issued behind the last barrier and waited for at the top of the
-    // next item, i.e. a memory round trip per tile with every CU's C stores in the way). g0 = this item's first K-tile in the
-    // workgroup's stream of K-tiles: the ring slot of a K-tile is the parity of its stream index.
-#define G3_M0(T) ((T) < nk ? m0 : nm0)
-#define G3_N0(T) ((T) < nk ? n0 : nn0)
-#define G3_K0(T) ((T) < nk ? kbeg + (T) * BK : nkbeg + ((T) - nk) * BK)
-#define G3_SL(T) (((g0 + (T)) & 1) * SLOT)
-#define G3_ISSUE_A(T, H) stage_half<A_KC, 64>(A, p.lda, G3_M0(T), G3_K0(T), p.M, smem + G3_SL(T) + (H) * HALF, H, wave, lane)
-#define G3_ISSUE_B(T, H) stage_half<B_KC, 32, GSB>(B, p.ldb, G3_N0(T), G3_K0(T), p.N, smem + G3_SL(T) + (2 + (H)) * HALF, H, wave, lane)
-#define G3_ISSUE_A1(T, H, PC) stage_half<A_KC, 64, 128, PC, PC + 1>(A, p.lda, G3_M0(T), G3_K0(T), p.M, smem + G3_SL(T) + (H) * HALF, H, wave, lane)
-#define G3_ISSUE_B1(T, H, PC) stage_half<B_KC, 32, GSB, PC, PC + 1>(B, p.ldb, G3_N0(T), G3_K0(T), p.N, smem + G3_SL(T) + (2 + (H)) * HALF, H, wave, lane)
+#define G3_ISSUE_A(T, H) stage_half<A_KC, 64>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
+#define G3_ISSUE_B(T, H) stage_half<B_KC, 32, GSB>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
+#define G3_ISSUE_A1(T, H, PC) stage_half<A_KC, 64, 128, PC, PC + 1>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
+#define G3_ISSUE_B1(T, H, PC) stage_half<B_KC, 32, GSB, PC, PC + 1>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
 #define G3_READ_A(SL, H)                                                                                          \
     do {                                                                                                          \
         if constexpr (A_KC) {                                                                                     \
@@ -512,28 +502,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         if (nk > 1) { G3_ISSUE_A(1, 0); G3_ISSUE_B(1, 1); }                                                       \
     } while (0)
     int bslot = 0;
-    int g0 = 0;                                                      // stream index of this item's first K-tile (ring slot parity)
-    int nm0 = 0, nn0 = 0, nkbeg = 0, nnk = 0;                        // the next item of this workgroup (nnk = 0: none)
-    bool streamed = false;                                           // this item's first K-tiles were requested by the previous item's last phases
     G3_PROLOGUE();
     int pend = 0;                                                    // store instructions this wave left in flight behind the prologue
     while (true) {
-        // Continuous stream: look one item ahead. Only when both items have at least two K-tiles (the stream looks at most two K-tiles
-        // ahead) -- otherwise the next item starts with its own prologue as before.
-        nnk = 0;
-        if (p.cont && L + (int)gridDim.x < total && nk >= 2) {
-            const int sm0 = m0, sn0 = n0, szs = zs, skbeg = kbeg, snk = nk;
-            item(L + gridDim.x);
-            nm0 = m0; nn0 = n0; nkbeg = kbeg; nnk = nk >= 2 ? nk : 0;
-            m0 = sm0; n0 = sn0; zs = szs; kbeg = skbeg; nk = snk;
-        }
         // K-tile 0 of this item must have landed. vmcnt counts loads, stores and DMA pieces in ONE in-order queue, and behind
         // K-tile 0's pieces sit the 4 pieces of K-tile 1 and the `pend` stores of the previous item's epilogue (exactly 16 / 32
         // per wave when that tile was interior and store-only; 0 = "unknown", which waits for the stores too): leave them flying.
-        if (streamed) {
-            // K-tile 0 landed behind the previous item's last counted wait; only the bias piece of this item is new (wave 0, oldest of
-            // what follows: every later counted wait covers it)
-        } else if (nk > 1) {
+        if (nk > 1) {
             if (pend == 32) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
             else if (pend == 16) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
             else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
@@ -544,9 +519,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         }
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
-        const int nkx = nk + nnk;                                    // K-tiles this item's phases may request: its own and the next item's first ones
         for (int kt = 0; kt < nk; ++kt) {
-            const int sl = (g0 + kt) & 1;
+            const int sl = kt & 1;
             // phase 0: quadrant (0,0)
             G3_READ_B(sl, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -558,26 +532,26 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             constexpr bool SPLIT = !(A_KC && B_KC);
 #define G3_ISSUE2(ISS, T, H) do { if constexpr (SPLIT) { ISS##1(T, H, 0); } else { ISS(T, H); } } while (0)
 #define G3_MID(ISS, COND, T, H) do { if constexpr (SPLIT) { if (COND) ISS##1(T, H, 1); } } while (0)
-            if (kt + 1 < nkx) G3_ISSUE2(G3_ISSUE_A, kt + 1, 1);
-            G3_MMA(0, 0, true, true, G3_MID(G3_ISSUE_A, kt + 1 < nkx, kt + 1, 1));
+            if (kt + 1 < nk) G3_ISSUE2(G3_ISSUE_A, kt + 1, 1);
+            G3_MMA(0, 0, true, true, G3_MID(G3_ISSUE_A, kt + 1 < nk, kt + 1, 1));
             // phase 1: quadrant (0,1)
             G3_READ_B(sl, 1);
-            if (kt + 1 < nkx) G3_ISSUE2(G3_ISSUE_B, kt + 1, 0);
-            G3_MMA(0, 1, false, true, G3_MID(G3_ISSUE_B, kt + 1 < nkx, kt + 1, 0));
+            if (kt + 1 < nk) G3_ISSUE2(G3_ISSUE_B, kt + 1, 0);
+            G3_MMA(0, 1, false, true, G3_MID(G3_ISSUE_B, kt + 1 < nk, kt + 1, 0));
             // phase 2: quadrant (1,1)
             G3_READ_A(sl, 1);
-            if (kt + 2 < nkx) G3_ISSUE2(G3_ISSUE_A, kt + 2, 0);
-            G3_MMA(1, 1, true, false, G3_MID(G3_ISSUE_A, kt + 2 < nkx, kt + 2, 0));
+            if (kt + 2 < nk) G3_ISSUE2(G3_ISSUE_A, kt + 2, 0);
+            G3_MMA(1, 1, true, false, G3_MID(G3_ISSUE_A, kt + 2 < nk, kt + 2, 0));
             // phase 3: quadrant (1,0)
             G3_READ_B(sl, 0);
-            if (kt + 2 < nkx) {
+            if (kt + 2 < nk) {
                 G3_ISSUE2(G3_ISSUE_B, kt + 2, 1);
                 // in flight behind the wait: A0(t+2) (2 pieces) + B1(t+2) (both pieces, or the first one when split)
                 if constexpr (SPLIT) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            G3_MMA(1, 0, false, true, G3_MID(G3_ISSUE_B, kt + 2 < nkx, kt + 2, 1));
+            G3_MMA(1, 0, false, true, G3_MID(G3_ISSUE_B, kt + 2 < nk, kt + 2, 1));
 #undef G3_ISSUE2
 #undef G3_MID
         }
@@ -589,19 +563,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         const int eL = L;
         L += gridDim.x;
         const bool more = L < total;
-        const bool was_streamed = nnk > 0;                           // the next item's K-tiles 0 and 1 (A0, B1) are in the ring already
         if (more) {
-            g0 += nk;
             item(L);
-            if (was_streamed) {
-                bslot ^= 1;
-                if (p.bias && wave == 0) glds16(reinterpret_cast<const bf16_t*>(p.bias + min(n0 + lane * 4, p.N - 4)), smem + 2 * SLOT + bslot * 1024);
-            } else {
-                g0 = 0;
-                G3_PROLOGUE();
-            }
+            G3_PROLOGUE();
         }
-        streamed = more && was_streamed;
         const bool etail = p.tail_split > 1 && eL >= p.n_full;       // the finished item was one K range of a tail tile
         if (etail) {
             // a tail item dumps its accumulators in register order (1 KiB per wave instruction); tail_finish_kernel knows the layout
@@ -629,10 +594,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #undef G3_PROLOGUE
-#undef G3_M0
-#undef G3_N0
-#undef G3_K0
-#undef G3_SL
 #undef G3_ISSUE_A
 #undef G3_ISSUE_B
 #undef G3_ISSUE_A1
@@ -735,7 +696,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096 | 8192 | 16384 | 32768 | PB_GEMM_NO_ROW_SPLIT | PB_GEMM_NO_STREAM)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096 | 8192 | 16384 | 32768)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue other than accumulate");
         return -2;
     }
@@ -778,7 +739,6 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     } while (0)
     bool cs_fused = false;
     a.n_full = 0; a.tail_split = 1; a.tail_kc = 0; a.tail_slabs = nullptr;
-    a.cont = (d->flags & PB_GEMM_NO_STREAM) ? 0 : 1;
     if (big && (d->flags & PB_GEMM_TAIL_SPLIT) && !(d->flags & 2048) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 && !d->colsum_out &&
         !(d->flags & (PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | 128))) {
         // The persistent grid runs ceil(tiles / CUs) rounds; a last round that fills only part of the chip (N = 768: 312 tiles =
@@ -809,7 +769,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
             }
         }
     }
-    // Row split (round 3). A partly filled last round of the persistent grid costs a whole tile time: N = 768 at 26 624 rows is 312
+    // Row split (round 3; on request: PB_GEMM_ROW_SPLIT). A partly filled last round of the persistent grid costs a whole tile time: N = 768 at 26 624 rows is 312
     // tiles = 1.22 rounds of 256 CUs, paid as 2. When the K-range split above did not take the case (it moves f32 partials through
     // HBM and loses at small K), the M tiles of the FULL rounds stay with the 256 x 256 kernel and the remaining rows go to a second
     // launch of the 128 x 128 kernel (2 workgroups per CU, every tile resident at once): both write C directly, no partials, no
@@ -817,7 +777,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // 1.53 nk + 6.5, a round of the 128 x 128 kernel 0.75 nk + 4 (one workgroup per CU) or 1.0 nk + 4 (two), a kernel boundary 2.
     Gemm2Args rest;
     bool row_split = false;
-    if (big && a.tail_split == 1 && !(d->flags & (2048 | 4096 | PB_GEMM_NO_ROW_SPLIT | 128)) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 &&
+    if (big && a.tail_split == 1 && (d->flags & PB_GEMM_ROW_SPLIT) && !(d->flags & (2048 | 4096 | 128)) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 &&
         !d->colsum_out && d->M % 8 == 0) {
         const int ncu = pb_num_cus(), ntile = a.tiles_m * a.tiles_n, rounds = ntile / ncu, rem = ntile % ncu, nkt = d->K / BK;
         if (rounds >= 1 && rem > 0) {

@@ -326,7 +326,7 @@ def test_gemm_tail_split_matches_whole_tiles(ops, M, N, K, lay, epi):
 @pytest.mark.parametrize('epi', ['bias', 'accum', 'f32', 'gelu'])
 def test_gemm_row_split_matches_one_launch(ops, M, N, K, lay, epi):
     """Round 3: the rows of a partly filled last round of the persistent 256x256 grid go to a second launch of the 128x128 kernel
-    (pb_gemm2_try, "Row split"). Against the same GEMM with PB_GEMM_NO_ROW_SPLIT (65536): every output row written exactly once --
+    (pb_gemm2_try, "Row split", PB_GEMM_ROW_SPLIT = 65536). Against the same GEMM without the flag: every output row written exactly once --
     equal to the order of the f32 sums inside a tile (one bf16 ulp) -- and both against an fp32 matmul; the GELU form also checks
     the derivative rows the split launch writes through its own aux pointer."""
     from pianobart_amd._lib import PB_BF16
@@ -338,7 +338,7 @@ def test_gemm_row_split_matches_one_launch(ops, M, N, K, lay, epi):
     c32 = epi == 'f32'
     C0 = torch.randn(M, N, device='cuda', generator=g).to(torch.float32 if c32 else torch.bfloat16)
     outs, auxs = [], []
-    for flags in (65536, 0):
+    for flags in (0, 65536):
         C = C0.clone()
         aux = torch.full((M, N), 7.0, device='cuda', dtype=torch.bfloat16) if epi == 'gelu' else None
         ops.gemm(A, Bop, C, M=M, N=N, K=K, dtype=PB_BF16, b_kc=(lay == 'NT'), bias=bias, accum=(epi == 'accum'), c_f32=c32, dbg=flags,
