@@ -278,6 +278,11 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
             E._PACK_ROWS = saved
     except Exception as ex:                                            # noqa: BLE001 -- a failed leg must not cost the main line
         out["padded_step"] = {"error": repr(ex)[:200]}
+    # RCCL prints its version banner on file descriptor 1 when the first communicator comes up: stdout carries the ONE JSON line and nothing
+    # else, so descriptor 1 points at stderr while this leg runs
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
     try:
         from pianobart_amd.parallel import GradReducer
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -307,6 +312,15 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
     except Exception as ex:                                            # noqa: BLE001
         eng.grad_hook = None
         out["dp_mode_step"] = {"error": repr(ex)[:200]}
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)                             # the banner sits in libc's stdout buffer (a pipe / file is fully buffered)
+        except Exception:                                              # noqa: BLE001
+            pass
+        os.dup2(fd_out, 1)
+        os.close(fd_out)
     try:
         biases = [p.detach().clone() for p in model.mask_lm.proj.parameters()]
         model.eval()
