@@ -40,8 +40,6 @@ const char* pb_last_error(void);
 #define PB_GEMM_ONE_BARRIER 2048 /* A/B runs: 256x256 tile with the one-barrier kernel instead of the ping-pong one   */
 #define PB_GEMM_PLAIN_GRID 4096  /* 256x256 ping-pong kernel as an ordinary grid (one workgroup per work item) instead of the
                                     persistent one-per-CU grid: what to ask for when other kernels (RCCL) hold CUs        */
-#define PB_GEMM_NO_192 8192      /* A/B runs: never pick the 256x192 tile                                                */
-#define PB_GEMM_FORCE_192 16384  /* A/B runs: always pick the 256x192 tile when the 256-row kernel is used               */
 #define PB_GEMM_TAIL_SPLIT 32768 /* 256x256 kernel: the tiles of a partly filled last round of the grid may be cut into K ranges that
                                     occupy the idle CUs (f32 partials, finished by a second small launch); a cost model decides.
                                     Pays for a caller that runs one GEMM at a time (N = 768 at 26 624 rows: +13-17 %): the training

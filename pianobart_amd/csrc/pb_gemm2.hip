@@ -720,12 +720,9 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // the small split-K wgrads (768 x 768: 692 vs 620 TF). TN callers pass PB_GEMM_TILE256 together with their split-K factor.
     const bool big = !(d->flags & PB_GEMM_TILE128) && d->M >= 256 && d->N >= 256 &&
                      ((d->flags & PB_GEMM_TILE256) || (nsplit == 1 && d->M >= 2048 && d->N >= 512));
-    // 256 x 192 tiles (512 tiles = 2 full rounds at N = 768, T = 32768, where 256 x 256 gives 384 = 1.5) exist behind
-    // PB_GEMM_FORCE_192 only. Back-to-back launches of one shape measured them +4-6 % (fc2 1136 -> 1190 TF), but the same-box A/B of
-    // the whole training step lost 1.5 ms (77.9 vs 76.4 ms) with them: every A row panel is then streamed by 4 column tiles instead
-    // of 3, which the warm Infinity Cache of a repeated-launch benchmark hides and a real step does not. (A 192-wide tile also costs
-    // ~0.95 of a 256-wide one, not 0.75: the ping-pong interval is set by the load half, unchanged, not by the MFMAs.)
-    const bool wide192 = big && (d->flags & 16384) && !(d->flags & 2048) && nb1 * a.nb2 == 1;
+    // (A 256 x 192 instantiation -- 512 tiles = 2 full rounds at N = 768, T = 32768 -- measured +4-6 % back to back and -1.5 ms on the whole
+    // step in round 2: every A row panel is then streamed by 4 column tiles instead of 3. It lost its A/B and was removed in round 3.)
+    constexpr bool wide192 = false;
     const int BMs = big ? 256 : 128, BNs = big ? (wide192 ? 192 : 256) : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
     a.nsplit = nsplit;
@@ -810,7 +807,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         }                          // bit 11: A/B against the one-barrier 256x256 kernel; bit 12: ordinary (non-persistent) grid
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
-        auto kfn = wide192 ? gemm3_kernel<AK, BK_, 3> : gemm3_kernel<AK, BK_, 4>;                                          \
+        auto kfn = gemm3_kernel<AK, BK_, 4>;                                                                               \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
         const unsigned items = a.tail_split > 1 ? a.n_full + (grid.x - a.n_full) * a.tail_split : grid.x;                    \
         dim3 pgrid(std::min<unsigned>(items, (d->flags & 4096) ? items : (unsigned)pb_num_cus()), grid.y, 1);               \

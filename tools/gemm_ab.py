@@ -23,8 +23,8 @@ for name, M, N, K, a_kc, b_kc, sk in shapes:
     sk2 = sk if sk == 1 else max(1, 256 // (((M + 255) // 256) * ((N + 127) // 128)))
     sk3 = sk if sk == 1 else max(1, round(512 / (((M + 127) // 128) * ((N + 127) // 128))))
     slabs = torch.empty(max(sk, sk2, sk3) * M * N, device=dev) if sk > 1 else None
-    fs = [lambda C=Cs[0]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=True, dbg=8192),
-          lambda C=Cs[1]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=True, dbg=16384),
+    fs = [lambda C=Cs[0]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=True, dbg=0),
+          lambda C=Cs[1]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=True, dbg=65536),
           lambda C=Cs[2]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk, slabs=slabs, tile256=sk > 1 and M * N > 768 * 768),
           lambda C=Cs[3]: ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=a_kc, b_kc=b_kc, c_f32=c32, **ex, splitk=sk3, slabs=slabs, tile128=True)]
     for f in fs:
