@@ -9,7 +9,6 @@
 //   * every wave owns 32 rows (2 MFMA tiles), halving LDS fragment reads per MFMA.
 #include "pb_common.h"
 #include "pb_api_internal.h"
-#include <cstdlib>
 
 namespace {
 
@@ -416,179 +415,6 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args pin) {
             }
             if (g == 0) p.lse[((long)b * p.H + h) * lse_ld + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;   // m = the reference l was summed against
         }
-    }
-}
-
-// ================================================================== forward, head_dim 64, 8 waves x 16 queries (round 3)
-// Same math, LDS images and DMA ring as fa64_fwd_kernel<64>, cut differently: a workgroup is still 128 queries, but 8 waves of ONE
-// 16-query tile each instead of 4 waves of two. A wave then needs ~100 registers instead of 218, so FOUR waves share a SIMD (two
-// workgroups per CU as before: the K / V ring is per workgroup). The kernels above are bound by dependent latency (S -> exp -> P -> PV,
-// LDS round trips, one barrier per tile: ~45 % of the SIMD cycles nothing issues with two waves per SIMD), not by an execution
-// unit; what a smaller wave costs is LDS read traffic per MFMA (every wave reads the whole K and V tile: 16 KiB per 18 MFMAs
-// instead of per 36), which at 16 waves per CU is ~1000-1300 LDS cycles per round of wave tiles against ~1150 matrix-pipe and
-// ~1250 vector-issue cycles per SIMD: still under them. V fragments are fetched two 16-column blocks at a time (16 registers).
-constexpr int FT8 = 512;
-__global__ __launch_bounds__(FT8, 4) void fa64_fwd8_kernel(const Fa64Args pin) {
-    constexpr int KS = 2, DT = 4, HDT = 64;
-    using C = FaCfg<1>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    int rb, h, b;
-    block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b);
-    if (pin.causal) rb = (pin.Sq + 127) / 128 - 1 - rb;
-    const int q0 = rb * 128;
-    Fa64Args p = pin;
-    varlen_localize(p, b);
-    const int lse_ld = pin.Sq;
-    if (q0 >= p.Sq) return;
-    const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
-    const bf16_t* K = p.k + b * p.k_sb + h * HDT;
-    const bf16_t* V = p.v + b * p.v_sb + h * HDT;
-    const float c = p.scale * LOG2E;
-    const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
-    const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
-    const int nt = (kend + 63) / 64;
-    float* ldsBias = reinterpret_cast<float*>(smem + C::NS * C::STB);
-    unsigned* ldsFlag = reinterpret_cast<unsigned*>(ldsBias + ((p.Sk + 63) / 64) * 64);
-    for (int tile = wave; tile < nt; tile += 8) {
-        const int key = tile * 64 + lane;
-        const bool vis = key < (pin.vl_q_off ? kvis_end : p.Sk) && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
-        ldsBias[key] = vis ? 0.f : -INFINITY;
-        const bool allvis = __builtin_amdgcn_ballot_w64(vis) == ~0ull;
-        if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
-    }
-    const int myq = q0 + wave * 16 + lr;
-    bf16x8 qf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = scale_frag(frag_global(Q, p.q_ss, myq, p.Sq, ks * 32 + g * 8), c);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));       // ordinary loads are done before the first DMA
-    f32x4 oacc[DT];
-#pragma unroll
-    for (int i = 0; i < DT; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY;
-    f32x4 cinit = {0.f, 0.f, 0.f, 0.f};
-    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
-    const bf16_t one = (bf16_t)1.0f;
-    const bf16x8 ones = {one, one, one, one, one, one, one, one};
-    unsigned voff[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_u32(smem) + 8192 + tr_lane_off64(dt * 16, lane);
-    // one DMA piece of K and one of V per wave and tile (8 KiB image = 8 pieces)
-    const int srow = wave * 8 + (lane >> 3);
-    const unsigned schunk = (unsigned)((lane & 7) ^ fsw(srow));
-    const unsigned soff_k = (unsigned)(srow * p.k_ss + (schunk << 3)), soff_v = (unsigned)(srow * p.v_ss + (schunk << 3));
-    auto stage = [&](int it, int sidx) {
-        char* st = smem + sidx * C::STB;
-        const int r0 = it * 64;
-        if (r0 + 64 <= p.Sk) {
-            glds16(K + (long)r0 * p.k_ss + soff_k, st + wave * 1024);
-            glds16(V + (long)r0 * p.v_ss + soff_v, st + 8192 + wave * 1024);
-        } else {
-            const int gr = min(r0 + srow, p.Sk - 1);
-            glds16(K + (long)gr * p.k_ss + (schunk << 3), st + wave * 1024);
-            glds16(V + (long)gr * p.v_ss + (schunk << 3), st + 8192 + wave * 1024);
-        }
-    };
-    if (nt > 0) stage(0, 0);
-    if (nt > 1) { stage(1, 1); wait_vm<2>(); } else { wait_vm<0>(); }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-    int sidx = 0;
-    for (int it = 0; it < nt; ++it) {
-        const char* st = smem + sidx * C::STB;
-        const int nidx = sidx == 0 ? C::NS - 1 : sidx - 1;
-        if (it + C::NS - 1 < nt) stage(it + C::NS - 1, nidx);
-        const float* ldsB = ldsBias + it * 64;
-        const int k0 = it * 64;
-        const bool diag = p.causal && (k0 + 63 > q0 + wave * 16);
-        const bool masked = diag || __builtin_amdgcn_readfirstlane(ldsFlag[it]) != 0u;
-        f32x4 s[4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = cinit;
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) s[kt] = MFMA16(frag_row(st, kt * 16 + lr, k2, g), qf[k2], s[kt]);
-        }
-        s16x4 tv[2][2][2];                                                // V column blocks 0, 1: requested before the softmax
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * C::STB));
-        bool exact = masked;
-        if (!masked) {
-            float t0 = m == -INFINITY ? INFINITY : -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t0 = fmaxf(t0, s[kt][r]);
-            exact = __builtin_amdgcn_ballot_w64(t0 > LAZY_THR) != 0ull;
-        }
-        if (exact) {
-            asm volatile("; exact softmax path" ::: "memory");
-            const float mold = m == -INFINITY ? 0.f : m;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-                if (masked) bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = s[kt][r] + mold + bias[r];
-                    if (diag && (k0 + kt * 16 + g * 4 + r) > myq) x = -INFINITY;
-                    s[kt][r] = x;
-                    mx = fmaxf(mx, x);
-                }
-            }
-            mx = grp_max(mx);
-            const float mnew = fmaxf(m, mx);
-            const float muse = mnew == -INFINITY ? 0.f : mnew;
-            const float alpha = __builtin_amdgcn_exp2f(m - muse);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[kt][r] -= muse;
-            lacc *= alpha;
-#pragma unroll
-            for (int i = 0; i < DT; ++i) oacc[i] *= alpha;
-            m = mnew;
-            cinit = f32x4{-muse, -muse, -muse, -muse};
-        }
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r]);
-        bf16x8 pf[2];
-        pf[0] = pack_pair(s[0], s[1]);
-        pf[1] = pack_pair(s[2], s[3]);
-        lacc = MFMA16(ones, pf[1], MFMA16(ones, pf[0], lacc));
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half == 1) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) ds_tr_block(tv[dt], voff[2 + dt] + (unsigned)(sidx * C::STB));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0][0][0]), "+v"(tv[0][0][1]), "+v"(tv[0][1][0]), "+v"(tv[0][1][1]),
-                                                  "+v"(tv[1][0][0]), "+v"(tv[1][0][1]), "+v"(tv[1][1][0]), "+v"(tv[1][1][1]));
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 v0 = tr_join(tv[dt][0][0], tv[dt][0][1]), v1 = tr_join(tv[dt][1][0], tv[dt][1][1]);
-                oacc[half * 2 + dt] = MFMA16(v1, pf[1], MFMA16(v0, pf[0], oacc[half * 2 + dt]));
-            }
-        }
-        if (it + 2 < nt) { wait_vm<2>(); } else { wait_vm<0>(); }
-        __builtin_amdgcn_s_barrier();
-        sidx = sidx == C::NS - 1 ? 0 : sidx + 1;
-    }
-    if (myq < p.Sq) {
-        const float lq = lacc[0];
-        const float inv = lq > 0.f ? 1.0f / lq : 0.f;
-        bf16_t* O = p.out + b * p.o_sb + (long)myq * p.o_ss + h * HDT;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            bf16x4 r = {(bf16_t)(oacc[dt][0] * inv), (bf16_t)(oacc[dt][1] * inv), (bf16_t)(oacc[dt][2] * inv), (bf16_t)(oacc[dt][3] * inv)};
-            *reinterpret_cast<bf16x4*>(O + dt * 16 + g * 4) = r;
-        }
-        if (g == 0) p.lse[((long)b * p.H + h) * lse_ld + myq] = lq > 0.f ? (m + log2f(lq)) / LOG2E : INFINITY;
     }
 }
 
@@ -1010,15 +836,6 @@ static int fa64_fwd_launch(const Fa64Args& a, hipStream_t stream) {
     using C = FaCfg<(HD + 63) / 64>;
     const size_t lds = (size_t)C::NS * C::STB + (size_t)((a.Sk + 63) / 64) * (64 * 4 + 4);
     PB_REQUIRE(lds <= 160 * 1024, "pb_flash_fwd: Sk=%d needs %zu bytes of LDS", a.Sk, lds);
-    if constexpr (HD == 64) {
-        static const int fwd8 = [] { const char* e = getenv("PB_FA_FWD8"); return e ? atoi(e) : 1; }();     // A/B: 0 = the 4-wave x 32-query kernel
-        if (fwd8) {
-            if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(fa64_fwd8_kernel, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT8), lds, stream, a);
-            PB_LAUNCH_CHECK();
-            return 0;
-        }
-    }
     if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_fwd_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fa64_fwd_kernel<HD>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds, stream, a);
     PB_LAUNCH_CHECK();
