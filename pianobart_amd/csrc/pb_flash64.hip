@@ -9,7 +9,6 @@
 //   * every wave owns 32 rows (2 MFMA tiles), halving LDS fragment reads per MFMA.
 #include "pb_common.h"
 #include "pb_api_internal.h"
-#include <cstdlib>
 
 namespace {
 
@@ -415,230 +414,6 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args pin) {
                 *reinterpret_cast<bf16x4*>(O + dt * 16 + g * 4) = r;
             }
             if (g == 0) p.lse[((long)b * p.H + h) * lse_ld + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;   // m = the reference l was summed against
-        }
-    }
-}
-
-// ================================================================== forward, head_dim 64, software-pipelined over key tiles (round 3)
-// Same tiles, LDS images, lazy reference maximum and results as fa64_fwd_kernel<64>; what changes is WHEN a wave issues what.
-// The plain loop is three clusters per tile -- S MFMAs, ~90 vector instructions of softmax, PV MFMAs -- and the counters say
-// the matrix and the vector pipe take turns (SQ_VALU_MFMA_COEXEC_CYCLES = 20 % of the matrix pipe's busy cycles). Here the S
-// chains of tile it+1 are issued BETWEEN the exp / pack groups of tile it (two score buffers, named A / B, swapped by unrolling
-// the loop twice), and the "does tile it+1 need the exact path" maxima are taken between the PV MFMAs of tile it: every MFMA
-// gap has the wave's own vector work in it. Ring of 4 stages (tile it+1 must be in LDS one tile early): 64 KiB + bias per
-// workgroup, still two workgroups per CU.
-constexpr int NSP = 4;
-template <int KO>
-__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fa64_fwdp_kernel(const Fa64Args pin) {
-    constexpr int KS = 2, DT = 4, HDT = 64, STB = 16384, PCS = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    int rb, h, b;
-    block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b);
-    if (pin.causal) rb = (pin.Sq + 127) / 128 - 1 - rb;
-    const int q0 = rb * 128;
-    Fa64Args p = pin;
-    varlen_localize(p, b);
-    const int lse_ld = pin.Sq;
-    if (q0 >= p.Sq) return;
-    const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
-    const bf16_t* K = p.k + b * p.k_sb + h * HDT;
-    const bf16_t* V = p.v + b * p.v_sb + h * HDT;
-    const float c = p.scale * LOG2E;
-    const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
-    const int kend = p.causal ? min(kvis_end, q0 + 128) : kvis_end;
-    const int nt = (kend + 63) / 64;
-    float* ldsBias = reinterpret_cast<float*>(smem + NSP * STB);
-    unsigned* ldsFlag = reinterpret_cast<unsigned*>(ldsBias + ((p.Sk + 63) / 64) * 64);
-    for (int tile = wave; tile < nt; tile += 4) {
-        const int key = tile * 64 + lane;
-        const bool vis = key < (pin.vl_q_off ? kvis_end : p.Sk) && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
-        ldsBias[key] = vis ? 0.f : -INFINITY;
-        const bool allvis = __builtin_amdgcn_ballot_w64(vis) == ~0ull;
-        if (lane == 0) ldsFlag[tile] = allvis ? 0u : 1u;
-    }
-    int myq[2];
-    bf16x8 qf[2][KS];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        myq[qt] = q0 + wave * 32 + qt * 16 + lr;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = scale_frag(frag_global(Q, p.q_ss, myq[qt], p.Sq, ks * 32 + g * 8), c);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[0][ks]), "+v"(qf[1][ks]));
-    f32x4 oacc[2][DT];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int i = 0; i < DT; ++i) oacc[qt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m[2] = {-INFINITY, -INFINITY};
-    f32x4 cinit[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const bf16_t one = (bf16_t)1.0f;
-    const bf16x8 ones = {one, one, one, one, one, one, one, one};
-    unsigned voff[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_u32(smem) + 8192 + tr_lane_off64(dt * 16, lane);
-    const StageOff so_k = stage_off(p.k_ss, wave, lane), so_v = stage_off(p.v_ss, wave, lane);
-    auto stage = [&](int it, int sidx) {
-        char* st = smem + sidx * STB;
-        stage64(K, p.k_ss, it * 64, p.Sk, st, wave, lane, so_k, 8, p.zeros);
-        stage64(V, p.v_ss, it * 64, p.Sk, st + 8192, wave, lane, so_v, 8, p.zeros);
-    };
-    if (nt > 0) stage(0, 0);
-    if (nt > 1) stage(1, 1);
-    if (nt > 2) { stage(2, 2); wait_vm<PCS>(); } else { wait_vm<0>(); }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-    // S chains of one tile: s' = (c K) Q^T - m_ref, the reference riding in as the initial accumulator
-    auto qk = [&](const char* st, f32x4 (&s)[2][4]) {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) s[qt][kt] = cinit[qt];
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const bf16x8 kk = frag_row(st, kt * 16 + lr, k2, g);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) s[qt][kt] = MFMA16(kk, qf[qt][k2], s[qt][kt]);
-            }
-        }
-    };
-    // does any score sit more than LAZY_THR above its row's reference (or has a row no reference yet)?
-    auto over = [&](const f32x4 (&s)[2][4]) {
-        float t0 = m[0] == -INFINITY ? INFINITY : -INFINITY, t1 = m[1] == -INFINITY ? INFINITY : -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { t0 = fmaxf(t0, s[0][kt][r]); t1 = fmaxf(t1, s[1][kt][r]); }
-        return __builtin_amdgcn_ballot_w64(fmaxf(t0, t1) > LAZY_THR) != 0ull;
-    };
-    f32x4 sA[2][4], sB[2][4];
-    bool needex = true;
-    if (nt > 0) { qk(smem, sA); needex = over(sA); }
-    int it = 0, sidx = 0;
-    s16x4 tv[2][2][2];                                                    // V column blocks 0, 1 (2, 3 follow between the PV MFMAs)
-    // one tile: `sc` holds its scores, `sn` receives the next tile's
-    auto body = [&](f32x4 (&sc)[2][4], f32x4 (&sn)[2][4]) {
-        const char* st = smem + sidx * STB;
-        const char* nx = smem + ((sidx + 1) & 3) * STB;
-        if (KO != 5 && it + 3 < nt) stage(it + 3, (sidx + 3) & 3);
-        const float* ldsB = ldsBias + it * 64;
-        const int k0 = it * 64;
-        const bool diag = p.causal && (k0 + 63 > q0 + wave * 32);
-        const bool masked = diag || __builtin_amdgcn_readfirstlane(ldsFlag[it]) != 0u;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) if (KO != 3 || it == 0) ds_tr_block(tv[dt], voff[dt] + (unsigned)(sidx * STB));
-        bf16x8 pf[2][2];
-        // exact path (rare: first tile of a row, masked / diagonal tiles, a score far above the reference): true row maximum, new
-        // reference, rescale of O and l in place; it leaves s - m_new in `sc`, so that the exp / pack below is the only copy
-        auto exact_prep = [&](auto tag) {
-            constexpr bool MASKED = decltype(tag)::value;
-            asm volatile("; exact softmax path" ::: "memory");
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const float mold = m[qt] == -INFINITY ? 0.f : m[qt];
-                float mx = -INFINITY;
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (MASKED) bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = sc[qt][kt][r] + mold;
-                        if constexpr (MASKED) {
-                            x += bias[r];
-                            if (diag && (k0 + kt * 16 + g * 4 + r) > myq[qt]) x = -INFINITY;
-                        }
-                        sc[qt][kt][r] = x;
-                        mx = fmaxf(mx, x);
-                    }
-                }
-                mx = grp_max(mx);
-                const float mnew = fmaxf(m[qt], mx);
-                const float muse = mnew == -INFINITY ? 0.f : mnew;
-                const float alpha = __builtin_amdgcn_exp2f(m[qt] - muse);
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sc[qt][kt][r] -= muse;
-                lacc[qt] *= alpha;
-#pragma unroll
-                for (int i = 0; i < DT; ++i) oacc[qt][i] *= alpha;
-                m[qt] = mnew;
-                cinit[qt] = f32x4{-muse, -muse, -muse, -muse};
-            }
-        };
-        if (masked) exact_prep(BoolTag<true>{}); else if (needex) exact_prep(BoolTag<false>{});
-        // one v_exp_f32 per score, packed to the PV operand; the next tile's S chains (against the reference as it stands now) in between
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            // (behind the last tile this reads a stale ring slot: the scores are never used, and no branch splits the block)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) sn[qt][kt] = cinit[qt];
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const bf16x8 kk = KO == 4 ? qf[1][k2 ^ 1] : frag_row(nx, kt * 16 + lr, k2, g);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) sn[qt][kt] = MFMA16(kk, qf[qt][k2], sn[qt][kt]);
-            }
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sc[qt][kt][r] = KO == 1 ? sc[qt][kt][r] * 0.5f : __builtin_amdgcn_exp2f(sc[qt][kt][r]);
-            if (kt & 1) {
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) pf[qt][kt >> 1] = pack_pair(sc[qt][kt - 1], sc[qt][kt]);
-            }
-        }
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) lacc[qt] = MFMA16(ones, pf[qt][1], MFMA16(ones, pf[qt][0], lacc[qt]));
-        float t0 = m[0] == -INFINITY ? INFINITY : -INFINITY, t1 = m[1] == -INFINITY ? INFINITY : -INFINITY;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0][0][0]), "+v"(tv[0][0][1]), "+v"(tv[0][1][0]), "+v"(tv[0][1][1]),
-                                                  "+v"(tv[1][0][0]), "+v"(tv[1][0][1]), "+v"(tv[1][1][0]), "+v"(tv[1][1][1]));
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 v0 = tr_join(tv[dt][0][0], tv[dt][0][1]), v1 = tr_join(tv[dt][1][0], tv[dt][1][1]);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) oacc[qt][half * 2 + dt] = MFMA16(v1, pf[qt][1], MFMA16(v0, pf[qt][0], oacc[qt][half * 2 + dt]));
-            }
-            if (half == 0 && KO != 3) {                                   // same registers: the MFMAs above have read them at issue
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) ds_tr_block(tv[dt], voff[2 + dt] + (unsigned)(sidx * STB));
-            }
-            // the next tile's lazy test rides in the PV MFMAs' gaps
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (KO != 6) { t0 = fmaxf(t0, sn[0][half * 2 + dt][r]); t1 = fmaxf(t1, sn[1][half * 2 + dt][r]); }
-        }
-        needex = __builtin_amdgcn_ballot_w64(fmaxf(t0, t1) > LAZY_THR) != 0ull;
-        if (it + 3 < nt) { wait_vm<PCS>(); } else { wait_vm<0>(); }
-        if (KO != 2) __builtin_amdgcn_s_barrier();
-        sidx = (sidx + 1) & 3;
-        ++it;
-    };
-    while (it < nt) {
-        body(sA, sB);
-        if (it >= nt) break;
-        body(sB, sA);
-    }
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        if (myq[qt] < p.Sq) {
-            const float lq = lacc[qt][0];
-            const float inv = lq > 0.f ? 1.0f / lq : 0.f;
-            bf16_t* O = p.out + b * p.o_sb + (long)myq[qt] * p.o_ss + h * HDT;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                bf16x4 r = {(bf16_t)(oacc[qt][dt][0] * inv), (bf16_t)(oacc[qt][dt][1] * inv), (bf16_t)(oacc[qt][dt][2] * inv), (bf16_t)(oacc[qt][dt][3] * inv)};
-                *reinterpret_cast<bf16x4*>(O + dt * 16 + g * 4) = r;
-            }
-            if (g == 0) p.lse[((long)b * p.H + h) * lse_ld + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;
         }
     }
 }
@@ -1061,24 +836,6 @@ static int fa64_fwd_launch(const Fa64Args& a, hipStream_t stream) {
     using C = FaCfg<(HD + 63) / 64>;
     const size_t lds = (size_t)C::NS * C::STB + (size_t)((a.Sk + 63) / 64) * (64 * 4 + 4);
     PB_REQUIRE(lds <= 160 * 1024, "pb_flash_fwd: Sk=%d needs %zu bytes of LDS", a.Sk, lds);
-    if constexpr (HD == 64) {
-        static const int piped = [] { const char* e = getenv("PB_FA_FWDP"); return e ? atoi(e) : 1; }();     // A/B: 0 = the plain loop
-        const size_t ldsp = (size_t)NSP * 16384 + (size_t)((a.Sk + 63) / 64) * (64 * 4 + 4);
-        if (piped && ldsp <= 80 * 1024) {                                     // two workgroups per CU must still fit
-            static const int ko = [] { const char* e = getenv("PB_FA_KO"); return e ? atoi(e) : 0; }();
-            auto go = [&](auto kern) {
-                if (ldsp > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-                hipLaunchKernelGGL(kern, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), ldsp, stream, a);
-            };
-            switch (ko) {
-                case 1: go(fa64_fwdp_kernel<1>); break; case 2: go(fa64_fwdp_kernel<2>); break; case 3: go(fa64_fwdp_kernel<3>); break;
-                case 4: go(fa64_fwdp_kernel<4>); break; case 5: go(fa64_fwdp_kernel<5>); break; case 6: go(fa64_fwdp_kernel<6>); break;
-                default: go(fa64_fwdp_kernel<0>);
-            }
-            PB_LAUNCH_CHECK();
-            return 0;
-        }
-    }
     if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(fa64_fwd_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fa64_fwd_kernel<HD>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(FT), lds, stream, a);
     PB_LAUNCH_CHECK();
