@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
                 if (argmax_out) argmax_out[row * 8 + i] = (int16_t)am;
             }
             if (dlogits) {
-                const float k = m != 0.f ? coef[i] * m : 0.f;
+                const float k = coef[i] * m;                                 // empty head: inf * 0 = NaN, as in pretrain.py:117
                 const float inv = 1.0f / se;
                 T* g = dlogits + row * V + o;
                 for (int c = lane; c < n; c += 64) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ce_rows_reg_kernel(const float* __restric
                 if (argmax_out) argmax_out[row * 8 + i] = (int16_t)am;
             }
             if (dlogits) {
-                const float kk = m != 0.f ? coef[i] * m : 0.f;
+                const float kk = coef[i] * m;                           // a head with no loss position in the batch: coef = inf, inf * 0 = NaN, as in pretrain.py:117
                 const float inv = 1.0f / se;
                 T* g = dlogits + row * V + o;
 #pragma unroll

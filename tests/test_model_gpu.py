@@ -343,6 +343,40 @@ def test_tiny_batch_one_short_sequence():
         assert _rel(torch.cat(m(enc.cuda(), dec.cuda(), emask.cuda(), dmask.cuda()), -1), torch.cat(o(enc, dec, emask, dmask), -1)) < 1e-4
 
 
+def test_head_without_a_loss_position_is_nan_like_the_reference():
+    """pretrain.py:117 divides a head's masked loss sum by its mask count: a head with no loss position in the whole batch is 0 / 0,
+    the total loss and every gradient that hangs on that head's logits become NaN. Same on the HIP path, fused and
+    module route; the other heads' numbers are untouched."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    from pianobart_amd import ops
+    m = _lm(64, 64, 1, 128, 2, 17, 'fp32', dropout=0.0).train()
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(max_position_embeddings=64, d_model=64, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=128,
+                                               decoder_ffn_dim=128, encoder_attention_heads=2, decoder_attention_heads=2, dropout=0.0), E2W, W2E)).train()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda()
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(2, 64, seed=21)
+    loss_mask = loss_mask.clone()
+    loss_mask[:, :, 3] = 0                                               # the Pitch head never carries a loss term
+    tot_o, head_o, *_ = O.pretrain_loss(o(enc, dec, emask, dmask), target, loss_mask, E2W)
+    tot_o.backward()
+    assert torch.isnan(tot_o) and torch.isnan(o.mask_lm.proj[3].weight.grad).all()
+    g = [t.cuda() for t in (enc, dec, loss_mask, emask, dmask, target)]
+    eng = m._get_engine()
+    eng.bind(g[0].device)
+    sums = eng.loss_and_grads(ops.ids_to_i16(g[0]), ops.ids_to_i16(g[1]), ops.ids_to_i16(g[5]), g[2].contiguous(), g[3], g[4], train=True).cpu().double()
+    head = sums[0:8] / sums[8:16]
+    assert float(sums[8 + 3]) == 0.0 and torch.isnan(head[3])
+    keep = [i for i in range(8) if i != 3]
+    ho = torch.stack([h.detach().double() for h in head_o]) if isinstance(head_o, (list, tuple)) else head_o.detach().double()
+    assert torch.allclose(head[keep], ho[keep], rtol=1e-4, atol=1e-6)
+    torch.cuda.synchronize()
+    assert torch.isnan(eng.g['head.w']).any()                            # the NaN reaches the head weights (and everything below them)
+    y = m(g[0], g[1], g[3], g[4])
+    tot_m, *_ = O.pretrain_loss(y, g[5], g[2], E2W)
+    assert torch.isnan(tot_m)
+
+
 @pytest.mark.parametrize('precision,train', [('bf16', True), ('bf16', False), ('fp32', True)])
 def test_second_stream_gives_identical_gradients(precision, train):
     """Weight-gradient GEMMs and the cross-attention K/V projections run on a second HIP stream (engine._WGRAD_STREAM): every
