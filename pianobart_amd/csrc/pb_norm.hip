@@ -677,7 +677,19 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const T* __restrict__ x,
     }
 }
 __global__ void ids_to_i16_kernel(const int64_t* __restrict__ ids, int16_t* __restrict__ out, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (int16_t)ids[i];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int64_t v = ids[i];
+        out[i] = (v < 0 || v > 32767) ? (int16_t)-1 : (int16_t)v;        // not an int16: stays recognisable for pb_ids_check
+    }
+}
+// nn.Embedding raises IndexError on an id outside its table (PianoBart.py:15-16); a kernel cannot, so it leaves a mark
+__global__ void ids_check_kernel(const int16_t* __restrict__ ids, long n, const int* __restrict__ limits, int* __restrict__ flag) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int v = ids[i];
+        bad |= v < 0 || v >= limits[i & 7];
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 __global__ void shift_right_kernel(const int16_t* __restrict__ ids, const int16_t* __restrict__ sos, int16_t* __restrict__ out, int B, int S) {
     const long n = (long)B * S * 8;
@@ -693,6 +705,14 @@ extern "C" int pb_ids_to_i16(const int64_t* ids, int16_t* out, int64_t n, void* 
     if (n <= 0) return 0;
     const int grid = (int)min((long)2048, (long)((n + 255) / 256));
     hipLaunchKernelGGL(ids_to_i16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, ids, out, (long)n);
+    PB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pb_ids_check(const int16_t* ids16, int64_t n, const int32_t* limits8, int32_t* flag, void* stream_) {
+    PB_REQUIRE(ids16 && limits8 && flag && n % 8 == 0, "pb_ids_check: null argument or n not a multiple of 8");
+    if (n <= 0) return 0;
+    const int grid = (int)min((long)1024, (long)((n + 255) / 256));
+    hipLaunchKernelGGL(ids_check_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, ids16, (long)n, limits8, flag);
     PB_LAUNCH_CHECK();
     return 0;
 }

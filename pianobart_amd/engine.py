@@ -943,8 +943,25 @@ class Engine:
             raise PBError('inputs are on %s but the model is on %s' % (enc_ids.device, self.device))
         enc16 = ops.ids_to_i16(enc_ids)
         dec16 = ops.ids_to_i16(dec_ids) if dec_ids is not None else None
+        self.note_ids(enc16)
+        if dec16 is not None and dec16.dim() == 3:
+            self.note_ids(dec16)
         f = lambda m: None if m is None else m.to(dtype=torch.float32).contiguous()
         return enc16, dec16, f(emask), f(dmask)
+
+    def note_ids(self, ids16):
+        """Enqueue the range check of (..., 8) Octuple ids (PianoBart.py:15-16: nn.Embedding raises IndexError on an id outside its
+        table); the verdict is read by check_ids() at a point where the host waits for the device anyway."""
+        if getattr(self, '_id_flag', None) is None or self._id_flag.device != ids16.device:
+            self._id_flag = torch.zeros(1, dtype=torch.int32, device=ids16.device)
+            self._id_lim = torch.tensor(ops.SEG_SIZES, dtype=torch.int32, device=ids16.device)
+        ops.ids_check(ids16, self._id_lim, self._id_flag)
+
+    def check_ids(self):
+        """Synchronises. Raises IndexError if a checked batch held an id outside its embedding table."""
+        if getattr(self, '_id_flag', None) is not None and int(self._id_flag.item()) != 0:
+            self._id_flag.zero_()
+            raise IndexError('index out of range in self: an Octuple id lies outside its embedding table (sizes %s)' % ops.SEG_SIZES)
 
     def _next_seed(self):
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
@@ -957,7 +974,9 @@ class Engine:
             raise PBError('pianobart_amd needs HIP device tensors (got %s); there is no CPU path' % enc_ids.device)
         self.bind(enc_ids.device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
-        return _LMFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, *self.params)
+        out = _LMFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, *self.params)
+        self.check_ids()                                                 # nn.Embedding's IndexError (the module route hands tensors to host code next anyway)
+        return out
 
     def module_forward_hidden(self, enc_ids, dec_ids, emask, dmask, training, dec_embeds=None):
         if enc_ids.device.type != 'cuda':
@@ -966,6 +985,7 @@ class Engine:
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
         n_backbone = len(self.params) - (16 if self.mlm is not None else 0)
         out = _HiddenFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, dec_embeds, *self.params[:n_backbone])
+        self.check_ids()
         return out
 
     # ------------------------------------------------------------------ fused pre-train step (bench / Pretrainer)
@@ -1096,6 +1116,7 @@ class Engine:
         result = pad.repeat(1, S, 1)
         em = emask.to(torch.float32).contiguous() if emask is not None else None
         enc16 = ops.ids_to_i16(enc_ids)
+        self.note_ids(enc16); self.check_ids()
         e = lambda *shape, dt=X: torch.empty(*shape, dtype=dt, device=dev)
         with torch.no_grad():
             _, enc_out = self.forward_hidden(enc16, None, em, None, False, 0)
@@ -1193,6 +1214,7 @@ class Engine:
         result = pad.repeat(1, S, 1)
         em = emask.to(torch.float32).contiguous() if emask is not None else None
         enc16 = ops.ids_to_i16(enc_ids)
+        self.note_ids(enc16); self.check_ids()
         e = lambda *shape, dt=X: torch.empty(*shape, dtype=dt, device=dev)
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         with torch.no_grad():
@@ -1254,6 +1276,7 @@ class Engine:
         pad_cpu = torch.from_numpy(pb.pad_word_np)
         em = emask.to(torch.float32).contiguous() if emask is not None else None
         enc16 = ops.ids_to_i16(enc_ids)
+        self.note_ids(enc16); self.check_ids()
         with torch.no_grad():
             for i in range(S):
                 dec16 = ops.ids_to_i16(dec)

@@ -102,6 +102,11 @@ def ids_to_i16(ids):
     return out
 
 
+def ids_check(ids16, limits, flag):
+    """flag (device int32[1]) |= 1 if any of the (..., 8) int16 ids lies outside [0, limits[column])."""
+    LIB.call('pb_ids_check', _p(ids16), ids16.numel(), _p(limits), _p(flag), _stream())
+
+
 def embed_ln_fwd(ids16, P, lin_bias, pos, ln_w, ln_b, y, mean, rstd, S, eps, seed, site, p_drop, padded=False, row_ids=None):
     T, d = y.shape
     if row_ids is not None:

@@ -186,6 +186,7 @@ class Pretrainer:
             _dist_init(self.device)
             self.reducer = GradReducer(self.engine, self.world)
         self._w = np.array([len(pianobart.e2w[k]) for k in pianobart.e2w], dtype=np.float64)   # e2w dict order (pretrain.py:185-189)
+        self._id_limits = np.array(pianobart.n_tokens, dtype=np.int64)                      # table sizes, classes order (PianoBart.py:29-31)
         # corruption stream keyed by the rank: ranks must not draw the same positions (the dropout stream is keyed in Engine)
         self._step_seed = (0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * self.rank) & 0xFFFFFFFFFFFFFFFF
         self._epoch = 0
@@ -238,6 +239,10 @@ class Pretrainer:
 
     def prepare_batch(self, ori_seq_batch):
         """pretrain.py:125-153 on the device: corrupted encoder ids, shift-right decoder ids, loss mask, attention masks."""
+        if ori_seq_batch.device.type == 'cpu':                             # nn.Embedding's IndexError (PianoBart.py:15-16), on the loader's host copy
+            a = ori_seq_batch.numpy()
+            if a.size and (a.min() < 0 or (a.reshape(-1, 8).max(0) >= self._id_limits).any()):
+                raise IndexError('index out of range in self: an Octuple id lies outside its embedding table (sizes %s)' % list(self._id_limits))
         ori = ori_seq_batch.to(self.device, non_blocking=True)
         tgt16 = ori.contiguous() if ori.dtype == torch.int16 else ops.ids_to_i16(ori.long() if ori.dtype != torch.int64 else ori)
         B, S = tgt16.shape[:2]

@@ -343,6 +343,30 @@ def test_tiny_batch_one_short_sequence():
         assert _rel(torch.cat(m(enc.cuda(), dec.cuda(), emask.cuda(), dmask.cuda()), -1), torch.cat(o(enc, dec, emask, dmask), -1)) < 1e-4
 
 
+def test_id_outside_its_table_raises_index_error_like_nn_embedding():
+    """PianoBart.py:15-16: nn.Embedding raises IndexError on an id >= its table size (and the reference's CPU path on a negative one).
+    The HIP route checks on the device and raises at the forward's own synchronisation point; valid batches are untouched."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    m = _lm(32, 64, 1, 64, 2, 3, 'fp32').eval().cuda()
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(2, 32, seed=2)]
+    with torch.no_grad():
+        m(enc, dec, emask, dmask)                                        # clean batch: no error
+        for col, bad in ((1, 134), (5, 38), (0, -1), (3, 70000)):
+            e = enc.clone(); e[1, 7, col] = bad
+            with pytest.raises(IndexError):
+                m(e, dec, emask, dmask)
+            d = dec.clone(); d[0, 3, col] = bad
+            with pytest.raises(IndexError):
+                m(enc, d, emask, dmask)
+        m(enc, dec, emask, dmask)                                        # the mark does not stick
+        o = O.PianoBartLM(O.PianoBart(O.BartConfig(max_position_embeddings=32, d_model=64, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=64,
+                                                   decoder_ffn_dim=64, encoder_attention_heads=2, decoder_attention_heads=2), E2W, W2E)).eval()
+        e = enc.cpu().clone(); e[1, 7, 1] = 134
+        with pytest.raises(IndexError):
+            o(e, dec.cpu(), emask.cpu(), dmask.cpu())                    # the checker agrees on the error type
+
+
 def test_head_without_a_loss_position_is_nan_like_the_reference():
     """pretrain.py:117 divides a head's masked loss sum by its mask count: a head with no loss position in the whole batch is 0 / 0,
     the total loss and every gradient that hangs on that head's logits become NaN. Same on the HIP path, fused and

@@ -93,6 +93,9 @@ def test_pretrainer_step_matches_oracle_on_its_own_batch():
     assert abs(mine - float(total)) / float(total) < 1e-4
     masked, pos = tr.gen_mask(batch[0], 2)
     assert masked.shape == (64, 8) and pos.shape == (64,) and int(pos.sum()) == round(64 * 0.15)
+    bad = batch.clone(); bad[2, 5, 4] = 134                               # Duration table has 134 rows: nn.Embedding's IndexError (PianoBart.py:15-16)
+    with pytest.raises(IndexError):
+        tr.prepare_batch(bad)
 
 
 def test_generation_trainer_step_matches_reference_formula():
