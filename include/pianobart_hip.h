@@ -75,9 +75,10 @@ int64_t pb_gemm_colsum_ws_floats(int32_t M, int32_t N);
 int pb_ids_to_i16(const int64_t* ids, int16_t* out, int64_t n, void* stream);
 /* Range check of (T,8) Octuple ids against the 8 table sizes (device int32[8], classes order): *flag |= 1 (device word) when an id is
  * negative or >= its table size -- what nn.Embedding answers with an IndexError (PianoBart.py:15-16). pb_ids_to_i16 writes -1
- * for a value that does not fit int16, so a checked conversion cannot alias into a valid id. The host reads the word at its next
- * synchronisation point (Engine.check_ids). */
-int pb_ids_check(const int16_t* ids16, int64_t n, const int32_t* limits8, int32_t* flag, void* stream);
+ * for a value that does not fit int16, so a checked conversion cannot alias into a valid id. An offending id is REPLACED by 0 in
+ * ids16, so that the gather kernels enqueued behind the check never leave their tables; the host reads the word at its next
+ * synchronisation point (Engine.check_ids) and raises before any result is used. */
+int pb_ids_check(int16_t* ids16, int64_t n, const int32_t* limits8, int32_t* flag, void* stream);
 int pb_embed_ln_fwd(const int16_t* ids16 /*(T,8)*/, const float* P, const int32_t* seg_off /*host, 8*/,
                     const float* lin_bias, const float* pos /*(S+2,d)*/, const float* ln_w, const float* ln_b,
                     void* y /*(T,d) dtype*/, float* mean, float* rstd, int32_t T, int32_t S, int32_t d,

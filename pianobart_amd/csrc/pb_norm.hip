@@ -683,11 +683,11 @@ __global__ void ids_to_i16_kernel(const int64_t* __restrict__ ids, int16_t* __re
     }
 }
 // nn.Embedding raises IndexError on an id outside its table (PianoBart.py:15-16); a kernel cannot, so it leaves a mark
-__global__ void ids_check_kernel(const int16_t* __restrict__ ids, long n, const int* __restrict__ limits, int* __restrict__ flag) {
+__global__ void ids_check_kernel(int16_t* __restrict__ ids, long n, const int* __restrict__ limits, int* __restrict__ flag) {
     bool bad = false;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int v = ids[i];
-        bad |= v < 0 || v >= limits[i & 7];
+        if (v < 0 || v >= limits[i & 7]) { bad = true; ids[i] = 0; }     // the gathers enqueued behind this kernel stay inside their tables
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
@@ -708,7 +708,7 @@ extern "C" int pb_ids_to_i16(const int64_t* ids, int16_t* out, int64_t n, void* 
     PB_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int pb_ids_check(const int16_t* ids16, int64_t n, const int32_t* limits8, int32_t* flag, void* stream_) {
+extern "C" int pb_ids_check(int16_t* ids16, int64_t n, const int32_t* limits8, int32_t* flag, void* stream_) {
     PB_REQUIRE(ids16 && limits8 && flag && n % 8 == 0, "pb_ids_check: null argument or n not a multiple of 8");
     if (n <= 0) return 0;
     const int grid = (int)min((long)1024, (long)((n + 255) / 256));

@@ -44,7 +44,8 @@ __global__ void sqnorm_finalize_kernel(const float* __restrict__ partials, int n
 __global__ void clip_coef_kernel(const float* __restrict__ sq, float max_norm, float gscale, float* __restrict__ coef) {
     if (threadIdx.x == 0) {
         const float total = sqrtf(sq[0]) * gscale;                       // norm of the (scaled) gradient
-        coef[0] = fminf(1.0f, max_norm / (total + 1e-6f)) * gscale;      // torch clip_grad_norm_ rule
+        const float r = max_norm / (total + 1e-6f);                      // torch clip_grad_norm_ rule: clamp(r, max=1), and clamp hands a NaN on
+        coef[0] = (r != r ? r : fminf(1.0f, r)) * gscale;                // (a NaN gradient norm poisons every parameter in the reference; fminf would drop it)
     }
 }
 

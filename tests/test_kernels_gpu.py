@@ -257,6 +257,11 @@ def test_optimizer_kernels(ops):
     x = torch.randn(1027, device='cuda', generator=g); xb = torch.empty(1027, device='cuda', dtype=torch.bfloat16); xf = torch.empty(1027, device='cuda')
     ops.cast_f32_to_bf16(x, xb); ops.cast_bf16_to_f32(xb, xf)
     assert torch.equal(xb, x.to(torch.bfloat16)) and torch.equal(xf, xb.float())
+    # degenerate norms follow torch.nn.utils.clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1) hands a NaN on, an infinite norm gives 0
+    for bad, want in ((float('nan'), float('nan')), (float('inf'), 0.0), (0.0, 1.0)):
+        sq.fill_(bad); ops.clip_coef(sq, 3.0, 1.0, coef)
+        ref = torch.clamp(torch.tensor(3.0) / (torch.tensor(bad).sqrt() + 1e-6), max=1.0)
+        assert (torch.isnan(coef).item() and torch.isnan(ref).item()) if want != want else float(coef) == float(ref) == want
 
 
 @pytest.mark.parametrize('hd', [32, 64, 96, 128])

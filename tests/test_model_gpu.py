@@ -367,6 +367,28 @@ def test_id_outside_its_table_raises_index_error_like_nn_embedding():
             o(e, dec.cpu(), emask.cpu(), dmask.cpu())                    # the checker agrees on the error type
 
 
+def test_missing_masks_and_other_mask_dtypes():
+    """PianoBart.forward's masks default to None (= everything visible, modeling_bart.py) and callers hand over float, bool or integer
+    0 / 1 masks: same logits as the oracle for every spelling."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    m = _lm(48, 64, 2, 128, 4, 13, 'fp32').eval()
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(max_position_embeddings=48, d_model=64, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=128,
+                                               decoder_ffn_dim=128, encoder_attention_heads=4, decoder_attention_heads=4), E2W, W2E)).eval()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda()
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(3, 48, seed=4)
+    with torch.no_grad():
+        ref_none = torch.cat(o(enc, dec, None, None), -1)
+        assert _rel(torch.cat(m(enc.cuda(), dec.cuda()), -1), ref_none) < 1e-4
+        assert _rel(torch.cat(m(enc.cuda(), dec.cuda(), None, dmask.cuda()), -1), torch.cat(o(enc, dec, None, dmask), -1)) < 1e-4
+        ref = torch.cat(o(enc, dec, emask, dmask), -1)
+        for cast in (lambda t: t.bool(), lambda t: t.long(), lambda t: t.to(torch.int32), lambda t: t.double(), lambda t: t.half()):
+            assert _rel(torch.cat(m(enc.cuda(), dec.cuda(), cast(emask).cuda(), cast(dmask).cuda()), -1), ref) < 1e-4
+        # int32 / int16 ids instead of int64 (the loader's shards)
+        assert _rel(torch.cat(m(enc.int().cuda(), dec.short().cuda(), emask.cuda(), dmask.cuda()), -1), ref) < 1e-4
+
+
 def test_head_without_a_loss_position_is_nan_like_the_reference():
     """pretrain.py:117 divides a head's masked loss sum by its mask count: a head with no loss position in the whole batch is 0 / 0,
     the total loss and every gradient that hangs on that head's logits become NaN. Same on the HIP path, fused and
