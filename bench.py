@@ -8,7 +8,9 @@ A "step" = one pass of the hot path over one resident synthetic Octuple batch: f
 dropout 0.1 active) -> fused 8-head CE/argmax/acc -> full backward -> [RCCL gradient all-reduce] ->
 clip(3.0) -> HF AdamW (+ bf16 shadow refresh). Corrupted inputs, decoder inputs, loss mask and
 attention masks are already in HBM when the timed region starts (corruption excluded).
-Workload at N=1 = BASELINE.json configs[1]: 12L/768d/ffn3072/12 heads, S=1024, B=32, bf16.
+Workload at N=1 = BASELINE.json configs[1]: 12L/768d/ffn3072/12 heads, S=1024, B=32, bf16 (the synthetic batch of SURVEY 8d,
+seed 1234). N>1 (configs[2], weak scaling): ONE global batch of N x 32 sequences from the same seed, dealt to the ranks by
+sequence length exactly as the pre-training loop's BalancedDistributedSampler deals its global batches (rank_share below).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -46,10 +48,26 @@ def train_flops_live_rows(Te, Td, pairs, d, N, f, V=1280, Ts=None):
     return 3 * 2 * macs
 
 
-def synth_batch(B, S, seed, device):
+def rank_share(lengths, world, rank):
+    """Which samples of a global batch rank `rank` steps: sorted by non-PAD length, dealt in snake order (0..W-1, W-1..0, ...), i.e. what
+    pianobart_amd.data.BalancedDistributedSampler hands the ranks of the real pre-training loop. The packed step drops a sample's PAD
+    rows, so a rank's step time follows its samples' lengths and the ranks meet at every gradient exchange."""
+    import numpy as np
+    order = np.argsort(-np.asarray(lengths), kind='stable')
+    per = len(order) // world
+    return [int(order[j * world + (rank if j % 2 == 0 else world - 1 - rank)]) for j in range(per)]
+
+
+def synth_rank_batch(B, S, world, rank, device):
+    """SURVEY 8(d)'s synthetic batch. One GPU: B sequences from seed 1234. N GPUs (weak scaling): every rank draws the same GLOBAL
+    batch of N x B sequences from seed 1234 and keeps its share of it (rank_share)."""
     sys.path.insert(0, os.path.join(ROOT))
     from tests.golden_util import synth_octuple_batch
-    return [t.to(device) for t in synth_octuple_batch(B, S, seed)]
+    t = synth_octuple_batch(B * world, S, 1234)
+    if world > 1:
+        idx = torch.tensor(rank_share(t[3].sum(1).numpy(), world, rank), dtype=torch.long)
+        t = [x[idx].contiguous() for x in t]
+    return [x.to(device) for x in t]
 
 
 def cpu_baseline_child(cfgkw, S):
@@ -411,7 +429,7 @@ def main():
     if args.mode == 'decode':
         return decode_bench(args, model, eng, dev, rank)
     B, S = args.batch, args.seq
-    enc, dec, loss_mask, emask, dmask, target = synth_batch(B, S, seed=1234 + rank, device=dev)
+    enc, dec, loss_mask, emask, dmask, target = synth_rank_batch(B, S, world, rank, dev)
     enc16, dec16, tgt16 = ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target)
     loss_mask = loss_mask.contiguous()
     reducer = GradReducer(eng, world) if (world > 1 or args.force_reducer) else None

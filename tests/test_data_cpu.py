@@ -220,3 +220,23 @@ def test_balanced_sampler_deals_global_batches_by_length():
     s2 = [BalancedDistributedSampler(L[:203], W, r, G, shuffle=False) for r in range(W)]
     c = [list(iter(s)) for s in s2]
     assert all(len(x) == 26 for x in c) and set(i for x in c for i in x) == set(range(203))
+
+
+def test_bench_deals_the_global_synthetic_batch_by_length():
+    """bench.py --gpus N: every rank draws the same global batch (seed 1234) and keeps its snake-dealt share -- each sample on exactly one
+    rank, the per-rank row counts within a fraction of a percent (per-rank seeds: 6 %), one GPU: the plain batch of seed 1234."""
+    import importlib.util
+    import numpy as np
+    from tests.golden_util import synth_octuple_batch
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    S, B = 256, 8
+    for world in (1, 2, 4, 8):
+        full = synth_octuple_batch(B * world, S, 1234)
+        shares = [bench.synth_rank_batch(B, S, world, r, 'cpu') for r in range(world)]
+        rows = sorted(tuple(x.reshape(-1).tolist()) for sh in shares for x in sh[5])
+        assert rows == sorted(tuple(x.reshape(-1).tolist()) for x in full[5])               # a permutation of the global batch
+        tot = np.array([float(sh[3].sum()) for sh in shares])
+        assert all(sh[0].shape[0] == B for sh in shares) and (tot.max() - tot.min()) <= 0.02 * tot.mean()
+    one = bench.synth_rank_batch(B, S, 1, 0, 'cpu')
+    assert all(torch.equal(a, b) for a, b in zip(one, synth_octuple_batch(B, S, 1234)))
