@@ -20,7 +20,7 @@ extern "C" {
 #define PB_F32 0
 #define PB_BF16 1
 
-#define PB_ABI_VERSION 3
+#define PB_ABI_VERSION 4   /* 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check; pb_ids_to_i16 writes -1 for a value that is not an int16 */
 int pb_abi_version(void);
 const char* pb_last_error(void);
 
