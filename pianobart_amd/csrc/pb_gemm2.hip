@@ -275,7 +275,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const Gemm2Args p) 
     const int wm = wave / WN, wn = wave % WN;
     int m0, n0, zs;
     block_tile<BM, BN>(p, blockIdx.x, m0, n0, zs);
-    const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
+    const int z = blockIdx.y;                                           // the division runs on the vector unit: back to scalars, or the
+    const int z1 = __builtin_amdgcn_readfirstlane(z / p.nb2), z2 = __builtin_amdgcn_readfirstlane(z % p.nb2);   // 64-bit batch offsets live in VGPRs across the K loop (2 spilled)
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
     const long coff = z1 * p.sC1 + z2 * p.sC2 + zs * p.sCz;
@@ -420,7 +421,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         }
     };
     item(L);
-    const int z = blockIdx.y, z1 = z / p.nb2, z2 = z % p.nb2;
+    const int z = blockIdx.y;                                           // the division runs on the vector unit: back to scalars, or the
+    const int z1 = __builtin_amdgcn_readfirstlane(z / p.nb2), z2 = __builtin_amdgcn_readfirstlane(z % p.nb2);   // 64-bit batch offsets live in VGPRs across the K loop (2 spilled)
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
 
@@ -723,6 +725,10 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // (A 256 x 192 instantiation -- 512 tiles = 2 full rounds at N = 768, T = 32768 -- measured +4-6 % back to back and -1.5 ms on the whole
     // step in round 2: every A row panel is then streamed by 4 column tiles instead of 3. It lost its A/B and was removed in round 3.)
     constexpr bool wide192 = false;
+    // the ping-pong kernel is instantiated for the two layouts the step uses (NT: both operands K-contiguous; TN: neither). The mixed
+    // layouts (NN dgrad without the transposed weight copies: PB_DGRAD_NT=0) take the one-barrier 256 x 256 kernel: their ping-pong
+    // instantiations kept two VGPRs in scratch around the K loop (code-object metadata) and are not built any more.
+    const bool pingpong = big && !(d->flags & 2048) && a_kc == b_kc;
     const int BMs = big ? 256 : 128, BNs = big ? (wide192 ? 192 : 256) : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
     a.nsplit = nsplit;
@@ -736,7 +742,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     } while (0)
     bool cs_fused = false;
     a.n_full = 0; a.tail_split = 1; a.tail_kc = 0; a.tail_slabs = nullptr;
-    if (big && (d->flags & PB_GEMM_TAIL_SPLIT) && !(d->flags & 2048) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 && !d->colsum_out &&
+    if (pingpong && (d->flags & PB_GEMM_TAIL_SPLIT) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 && !d->colsum_out &&
         !(d->flags & (PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | 128))) {
         // The persistent grid runs ceil(tiles / CUs) rounds; a last round that fills only part of the chip (N = 768: 312 tiles =
         // 1.22 rounds at 26 624 rows, 384 = 1.5 at 32 768) costs a whole one. Cut those tiles' K range so that they occupy the CUs
@@ -774,7 +780,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // 1.53 nk + 6.5, a round of the 128 x 128 kernel 0.75 nk + 4 (one workgroup per CU) or 1.0 nk + 4 (two), a kernel boundary 2.
     Gemm2Args rest;
     bool row_split = false;
-    if (big && a.tail_split == 1 && (d->flags & PB_GEMM_ROW_SPLIT) && !(d->flags & (2048 | 4096 | 128)) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 &&
+    if (pingpong && a.tail_split == 1 && (d->flags & PB_GEMM_ROW_SPLIT) && !(d->flags & (4096 | 128)) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 &&
         !d->colsum_out && d->M % 8 == 0) {
         const int ncu = pb_num_cus(), ntile = a.tiles_m * a.tiles_n, rounds = ntile / ncu, rem = ntile % ncu, nkt = d->K / BK;
         if (rounds >= 1 && rem > 0) {
@@ -799,7 +805,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
             }
         }
     }
-    if (big && !(d->flags & 2048)) {
+    if (pingpong) {
         if (d->colsum_out && nsplit == 1 && nb1 * a.nb2 == 1) {
             float* slice = pb_defer_alloc((size_t)2 * a.tiles_m * d->N);          // deferred reduction: the partial rows must outlive this call
             a.cs_ws = slice ? slice : d->colsum_ws;
@@ -814,9 +820,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         hipLaunchKernelGGL(kfn, pgrid, dim3(512), 131072 + 2048, stream, a);                                              \
         if (a.tail_split > 1) hipLaunchKernelGGL(tail_finish_kernel<4>, dim3((grid.x - a.n_full) * TAIL_FIN_PARTS), dim3(256), 0, stream, a); \
     } while (0)
-        if (a_kc && b_kc) PB_G3_LAUNCH(true, true);
-        else if (a_kc && !b_kc) PB_G3_LAUNCH(true, false);
-        else if (!a_kc && b_kc) PB_G3_LAUNCH(false, true);
+        if (a_kc) PB_G3_LAUNCH(true, true);
         else PB_G3_LAUNCH(false, false);
 #undef PB_G3_LAUNCH
     } else if (big) {
