@@ -181,6 +181,56 @@ def test_replay_batch_construction_matches_reference(ops):
     assert np.array_equal((dec16[:, :, 0] != 256).float().cpu().numpy(), z['batch_dmask'])
 
 
+def test_replay_against_the_oracle_on_random_and_degenerate_sequences(ops):
+    """Differential run beyond the 25 golden cases: 5 corruptions x 48 sequences -- random Octuple rows of every length from one EOS
+    row to a full window, single-bar pieces, pieces whose every row opens a new bar, all-PAD windows -- each corrupted by the oracle's
+    restatement of pretrain.py:211-546 under its own seed, its random decisions replayed through pb_corrupt_replay: rows and loss mask
+    bit for bit."""
+    import random
+    from oracle import pianobart_oracle as O
+    from tests.golden_util import load_vocab
+    e2w, w2e = load_vocab()
+    S = 64
+    pb = O.PianoBart(O.BartConfig(max_position_embeddings=S, d_model=32, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=64,
+                                  decoder_ffn_dim=64, encoder_attention_heads=4, decoder_attention_heads=4), e2w, w2e)
+    corr = O.Corruptor(pb, S, 0.15)
+    rng = np.random.default_rng(99)
+    hi = np.array([256, 128, 129, 256, 128, 32, 254, 49])
+    pad, eos = pb.pad_word_np.astype(np.int64), pb.eos_word_np.astype(np.int64)
+
+    def piece(L, bars):
+        x = np.tile(pad, (S, 1))
+        if L > 0:
+            body = rng.integers(0, hi, size=(L, 8))
+            if bars == 'one':
+                body[:, 0] = 3
+            elif bars == 'every':
+                body[:, 0] = np.arange(L) % 256
+            else:
+                body[:, 0] = np.minimum(np.cumsum(rng.random(L) < 0.2), 255)
+            x[:L] = body
+            x[L - 1] = eos
+        return x
+    lengths = [0, 1, 2, 3, 5, 8, 13, 21, 34, 55, 63, 64]
+    seqs = [piece(L, b) for L in lengths for b in ('walk', 'one', 'every')] + [piece(int(rng.integers(2, S + 1)), 'walk') for _ in range(12)]
+    cases = []
+    for k, x in enumerate(seqs):
+        for choice in range(1, 6):
+            random.seed(1000 + 7 * k + choice); np.random.seed(1000 + 7 * k + choice)
+            corr.trace = {}
+            masked, pos = corr.gen_mask(torch.from_numpy(x).long(), choice)
+            tr = corr.trace
+            cases.append(dict(ids=x.astype(np.int64), choice=tr['choice'], dec=tr['dec'], rand_rows=tr.get('rand_rows'),
+                              masked=np.asarray(masked).astype(np.int64), pos=np.asarray(pos).astype(np.int64).reshape(S, -1)[:, 0]))
+    corr.trace = None
+    for lo in range(0, len(cases), 60):
+        chunk = cases[lo:lo + 60]
+        out, lm = _replay(ops, chunk)
+        for b, c in enumerate(chunk):
+            assert np.array_equal(out[b], c['masked']), ('rows', c['choice'], lo + b)
+            assert np.array_equal(lm[b], np.repeat(c['pos'][:, None], 8, 1).astype(np.float32)), ('loss mask', c['choice'], lo + b)
+
+
 def test_philox_and_replay_share_the_apply_stage(ops, batch):
     """Decisions read back from a Philox run (what was deleted / masked / where rows went) and replayed give the identical output:
     the two DECIDE sources feed one APPLY stage."""
