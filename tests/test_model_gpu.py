@@ -389,6 +389,61 @@ def test_missing_masks_and_other_mask_dtypes():
         assert _rel(torch.cat(m(enc.int().cuda(), dec.short().cuda(), emask.cuda(), dmask.cuda()), -1), ref) < 1e-4
 
 
+@pytest.mark.parametrize('S,d,Le,Ld,fe,fd,h,B', [
+    (8, 64, 1, 1, 64, 64, 2, 1),            # head_dim 32, one short window
+    (24, 96, 1, 2, 160, 96, 1, 3),          # one head of 96; decoder deeper than the encoder; ffn not a multiple of 64
+    (40, 128, 2, 1, 200, 328, 4, 2),        # ffn sizes that are multiples of 8 only
+    (100, 192, 1, 1, 384, 384, 2, 2),       # head_dim 96
+    (130, 256, 1, 1, 512, 256, 2, 2),       # head_dim 128, S not a multiple of 64
+    (57, 320, 1, 1, 640, 640, 5, 3),        # d = 320, 5 heads
+    (33, 64, 1, 1, 96, 96, 4, 2),           # head_dim 16
+    (77, 48, 1, 1, 72, 72, 2, 2),           # head_dim 24, d = 48
+])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_shape_sweep_forward_loss_and_gradients_against_the_oracle(S, d, Le, Ld, fe, fd, h, B, precision):
+    """Shapes off the beaten path (odd sequence lengths, head_dim 16 ... 128, ffn sizes that are not tile multiples, unequal encoder /
+    decoder depth and width): the exact-f32 instantiation agrees with the oracle on logits, loss and every parameter gradient (the bf16
+    one within its looser bound: logits 8e-2, loss 2e-2, gradient norm 1e-1) -- or the library says loudly that it does not cover the
+    shape; never a silent difference."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from pianobart_amd._lib import PBError
+    kw = dict(max_position_embeddings=S, d_model=d, encoder_layers=Le, decoder_layers=Ld, encoder_ffn_dim=fe, decoder_ffn_dim=fd,
+              encoder_attention_heads=h, decoder_attention_heads=h, dropout=0.0)
+    m = PianoBartLM(PianoBart(BartConfig(**kw), E2W, W2E, precision=precision))
+    randomize_params(m, 5)
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(**kw), E2W, W2E)).train()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.train().cuda()
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(B, S, seed=S + d, min_len=max(2, S // 3))
+    try:
+        y = m(enc.cuda(), dec.cuda(), emask.cuda(), dmask.cuda())
+        tot, *_ = O.pretrain_loss(y, target.cuda(), loss_mask.cuda(), E2W)
+        tot.backward()
+    except (PBError, RuntimeError) as e:
+        assert 'pb_' in str(e) or 'pianobart' in str(e).lower(), e         # a refusal must name its origin
+        pytest.skip('shape refused loudly: %s' % str(e)[:120])
+    yo = o(enc, dec, emask, dmask)
+    tot_o, *_ = O.pretrain_loss(yo, target, loss_mask, E2W)
+    tot_o.backward()
+    f32 = precision == 'fp32'
+    assert _rel(torch.cat(y, -1).detach(), torch.cat(yo, -1).detach()) < (1e-4 if f32 else 8e-2)
+    assert abs(float(tot.detach()) - float(tot_o.detach())) / float(tot_o.detach()) < (1e-4 if f32 else 2e-2)
+    go = {k: p.grad for k, p in o.named_parameters() if p.grad is not None}
+    gm = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(go) == sorted(gm)
+    if not f32:
+        n_o = float(torch.sqrt(sum((g.double() ** 2).sum() for g in go.values())))
+        n_m = float(torch.sqrt(sum((g.double().cpu() ** 2).sum() for g in gm.values())))
+        assert abs(n_m - n_o) / n_o < 1e-1
+        return
+    scale = max(float(g.abs().max()) for g in go.values())
+    for k, g in go.items():
+        err = float((gm[k].cpu().double() - g.double()).abs().max())
+        assert err < 2e-3 * max(float(g.abs().max()), 1e-3 * scale), (k, err, float(g.abs().max()))
+
+
 def test_head_without_a_loss_position_is_nan_like_the_reference():
     """pretrain.py:117 divides a head's masked loss sum by its mask count: a head with no loss position in the whole batch is 0 / 0,
     the total loss and every gradient that hangs on that head's logits become NaN. Same on the HIP path, fused and
