@@ -207,6 +207,37 @@ def test_g8_generate_trace():
     assert np.array_equal(out.cpu().numpy(), z['tokens'])
 
 
+@pytest.mark.parametrize('seed', list(range(8)))
+def test_generate_against_the_oracle_on_random_prompts(seed):
+    """model.py:28-107 beyond the one golden trace: random weights, random prompts of every length (one row ... the full window), the
+    global np.random stream seeded alike on both sides -- the HIP decode (K/V caches, one token per step) emits the oracle's tokens
+    (encoder + decoder re-run per position, as the reference does), early stop and PAD fill included, and leaves the RNG where the
+    oracle leaves it."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    S = 20
+    m = _lm(S, 64, 1 + seed % 2, 128, 2 + 2 * (seed % 2), 50 + seed, 'fp32').eval()
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(max_position_embeddings=S, d_model=64, encoder_layers=1 + seed % 2, decoder_layers=1 + seed % 2,
+                                               encoder_ffn_dim=128, decoder_ffn_dim=128, encoder_attention_heads=2 + 2 * (seed % 2),
+                                               decoder_attention_heads=2 + 2 * (seed % 2)), E2W, W2E)).eval()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda()
+    L = [1, 2, 5, 9, 13, 17, 19, 20][seed]
+    enc = synth_octuple_batch(1, S, seed=200 + seed, min_len=L)[5]
+    pad = torch.from_numpy(m.pianobart.pad_word_np)
+    enc[0, L:] = pad                                                       # a prompt of exactly L rows
+    emask = (enc[:, :, 0] != int(m.pianobart.bar_pad_word)).float()
+    with torch.no_grad():
+        np.random.seed(777 + seed)
+        want = o(enc, None, emask, None, generate=True, device_num=-1)
+        st_o = np.random.get_state()[1].copy()
+        np.random.seed(777 + seed)
+        got = m(enc.cuda(), None, emask.cuda(), None, generate=True, device_num=0)
+        st_m = np.random.get_state()[1].copy()
+    assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want.numpy())
+    assert np.array_equal(st_o, st_m)
+
+
 def test_g10_cfg2_shape_spot_check():
     """cfg-2 model shape (12L/768/ffn3072/12 heads, S=1024, B=1) against vectors captured from the reference."""
     _need_gpu()
