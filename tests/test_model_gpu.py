@@ -162,6 +162,53 @@ def test_g4_fused_step_matches_golden_adamw():
     assert np.allclose(psum, z['adamw_param_sum'], rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize('lr', [2e-5, 1e-3])
+def test_five_training_steps_follow_the_oracle(lr):
+    """pretrain.py:159-196 five times over (fresh batch each step, dropout 0): forward, masked 8-head CE, backward, clip at 3.0, HF AdamW
+    with its moments carried from step to step -- the fused HIP loop (pipelined parameter update included) ends on the oracle's
+    parameters. lr 1e-3 makes the steps large enough that a wrong bias correction or decay order would show."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    from pianobart_amd import ops
+    m = _lm(48, 64, 2, 128, 4, 61, 'fp32', dropout=0.0).train()
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(max_position_embeddings=48, d_model=64, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=128,
+                                               decoder_ffn_dim=128, encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.0), E2W, W2E)).train()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    eng.pipeline_updates = True
+    params = [p for p in o.parameters()]
+    live = mo = vo = None
+    for step in range(1, 6):
+        enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(3, 48, seed=300 + step)
+        o.zero_grad()
+        tot, *_ = O.pretrain_loss(o(enc, dec, emask, dmask), target, loss_mask, E2W)
+        tot.backward()
+        if live is None:
+            live = [p for p in params if p.grad is not None]
+            mo = [torch.zeros_like(p) for p in live]; vo = [torch.zeros_like(p) for p in live]
+        grads = [p.grad for p in live]
+        O.clip_grad_norm(grads, 3.0)
+        with torch.no_grad():
+            O.hf_adamw_step([p.data for p in live], grads, mo, vo, step=step, lr=lr)
+        g = [t.cuda() for t in (enc, dec, loss_mask, emask, dmask, target)]
+        sums = eng.loss_and_grads(ops.ids_to_i16(g[0]), ops.ids_to_i16(g[1]), ops.ids_to_i16(g[5]), g[2].contiguous(), g[3], g[4], train=True)
+        eng.optimizer_step(lr=lr)
+        s = sums.double().cpu()
+        w = torch.tensor(O.loss_weights(E2W), dtype=torch.double)
+        assert abs(float(((s[0:8] / s[8:16]) * w).sum() / w.sum()) - float(tot.detach())) / float(tot.detach()) < 2e-4, step
+    eng.finish_updates()
+    torch.cuda.synchronize()
+    po = dict(o.named_parameters())
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if po[k].grad is None:
+            continue
+        worst = max(worst, _rel(p.detach(), po[k].detach()))
+    assert worst < (2e-5 if lr < 1e-4 else 2e-3), worst
+
+
 def test_dropout_train_step_is_consistent():
     """Dropout active (p=0.1): forward mask == backward mask. Check by finite differences on one bias."""
     _need_gpu()
