@@ -467,7 +467,11 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if os.environ.get('PB_LONG_RUN_DUMP') and rank == 0:             # developer aid (tools/long_run.py): the step times in order
+        with open(os.environ['PB_LONG_RUN_DUMP'], 'w') as fh:
+            json.dump(per_step, fh)
+    per_step.sort()
     ms_median = per_step[len(per_step) // 2]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
