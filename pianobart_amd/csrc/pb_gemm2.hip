@@ -726,7 +726,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // step in round 2: every A row panel is then streamed by 4 column tiles instead of 3. It lost its A/B and was removed in round 3.)
     constexpr bool wide192 = false;
     // the ping-pong kernel is instantiated for the two layouts the step uses (NT: both operands K-contiguous; TN: neither). The mixed
-    // layouts (NN dgrad without the transposed weight copies: PB_DGRAD_NT=0) take the one-barrier 256 x 256 kernel: their ping-pong
+    // layouts (NN dgrad without the transposed weight copies) take the one-barrier 256 x 256 kernel: their ping-pong
     // instantiations kept two VGPRs in scratch around the K loop (code-object metadata) and are not built any more.
     const bool pingpong = big && !(d->flags & 2048) && a_kc == b_kc;
     const int BMs = big ? 256 : 128, BNs = big ? (wide192 ? 192 : 256) : 128;

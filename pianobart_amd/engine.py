@@ -23,11 +23,11 @@ from . import ops, rowpack
 from ._lib import LIB, PB_BF16, PB_F32, PBError
 
 _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second HIP stream, bits: 1 = weight-gradient GEMMs, 2 = cross-attention K/V projections, 4 = backward GEMMs as ordinary grids (0: everything on one stream, for A/B)
-_WG_TARGET = int(os.environ.get('PB_WG_TARGET', '192' if _WGRAD_STREAM & 1 else '256'))            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
-_NO_DEFER = bool(int(os.environ.get('PB_NO_DEFER', '0')))                  # developer aid: reduce every bias / LayerNorm gradient right behind its producer (A/B)
-_DECODE_SPLIT = bool(int(os.environ.get('PB_DECODE_SPLIT', '1')))              # developer aid: 0 = single-query attention with one workgroup per head (A/B)
+_WG_TARGET = 192 if _WGRAD_STREAM & 1 else 256            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
+_NO_DEFER = False                  # settled (round 2): True reduces every bias / LayerNorm gradient right behind its producer
+_DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
 _DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token, 0 = the same fused launches issued directly, -1 = the round-2 per-launch loop
-_NO_FUSED_BIAS = bool(int(os.environ.get('PB_NO_FUSED_BIAS', '0')))     # developer aid: A/B the bias gradients fused into the GEMM / attention epilogues
+_NO_FUSED_BIAS = False             # settled (round 2): True takes the bias gradients out of the GEMM / attention epilogues
 
 LN_EPS = 1e-5
 
@@ -38,8 +38,8 @@ _RING = 2
 # events that order the two streams: HIP events without the system-scope fence (hipEventDisableSystemFence: 59.5 -> 59.1 ms/step
 # against plain hipEventDisableTiming events; hipEventReleaseToDevice: no gain)
 _EVENT_MODE = 1
-_SIDE_TAIL = int(os.environ.get('PB_SIDE_TAIL', '1'))  # end of backward: decoder half of dP, the deferred reductions and one f32 GEMM on the second stream
-_DGRAD_NT = int(os.environ.get('PB_DGRAD_NT', '1'))    # backward dX = dY W from transposed weight copies (NT GEMM) instead of the NN form
+_SIDE_TAIL = 1   # settled (round 2). End of backward: decoder half of dP, the deferred reductions and one f32 GEMM on the second stream
+_DGRAD_NT = 1    # settled (round 2): backward dX = dY W from transposed weight copies (NT GEMM) instead of the NN form
 _FWD_GEMM_FLAGS = int(os.environ.get('PB_FWD_GEMM_FLAGS', '32768'))      # PB_GEMM_TAIL_SPLIT for the forward projections (0: off)
 # dead-row compaction of the fused pre-train step (Engine._pack_batch): PB_PACK_ROWS=0 keeps every step dense
 _PACK_ROWS = int(os.environ.get('PB_PACK_ROWS', '1'))
