@@ -665,7 +665,7 @@ def test_decode_at_cfg2_size_matches_teacher_forced_full_pass(precision, tol):
         assert float((a == b).float().mean()) > 0.995
 
 
-@pytest.mark.parametrize('d,heads,S', [(256, 4, 200), (256, 2, 96), (512, 8, 72)])
+@pytest.mark.parametrize('d,heads,S', [(256, 4, 200), (256, 2, 96), (512, 8, 72), (1024, 8, 40), (768, 12, 130)])
 def test_graph_decode_equals_the_per_launch_decode(monkeypatch, d, heads, S):
     """Round 3: one hipGraph replay per token (position in device memory, q / k / v projections fused into the split single-query
     attention, 6 launches per layer) against (a) the same launches issued directly: bit-identical logits rows, and (b) the round-2
