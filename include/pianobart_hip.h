@@ -186,6 +186,28 @@ int pb_flash_bwd_packed(const void* q, const void* k, const void* v, const void*
                         int64_t dq_ss, int64_t dk_ss, int64_t dv_ss, float scale, int32_t causal,
                         float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* stream);
 
+/* ---- K4b: attention backward in ONE pass (pb_flash1.hip, head_dim 64) -------------------------------
+ * Same math, arguments and results (to bf16 rounding) as pb_flash_bwd / pb_flash_bwd_packed, computed key-stationary: a workgroup
+ * owns 256 keys of one (batch, head), keeps their dK / dV in accumulator registers and sweeps the query tiles once (5 matrix
+ * products and one exp pass per (query, key) pair instead of 7 and 2). dQ is summed over the key blocks without atomics: block j
+ * writes its partial into bf16 slab j of dq_ws (pb_flash_bwd1_ws_bytes(rows of the q side, H, hd, Sk_max) bytes; packed rows:
+ * q_rows = rows of the q tensor), a second kernel adds a row's slabs in f32 in block order and rounds once. Deterministic.
+ * Replaces the autograd backward of tf:modeling_bart.py:115-140 like K4. */
+int64_t pb_flash_bwd1_ws_bytes(int64_t rows, int32_t H, int32_t hd, int32_t Sk_max);
+int pb_flash_bwd1(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                  const float* key_mask, const int32_t* kmax, void* dq, void* dk, void* dv, float* delta,
+                  int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss,
+                  int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss,
+                  int64_t dq_sb, int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss,
+                  float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws,
+                  void* dq_ws, void* stream);
+int pb_flash_bwd1_packed(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                         void* dq, void* dk, void* dv, float* delta, const int32_t* q_off, const int32_t* q_len,
+                         const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H,
+                         int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss,
+                         int64_t dq_ss, int64_t dk_ss, int64_t dv_ss, float scale, int32_t causal,
+                         float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* dq_ws, int64_t q_rows, void* stream);
+
 /* ---- row maps for the packed step (pb_rowmap.hip) ------------------------------------------------
  * pb_rowmap_count: counts (B,8) int32 = {encoder rows visible as keys (emask != 0), decoder rows visible as keys (dmask != 0),
  *   decoder live rows (visible, or loss_mask (B,S,8) row != 0), 1 iff the visible decoder positions are exactly 0 .. L-1,

@@ -270,6 +270,41 @@ def flash_bwd_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, s
              _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _stream())
 
 
+_fa1_ws = {}
+
+
+def _flash1_ws(nbytes, device):
+    """The dQ slab workspace of the one-pass backward (one per device, grown on demand)."""
+    ws = _fa1_ws.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = _fa1_ws[device] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def flash_bwd1(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal, kmax=None, dbias=None, dbias_ws=None):
+    """pb_flash_bwd1: flash_bwd's arguments and results, one pass over the (key block, query tile) pairs (head_dim 64)."""
+    (qt, qo, qs, qb), (kt, ko, ks, kb), (vt, vo, vs, vb), (ot, oo, os_, ob) = q, k, v, o
+    (dqt, dqo, dqs, dqb), (dkt, dko, dks, dkb), (dvt, dvo, dvs, dvb) = dq, dk, dv
+    pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 2 * off)
+    ws = _flash1_ws(int(LIB.query('pb_flash_bwd1_ws_bytes', B * Sq, H, hd, Sk)), qt.device)
+    LIB.call('pb_flash_bwd1', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), _p(key_mask), _p(kmax), pp(dqt, dqo),
+             pp(dkt, dko), pp(dvt, dvo), _p(delta), B, H, Sq, Sk, hd, qb, qs, kb, ks, vb, vs, ob, os_, dqb, dqs, dkb, dks, dvb, dvs,
+             scale, int(causal), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
+             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(ws), _stream())
+
+
+def flash_bwd1_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, scale, causal, q_rows, dbias=None, dbias_ws=None):
+    """pb_flash_bwd1_packed: flash_bwd_packed's arguments and results in one pass; q_rows = rows of the q-side tensors."""
+    (qt, qo, qs), (kt, ko, ks), (vt, vo, vs), (ot, oo, os_) = q, k, v, o
+    (dqt, dqo, dqs), (dkt, dko, dks), (dvt, dvo, dvs) = dq, dk, dv
+    pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 2 * off)
+    ws = _flash1_ws(int(LIB.query('pb_flash_bwd1_ws_bytes', q_rows, H, hd, rows.Sk_max)), qt.device)
+    LIB.call('pb_flash_bwd1_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), pp(dqt, dqo), pp(dkt, dko), pp(dvt, dvo),
+             _p(delta), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off), _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd,
+             qs, ks, vs, os_, dqs, dks, dvs, scale, int(causal), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
+             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(ws), q_rows, _stream())
+
+
 def rowmap_count(emask, dmask, loss_mask, counts):
     B, S = emask.shape
     LIB.call('pb_rowmap_count', _p(emask), _p(dmask), _p(loss_mask), _p(counts), B, S, _stream())
