@@ -13,7 +13,7 @@ ARCH = 'gfx950'
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc parks them in AGPRs
 # and every VALU touch of an accumulator (softmax rescale, epilogues) costs a v_accvgpr_read/write pair.
 FLAGS = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-ffp-contract=fast', '-Wno-unused-result',
-         '-mllvm', '-amdgpu-mfma-vgpr-form=1']
+         '-mllvm', '-amdgpu-mfma-vgpr-form=1'] + os.environ.get('PB_EXTRA_HIPCC_FLAGS', '').split()      # e.g. -DPB_FA1_STAMPS (diagnostic build)
 
 
 def _hipcc():

@@ -713,6 +713,6 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* o, c
 
 // floats of workspace for the fused bias gradients of pb_flash_bwd (head_dim 64 / 96 / 128)
 extern "C" int64_t pb_flash_bias_ws_floats(int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd) {
-    const int kt_ = hd == 64 ? 2 : 1, nkb = (Sk + 64 * kt_ - 1) / (64 * kt_), nqb = (Sq + 127) / 128;
+    const int kt_ = hd == 64 ? 2 : 1, nkb = (Sk + 64 * kt_ - 1) / (64 * kt_), nqb = (Sq + 63) / 64;      // 64-row query chunks: the one-pass backward's partial rows (pb_flash1.hip)
     return (int64_t)B * H * hd * (2 * nkb + nqb);
 }
