@@ -20,7 +20,7 @@ extern "C" {
 #define PB_F32 0
 #define PB_BF16 1
 
-#define PB_ABI_VERSION 4   /* 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check; pb_ids_to_i16 writes -1 for a value that is not an int16 */
+#define PB_ABI_VERSION 5   /* 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
 int pb_abi_version(void);
 const char* pb_last_error(void);
 
@@ -174,17 +174,20 @@ int64_t pb_flash_bias_ws_floats(int32_t B, int32_t H, int32_t Sq, int32_t Sk, in
  * k / v / dk / dv; the first k_vis[b] key rows of the batch are the visible ones (the rest receive no gradient and are seen
  * by no query). causal: key row j is visible to query row i of the same batch iff j <= i (row indices within the batch) and
  * j < k_vis[b]. Sq_max / Sk_max: maxima of q_len / k_len (grid and LDS sizing); lse and delta are (B, H, Sq_max) f32.
- * dbias_ws: pb_flash_bias_ws_floats(B, H, Sq_max, Sk_max, hd) floats. All five descriptors are device int32 (B). */
+ * dbias_ws: pb_flash_bias_ws_floats(B, H, Sq_max, Sk_max, hd) floats. All five descriptors are device int32 (B).
+ * bh_order (device int32, B * H entries, or NULL): the order in which the grid takes the (batch, head) pairs (entry = b * H + h). Costs
+ * spread 4x over a packed batch; a caller that lists the pairs longest first, dealt eight at a time (one per XCD), removes the tail
+ * of a static grid. It changes the order of the work only: results are bit-identical with and without it. */
 int pb_flash_fwd_packed(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* q_off,
                         const int32_t* q_len, const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis,
                         int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss,
-                        int64_t v_ss, int64_t o_ss, float scale, int32_t causal, void* stream);
+                        int64_t v_ss, int64_t o_ss, float scale, int32_t causal, const int32_t* bh_order, void* stream);
 int pb_flash_bwd_packed(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                         void* dq, void* dk, void* dv, float* delta, const int32_t* q_off, const int32_t* q_len,
                         const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H,
                         int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss,
                         int64_t dq_ss, int64_t dk_ss, int64_t dv_ss, float scale, int32_t causal,
-                        float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* stream);
+                        float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, const int32_t* bh_order, void* stream);
 
 /* ---- K4b: attention backward in ONE pass (pb_flash1.hip, head_dim 64) -------------------------------
  * Same math, arguments and results (to bf16 rounding) as pb_flash_bwd / pb_flash_bwd_packed, computed key-stationary: a workgroup
@@ -206,7 +209,8 @@ int pb_flash_bwd1_packed(const void* q, const void* k, const void* v, const void
                          const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H,
                          int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss,
                          int64_t dq_ss, int64_t dk_ss, int64_t dv_ss, float scale, int32_t causal,
-                         float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* dq_ws, int64_t q_rows, void* stream);
+                         float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* dq_ws, int64_t q_rows,
+                         const int32_t* bh_order, void* stream);
 
 /* ---- row maps for the packed step (pb_rowmap.hip) ------------------------------------------------
  * pb_rowmap_count: counts (B,8) int32 = {encoder rows visible as keys (emask != 0), decoder rows visible as keys (dmask != 0),

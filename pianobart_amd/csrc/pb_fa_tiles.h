@@ -26,6 +26,10 @@ struct Fa64Args {
     // stride *_ss; the batch strides are not used), its key rows vl_k_off[b] .. + vl_k_len[b] - 1 of k / v / dk / dv, of which the
     // first kmax[b] are visible; Sq / Sk are the maxima over the batch (grid, LDS, and the row length of lse / delta). NULL: dense.
     const int *vl_q_off, *vl_k_off, *vl_q_len, *vl_k_len;
+    // dispatch order of the (batch, head) pairs (B * H entries, pair = b * H + h), or NULL = natural order: the grid hands its slots to
+    // pairs in THIS order, so a caller that knows the pairs' costs (packed rows: 4x spread of q_len * visible keys) lists them
+    // longest first, eight at a time across the XCDs. Only the order of the work changes, never a result.
+    const int* bh_order;
 };
 
 // Packed rows: give the kernel body the view of ONE batch -- its own Sq / Sk and base pointers rebased so that the dense address
@@ -133,11 +137,12 @@ constexpr int STG = 2 * 8192 + 512;        // one stage: two 8 KiB images + 128 
 // 1-D grid -> (row block, head, batch). Workgroups are dealt round-robin over the 8 XCDs (id % 8): all row blocks of one
 // (batch, head) are given to ONE XCD, back to back, so the K/V (or Q/dO) tiles they all stream stay in that XCD's 4 MiB
 // L2 (measured before: FETCH_SIZE 705 MB per forward launch = K/V re-fetched from beyond L2 by each of the 8 q-blocks).
-__device__ __forceinline__ void block_map(int nrb, int H, int B, int& rb, int& h, int& b) {
+__device__ __forceinline__ void block_map(int nrb, int H, int B, int& rb, int& h, int& b, const int* order = nullptr) {
     const int L = blockIdx.x, BH = H * B;
     int bh;
     if ((BH & 7) == 0) { const int x = L & 7, slot = L >> 3; bh = (slot / nrb) * 8 + x; rb = slot % nrb; }
     else { bh = L / nrb; rb = L % nrb; }
+    if (order) bh = order[bh];
     h = bh % H; b = bh / H;
 }
 

@@ -497,12 +497,12 @@ extern "C" int pb_flash_bwd(const void* q, const void* k, const void* v, const v
 extern "C" int pb_flash_fwd_packed(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* q_off, const int32_t* q_len,
                                    const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H, int32_t Sq_max,
                                    int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss, float scale,
-                                   int32_t causal, void* stream_) {
+                                   int32_t causal, const int32_t* bh_order, void* stream_) {
     if (check_common("pb_flash_fwd_packed", hd, q_ss, k_ss, v_ss, o_ss)) return -2;
     PB_REQUIRE(hd == 64 || hd == 96 || hd == 128, "pb_flash_fwd_packed: head_dim %d (64 / 96 / 128 only)", hd);
     PB_REQUIRE(q_off && q_len && k_off && k_len && k_vis, "pb_flash_fwd_packed: the five row descriptors are required");
     if (B <= 0 || H <= 0 || Sq_max <= 0) return 0;
-    const int* vl[4] = {q_off, q_len, k_off, k_len};
+    const int* vl[5] = {q_off, q_len, k_off, k_len, bh_order};
     return pb_flash64_fwd(q, k, v, o, lse, nullptr, k_vis, B, H, Sq_max, Sk_max, hd, 0, q_ss, 0, k_ss, 0, v_ss, 0, o_ss, scale, causal & 1,
                           (hipStream_t)stream_, vl);
 }
@@ -511,13 +511,14 @@ extern "C" int pb_flash_bwd_packed(const void* q, const void* k, const void* v, 
                                    void* dk, void* dv, float* delta, const int32_t* q_off, const int32_t* q_len, const int32_t* k_off,
                                    const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd,
                                    int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss, int64_t dq_ss, int64_t dk_ss, int64_t dv_ss,
-                                   float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* stream_) {
+                                   float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, const int32_t* bh_order,
+                                   void* stream_) {
     if (check_common("pb_flash_bwd_packed", hd, q_ss, k_ss, v_ss, o_ss)) return -2;
     PB_REQUIRE(hd == 64 || hd == 96 || hd == 128, "pb_flash_bwd_packed: head_dim %d (64 / 96 / 128 only)", hd);
     PB_REQUIRE(q_off && q_len && k_off && k_len && k_vis, "pb_flash_bwd_packed: the five row descriptors are required");
     PB_REQUIRE(dq_ss % 4 == 0, "pb_flash_bwd_packed: bad strides");
     if (B <= 0 || H <= 0 || Sq_max <= 0) return 0;
-    const int* vl[4] = {q_off, q_len, k_off, k_len};
+    const int* vl[5] = {q_off, q_len, k_off, k_len, bh_order};
     return pb_flash64_bwd(q, k, v, o, dout, lse, delta, nullptr, k_vis, dq, dk, dv, B, H, Sq_max, Sk_max, hd, 0, q_ss, 0, k_ss, 0, v_ss, 0, o_ss,
                           0, dq_ss, 0, dk_ss, 0, dv_ss, scale, causal & 1, dbias_q, dbias_k, dbias_v, dbias_ws, (hipStream_t)stream_, vl);
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nkb0 = (pin.a.Sk + KB1 - 1) / KB1;
     int rb, h, b;
-    block_map(nkb0, pin.a.H, pin.a.B, rb, h, b);
+    block_map(nkb0, pin.a.H, pin.a.B, rb, h, b, pin.a.bh_order);
     const int k0 = rb * KB1;
     Fa64Args p = pin.a;
     varlen_localize(p, b);
@@ -748,7 +748,7 @@ int pb_flash1_bwd(const void* q, const void* k, const void* v, const void* o, co
                   int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* ws, long q_rows, hipStream_t stream, const int* const* vl) {
     Fa1Args A = {};
     Fa64Args& a = A.a;
-    if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; }
+    if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; a.bh_order = vl[4]; }
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dout = (const bf16_t*)dout;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
@@ -811,13 +811,13 @@ extern "C" int pb_flash_bwd1_packed(const void* q, const void* k, const void* v,
                                     const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd,
                                     int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss, int64_t dq_ss, int64_t dk_ss, int64_t dv_ss,
                                     float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws,
-                                    void* dq_ws, int64_t q_rows, void* stream_) {
+                                    void* dq_ws, int64_t q_rows, const int32_t* bh_order, void* stream_) {
     PB_REQUIRE(hd == 64, "pb_flash_bwd1_packed: head_dim %d (64 only)", hd);
     PB_REQUIRE(q_ss % 8 == 0 && k_ss % 8 == 0 && v_ss % 8 == 0 && o_ss % 8 == 0 && dq_ss % 8 == 0 && dk_ss % 8 == 0 && dv_ss % 8 == 0,
                "pb_flash_bwd1_packed: strides must be multiples of 8 elements");
     PB_REQUIRE(q_off && q_len && k_off && k_len && k_vis, "pb_flash_bwd1_packed: the five row descriptors are required");
     if (B <= 0 || H <= 0 || Sq_max <= 0 || Sk_max <= 0) return 0;
-    const int* vl[4] = {q_off, q_len, k_off, k_len};
+    const int* vl[5] = {q_off, q_len, k_off, k_len, bh_order};
     return pb_flash1_bwd(q, k, v, o, dout, lse, delta, nullptr, k_vis, dq, dk, dv, B, H, Sq_max, Sk_max, 0, q_ss, 0, k_ss, 0, v_ss, 0, o_ss,
                          0, dq_ss, 0, dk_ss, 0, dv_ss, scale, causal & 1, dbias_q, dbias_k, dbias_v, dbias_ws, dq_ws, q_rows, (hipStream_t)stream_, vl);
 }

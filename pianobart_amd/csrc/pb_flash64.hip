@@ -33,7 +33,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args pin) {
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
-    block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b);
+    block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b, pin.bh_order);
     if (pin.causal) rb = (pin.Sq + 127) / 128 - 1 - rb;        // causal: a later row block visits more keys -- the long blocks of a (batch, head) are dispatched first
     const int q0 = rb * 128;
     Fa64Args p = pin;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args pin) {
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
-    block_map((pin.Sk + BK_ - 1) / BK_, pin.H, pin.B, rb, h, b);
+    block_map((pin.Sk + BK_ - 1) / BK_, pin.H, pin.B, rb, h, b, pin.bh_order);
     const int k0 = rb * BK_;
     Fa64Args p = pin;
     varlen_localize(p, b);
@@ -272,11 +272,22 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args pin) {
     const int sqp = ((p.Sq + 63) / 64) * 64;
     float* ldsNL = reinterpret_cast<float*>(smem + C::NS * C::STB);       // -lse * log2(e) per query (-inf: row contributes nothing)
     float* ldsND = ldsNL + sqp;                                          // -delta per query
-    for (int q = it0 * 64 + t; q < nt * 64; q += FT) {
-        const long li = ((long)b * p.H + h) * lse_ld + q;
-        const float ls = q < p.Sq ? p.lse[li] : INFINITY;
-        ldsNL[q] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
-        ldsND[q] = q < p.Sq ? -p.delta[li] : 0.f;
+    {   // all loads of a chunk of 4 x 256 queries are requested before the first is stored (one memory round trip per chunk, not per 256)
+        const long li0 = ((long)b * p.H + h) * lse_ld;
+        for (int qb = it0 * 64; qb < nt * 64; qb += 4 * FT) {
+            float tl[4], td[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = qb + t + i * FT;
+                tl[i] = q < p.Sq ? p.lse[li0 + q] : INFINITY;
+                td[i] = q < p.Sq ? p.delta[li0 + q] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = qb + t + i * FT;
+                if (q < nt * 64) { ldsNL[q] = tl[i] == INFINITY ? -INFINITY : -tl[i] * LOG2E; ldsND[q] = -td[i]; }
+            }
+        }
     }
     int mykey[KT];
     bf16x8 kf[KT][KS], vf[KT][KS];
@@ -390,8 +401,11 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args pin) {
                 const bf16x8 ot = tr_join(to[dt][0], to[dt][1]), qtf = tr_join(tq[dt][0], tq[dt][1]);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
-                    dv[kt][nb * 4 + dt] = MFMA16(pf[kt][si], ot, dv[kt][nb * 4 + dt]);
-                    dk[kt][nb * 4 + dt] = MFMA16(df[kt][si], qtf, dk[kt][nb * 4 + dt]);
+                    // A = the transposed dO / Q fragment (row = column), B = P^T / dS^T (column = key): a lane ends up with 4 consecutive
+                    // columns of ONE key per tile = an 8-byte store (the other operand order leaves 4 keys of one column: 2-byte stores,
+                    // and the store tail is paid per instruction, not per byte)
+                    dv[kt][nb * 4 + dt] = MFMA16(ot, pf[kt][si], dv[kt][nb * 4 + dt]);
+                    dk[kt][nb * 4 + dt] = MFMA16(qtf, df[kt][si], dk[kt][nb * 4 + dt]);
                 }
             }
         }
@@ -399,35 +413,47 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args pin) {
         __builtin_amdgcn_s_barrier();
         sidx = sidx == C::NS - 1 ? 0 : sidx + 1;
     }
-    float csk[DT], csv[DT];
+    // tile (kt, dt): lane = key 16 kt + lr of this wave, registers = columns 16 dt + 4 g + r
+    f32x4 csk[DT], csv[DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { csk[dt] = 0.f; csv[dt] = 0.f; }
+    for (int dt = 0; dt < DT; ++dt) { csk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; csv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; ++kt) {
+        const int key = k0 + wave * (16 * KT) + kt * 16 + lr;
+        const bool kvis = pin.vl_q_off ? key < (p.kmax ? p.kmax[b] : p.Sk)                       // packed rows: the visible keys are a prefix
+                                       : (!p.key_mask || p.key_mask[(long)b * p.Sk + (key < p.Sk ? key : 0)] != 0.f);    // a masked key receives no gradient
+        bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HDT + g * 4;
+        bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT + g * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = k0 + wave * (16 * KT) + kt * 16 + g * 4 + r;
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 vk = dk[kt][dt] * p.scale, vv = dv[kt][dt];
+            if (!kvis) { vk = f32x4{0.f, 0.f, 0.f, 0.f}; vv = f32x4{0.f, 0.f, 0.f, 0.f}; }
             if (key < p.Sk) {
-                const bool kvis = pin.vl_q_off ? key < (p.kmax ? p.kmax[b] : p.Sk)                 // packed rows: the visible keys are a prefix
-                                               : (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);    // a masked key receives no gradient
-                bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HDT;
-                bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const float vk = kvis ? dk[kt][dt][r] * p.scale : 0.f, vv = kvis ? dv[kt][dt][r] : 0.f;
-                    DK[dt * 16 + lr] = (bf16_t)vk;
-                    DV[dt * 16 + lr] = (bf16_t)vv;
-                    csk[dt] += vk; csv[dt] += vv;
-                }
+                bf16x4 rk = {(bf16_t)vk[0], (bf16_t)vk[1], (bf16_t)vk[2], (bf16_t)vk[3]}, rv = {(bf16_t)vv[0], (bf16_t)vv[1], (bf16_t)vv[2], (bf16_t)vv[3]};
+                *reinterpret_cast<bf16x4*>(DK + dt * 16) = rk;
+                *reinterpret_cast<bf16x4*>(DV + dt * 16) = rv;
+                csk[dt] += vk; csv[dt] += vv;
             }
         }
+    }
     if (p.cs_kv) {      // bias gradients: column sums of the block's dK / dV rows -> partial row (b, key block), head h's columns
         const int nkb = (pin.Sk + BK_ - 1) / BK_, d_model = p.H * HDT;
         float* red = reinterpret_cast<float*>(smem);                      // [4 waves][2 HDT]: the tile ring is free after the last barrier
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const float sk = grp_sum(csk[dt]), sv_ = grp_sum(csv[dt]);
-            if (g == 0) { red[wave * 2 * HDT + dt * 16 + lr] = sk; red[wave * 2 * HDT + HDT + dt * 16 + lr] = sv_; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                                 // sum over the 16 keys of a DPP row: row_mirror, row_half_mirror, quad_perm
+                float v = csk[dt][e], u = csv[dt][e];
+                v += PB_DPP_F(v, 0x140); u += PB_DPP_F(u, 0x140);
+                v += PB_DPP_F(v, 0x141); u += PB_DPP_F(u, 0x141);
+                v += PB_DPP_F(v, 0x4e); u += PB_DPP_F(u, 0x4e);
+                v += PB_DPP_F(v, 0xb1); u += PB_DPP_F(u, 0xb1);
+                csk[dt][e] = v; csv[dt][e] = u;
+            }
+            if (lr == 0) {
+                *reinterpret_cast<f32x4*>(red + wave * 2 * HDT + dt * 16 + g * 4) = csk[dt];
+                *reinterpret_cast<f32x4*>(red + wave * 2 * HDT + HDT + dt * 16 + g * 4) = csv[dt];
+            }
         }
         __syncthreads();
         if (t < 2 * HDT) {
@@ -450,7 +476,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args pin) {
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int rb, h, b;
-    block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b);
+    block_map((pin.Sq + 127) / 128, pin.H, pin.B, rb, h, b, pin.bh_order);
     if (pin.causal) rb = (pin.Sq + 127) / 128 - 1 - rb;        // causal: a later row block visits more keys -- the long blocks of a (batch, head) are dispatched first
     const int q0 = rb * 128;
     Fa64Args p = pin;
@@ -660,7 +686,7 @@ int pb_flash64_fwd(const void* q, const void* k, const void* v, void* o, float* 
                    long q_sb, long q_ss, long k_sb, long k_ss, long v_sb, long v_ss, long o_sb, long o_ss, float scale, int causal, hipStream_t stream,
                    const int* const* vl) {
     Fa64Args a = {};
-    if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; }
+    if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; a.bh_order = vl[4]; }
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal;
@@ -690,7 +716,7 @@ int pb_flash64_bwd(const void* q, const void* k, const void* v, const void* o, c
                    long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
                    int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, hipStream_t stream, const int* const* vl) {
     Fa64Args a = {};
-    if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; }
+    if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; a.bh_order = vl[4]; }
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dout = (const bf16_t*)dout;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask; a.kmax = kmax;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;

@@ -43,6 +43,9 @@ _DGRAD_NT = 1    # settled (round 2): backward dX = dY W from transposed weight 
 _FWD_GEMM_FLAGS = int(os.environ.get('PB_FWD_GEMM_FLAGS', '32768'))      # PB_GEMM_TAIL_SPLIT for the forward projections (0: off)
 # dead-row compaction of the fused pre-train step (Engine._pack_batch): PB_PACK_ROWS=0 keeps every step dense
 _PACK_ROWS = int(os.environ.get('PB_PACK_ROWS', '1'))
+# head_dim-64 attention backward in ONE pass (csrc/pb_flash1.hip) instead of the dQ + dK/dV kernel pair: 0 = never, 1 = the padded
+# (dense) non-causal calls, where it measured 14 % faster (default), 2 = packed non-causal calls too (equal there), 3 = causal calls too (slower)
+_ATTN_BWD1 = int(os.environ.get('PB_ATTN_BWD1', '1'))
 
 
 class _HipEvent:
@@ -396,13 +399,19 @@ class Engine:
                 if getattr(self, '_fbws', None) is None or self._fbws.numel() < need:
                     self._fbws = torch.empty(need, dtype=torch.float32, device=self.device)
                 wsb = self._fbws
+            one_pass = hd == 64 and _ATTN_BWD1 >= (3 if causal else 2 if rows is not None else 1)
             if rows is not None:
-                ops.flash_bwd_packed(q, k, v, out, dout[0], save['lse'], dq, dk, dv, ws['delta'], rows, B, H, hd, hd ** -0.5, causal,
-                                     dbias=dbias if fuse else None, dbias_ws=wsb)
+                if one_pass:
+                    ops.flash_bwd1_packed(q, k, v, out, dout[0], save['lse'], dq, dk, dv, ws['delta'], rows, B, H, hd, hd ** -0.5, causal, q[0].shape[0],
+                                          dbias=dbias if fuse else None, dbias_ws=wsb)
+                else:
+                    ops.flash_bwd_packed(q, k, v, out, dout[0], save['lse'], dq, dk, dv, ws['delta'], rows, B, H, hd, hd ** -0.5, causal,
+                                         dbias=dbias if fuse else None, dbias_ws=wsb)
                 return fuse
-            ops.flash_bwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
-                          ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal, kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None,
-                          dbias=dbias if fuse else None, dbias_ws=wsb)
+            (ops.flash_bwd1 if one_pass else ops.flash_bwd)(
+                ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
+                ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal, kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None,
+                dbias=dbias if fuse else None, dbias_ws=wsb)
             return fuse
         dP, dS, P = ws['scores'], ws['dS'], save['P']
         (qt, qo, ql), (kt, ko, kl), (vt, vo, vl) = q, k, v

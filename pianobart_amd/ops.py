@@ -247,9 +247,10 @@ class PackedRows:
     """Row descriptors of one packed attention call (include/pianobart_hip.h, pb_flash_*_packed): device int32 (B) tensors plus
     the two maxima."""
 
-    def __init__(self, q_off, q_len, k_off, k_len, k_vis, Sq_max, Sk_max, kind=''):
+    def __init__(self, q_off, q_len, k_off, k_len, k_vis, Sq_max, Sk_max, kind='', order=None):
         self.q_off, self.q_len, self.k_off, self.k_len, self.k_vis, self.Sq_max, self.Sk_max = q_off, q_len, k_off, k_len, k_vis, Sq_max, Sk_max
         self.kind = kind                    # a label for profiles ('enc', 'dec', 'cross')
+        self.order = order                  # device int32 (B * H): dispatch order of the (batch, head) pairs, longest first (or None)
 
 
 def flash_fwd_packed(q, k, v, o, lse, rows, B, H, hd, scale, causal):
@@ -257,7 +258,7 @@ def flash_fwd_packed(q, k, v, o, lse, rows, B, H, hd, scale, causal):
     (qt, qo, qs), (kt, ko, ks), (vt, vo, vs), (ot, oo, os_) = q, k, v, o
     pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 2 * off)
     LIB.call('pb_flash_fwd_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(lse), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off),
-             _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd, qs, ks, vs, os_, scale, int(causal), _stream())
+             _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd, qs, ks, vs, os_, scale, int(causal), _p(rows.order), _stream())
 
 
 def flash_bwd_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, scale, causal, dbias=None, dbias_ws=None):
@@ -267,7 +268,7 @@ def flash_bwd_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, s
     LIB.call('pb_flash_bwd_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), pp(dqt, dqo), pp(dkt, dko), pp(dvt, dvo),
              _p(delta), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off), _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd,
              qs, ks, vs, os_, dqs, dks, dvs, scale, int(causal), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
-             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _stream())
+             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(rows.order), _stream())
 
 
 _fa1_ws = {}
@@ -302,7 +303,7 @@ def flash_bwd1_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, 
     LIB.call('pb_flash_bwd1_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), pp(dqt, dqo), pp(dkt, dko), pp(dvt, dvo),
              _p(delta), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off), _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd,
              qs, ks, vs, os_, dqs, dks, dvs, scale, int(causal), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
-             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(ws), q_rows, _stream())
+             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(ws), q_rows, _p(rows.order), _stream())
 
 
 def rowmap_count(emask, dmask, loss_mask, counts):

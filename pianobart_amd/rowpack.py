@@ -16,6 +16,7 @@ PACK_TILE = 256                 # packed row counts are rounded up to whole GEMM
 PACK_MIN_GAIN = 0.97            # stay dense unless at least 3 % of the rows go
 SUB_LAST = int(os.environ.get('PB_SUB_LAST', '1'))     # last decoder layer: query side and LM heads on the loss rows only
 SUB_MIN_GAIN = 0.75             # ... unless more than 3/4 of the decoder rows carry a loss term
+ORDER_PAIRS = int(os.environ.get('PB_ORDER_PAIRS', '1'))   # attention grids take the (batch, head) pairs longest first (0: batch order, for A/B)
 
 
 def plan_packed_rows(live, S, tile=PACK_TILE):
@@ -37,6 +38,20 @@ class RowPack:
     loss_mask, src_* (row b*S + s of every packed row in the padded batch), inv_* (packed row of every (b, s), or -1) and the PackedRows
     descriptors of the encoder self-, decoder self- and cross-attention."""
 
+
+
+def dispatch_order(cost, H):
+    """Order in which an attention grid should take the (batch, head) pairs of a packed batch (ops.PackedRows.order): pairs sorted by cost,
+    longest first (all heads of a sequence cost the same), dealt eight at a time in snake order so that the 8 XCDs -- the grid gives
+    slot 8 g + x to XCD x -- receive equal sums. cost: (B,) array-like. Returns int32 (B * H,), entry = b * H + h."""
+    cost = np.asarray(cost, dtype=np.float64)
+    pairs = (np.argsort(-cost, kind='stable')[:, None] * H + np.arange(H)[None, :]).reshape(-1)
+    n = pairs.size
+    if n % 8 == 0:
+        g = pairs.reshape(-1, 8).copy()
+        g[1::2] = g[1::2, ::-1]
+        pairs = g.reshape(-1)
+    return pairs.astype(np.int32)
 
 
 def _mask_key(loss_mask, emask, dmask):
@@ -89,6 +104,7 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
         i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
         st = eng._pack_state = dict(key=(B, S), counts=i32(B, 8), counts_h=torch.empty(B, 8, dtype=torch.int32).pin_memory(),
                                      desc=i32(8, B), desc_h=[torch.empty(8, B, dtype=torch.int32).pin_memory() for _ in range(4)], desc_turn=0,
+                                     order=i32(4, B * eng.H), order_h=[torch.empty(4, B * eng.H, dtype=torch.int32).pin_memory() for _ in range(4)],
                                      src_e=i32(T), pos_e=i32(T), inv_e=i32(T), src_d=i32(T), pos_d=i32(T), inv_d=i32(T), src_s=i32(T), idx_s=i32(T),
                                      tgt16_s=torch.empty(T, 8, dtype=torch.int16, device=dev), lm_s=torch.empty(T, 8, dtype=torch.float32, device=dev),
                                      enc16=torch.empty(T, 8, dtype=torch.int16, device=dev), dec16=torch.empty(T, 8, dtype=torch.int16, device=dev),
@@ -150,9 +166,18 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
     me, md = int(len_e.max()), int(len_d.max())
     vis_e, vis_d = c[:, 0], c[:, 1]
     pk.pairs = (int((len_e * vis_e).sum()), int((vis_d * vis_d // 2 + (len_d - vis_d) * vis_d).sum()), int((len_d * vis_e).sum()))
-    pk.enc = ops.PackedRows(desc[0], desc[1], desc[0], desc[1], desc[2], me, me, 'enc')
-    pk.dec = ops.PackedRows(desc[3], desc[4], desc[3], desc[4], desc[5], md, md, 'dec')
-    pk.cross = ops.PackedRows(desc[3], desc[4], desc[0], desc[1], desc[2], md, me, 'cross')
+    # dispatch orders of the (batch, head) pairs, longest first (the costs spread 4x over a batch; a static grid in batch order ends on
+    # whatever lies last): encoder self-, decoder self-, cross-attention and the last layer's cross-attention on the loss rows
+    order = st['order']
+    if ORDER_PAIRS:
+        order_h = st['order_h'][st['desc_turn']]
+        costs = (len_e * vis_e, vis_d * vis_d // 2 + (len_d - vis_d) * vis_d, len_d * vis_e, (len_s if sub else len_d) * vis_e)
+        order_h.copy_(torch.from_numpy(np.stack([dispatch_order(x, eng.H) for x in costs])))
+        order.copy_(order_h, non_blocking=True)
+    o = (lambda i: order[i]) if ORDER_PAIRS else (lambda i: None)
+    pk.enc = ops.PackedRows(desc[0], desc[1], desc[0], desc[1], desc[2], me, me, 'enc', order=o(0))
+    pk.dec = ops.PackedRows(desc[3], desc[4], desc[3], desc[4], desc[5], md, md, 'dec')      # causal: batch order (longest first measured 4 - 10 % SLOWER there)
+    pk.cross = ops.PackedRows(desc[3], desc[4], desc[0], desc[1], desc[2], md, me, 'cross', order=o(2))
     pk.sub = None
     if sub:
         sb = pk.sub = RowPack()
@@ -162,7 +187,7 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
         ops.gather_rows16(pk.tgt16, sb.idx, sb.tgt16, Ts, 16)
         ops.gather_rows16(pk.loss_mask, sb.idx, sb.loss_mask, Ts, 32)
         ms = int(len_s.max())
-        sb.cross = ops.PackedRows(desc[6], desc[7], desc[0], desc[1], desc[2], ms, me, 'cross')
+        sb.cross = ops.PackedRows(desc[6], desc[7], desc[0], desc[1], desc[2], ms, me, 'cross', order=o(3))
         pk.pairs = pk.pairs[:2] + (pk.pairs[2] * (eng.ND - 1) // eng.ND + int((len_s * vis_e).sum()) // eng.ND,)     # layer mean
     return pk
 

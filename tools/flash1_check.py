@@ -67,7 +67,7 @@ def dense(B, H, S, mask_kind, causal, time_it=True):
         cmp(n, b1[i], b0[i])
 
 
-def packed(B, H, S, kind, time_it=True):
+def packed(B, H, S, kind, time_it=True, ordered=False):
     d = H * hd
     g = torch.Generator().manual_seed(1)
     qlen = torch.randint(S // 2, S + 1, (B,), generator=g)
@@ -80,6 +80,10 @@ def packed(B, H, S, kind, time_it=True):
     i32 = lambda t: t.to(torch.int32).to(dev)
     rows = ops.PackedRows(i32(qoff), i32(qlen), i32(koff), i32(klen), i32(kvis), int(qlen.max()), int(klen.max()), kind)
     causal = kind == 'dec'
+    if ordered:
+        from pianobart_amd.rowpack import dispatch_order
+        cost = (kvis * kvis // 2 + (qlen - kvis).clamp(min=0) * kvis) if causal else qlen * kvis
+        rows.order = torch.from_numpy(dispatch_order(cost.numpy(), H)).to(dev)
     scale = hd ** -0.5
     if kind == 'cross':
         qb = (torch.randn(Tq, d, device=dev) * 0.5).to(torch.bfloat16); kvb = (torch.randn(Tk, 2 * d, device=dev) * 0.5).to(torch.bfloat16)
@@ -90,6 +94,7 @@ def packed(B, H, S, kind, time_it=True):
     o = torch.empty(Tq, d, device=dev, dtype=torch.bfloat16); do = torch.randn(Tq, d, device=dev).to(torch.bfloat16)
     lse = torch.empty(B, H, rows.Sq_max, device=dev); delta = torch.zeros(B, H, rows.Sq_max, device=dev); delta1 = torch.zeros(B, H, rows.Sq_max, device=dev)
     ops.flash_fwd_packed(q, k, v, (o, 0, d), lse, rows, B, H, hd, scale, causal)
+    tfwd = timed(lambda: ops.flash_fwd_packed(q, k, v, (o, 0, d), lse, rows, B, H, hd, scale, causal)) if time_it else 0.0
     res = []
     for one, dl in ((False, delta), (True, delta1)):
         if kind == 'cross':
@@ -111,7 +116,8 @@ def packed(B, H, S, kind, time_it=True):
         t = timed(run) if time_it else 0.0
         res.append((outs(), db, t))
     (r0, b0, t0), (r1, b1, t1) = res
-    print('packed %s B=%d H=%d S=%d (Tq %d, Tk %d): two-kernel %.1f us, one-pass %.1f us' % (kind, B, H, S, Tq, Tk, t0, t1))
+    print('packed %s B=%d H=%d S=%d (Tq %d, Tk %d)%s: forward %.1f us, backward two-kernel %.1f us, one-pass %.1f us' % (
+        kind, B, H, S, Tq, Tk, ' longest first' if ordered else '', tfwd, t0, t1))
     for i, n in enumerate(('dq', 'dk', 'dv')):
         cmp(n, r1[i], r0[i])
     for i, n in enumerate(('dbq', 'dbk', 'dbv')):
@@ -122,7 +128,8 @@ if __name__ == '__main__':
     small = '--small' in sys.argv
     if small:
         dense(2, 2, 200, None, False, False); dense(2, 2, 333, 'ragged', False, False); dense(3, 2, 520, 'scattered', False, False); dense(2, 2, 300, None, True, False)
-        packed(3, 2, 400, 'enc', False); packed(3, 2, 400, 'dec', False); packed(3, 2, 400, 'cross', False)
+        packed(3, 2, 400, 'enc', False); packed(3, 2, 400, 'dec', False); packed(3, 2, 400, 'cross', False); packed(4, 2, 400, 'enc', False, ordered=True); packed(4, 2, 400, 'dec', False, ordered=True)
     else:
         dense(32, 12, 1024, None, False); dense(32, 12, 1024, 'ragged', False); dense(32, 12, 1024, None, True); dense(32, 12, 1024, 'ragged', True)
-        packed(32, 12, 1024, 'enc'); packed(32, 12, 1024, 'dec'); packed(32, 12, 1024, 'cross')
+        for kind in ('enc', 'dec', 'cross'):
+            packed(32, 12, 1024, kind); packed(32, 12, 1024, kind, ordered=True)
