@@ -311,7 +311,7 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
         red = GradReducer(eng, 1)
         try:
             def dp_step():
-                eng.loss_and_grads(*step.batch, train=True, count_hook=red.reduce_counts)
+                eng.loss_and_grads(*step.batch, train=True, count_hook=red.reduce_counts, ids_checked=True)
                 red.all_reduce_grads()
                 eng.optimizer_step(lr=2e-5, gscale=1.0)
             dp_step(); torch.cuda.synchronize()
@@ -444,7 +444,7 @@ def main():
         # requested now, so the next step's packing plan does not wait for this step to drain (Engine.prefetch_pack)
         if prefetch:
             eng.prefetch_pack(loss_mask, emask, dmask)              # for the step AFTER this one (this one's request went out a step ago)
-        sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=True,
+        sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=True, ids_checked=True,      # ids generated in range (synth_batch)
                                   count_hook=reducer.reduce_counts if reducer else None)
         if reducer:
             reducer.all_reduce_grads()

@@ -46,6 +46,7 @@ _PACK_ROWS = int(os.environ.get('PB_PACK_ROWS', '1'))
 # head_dim-64 attention backward in ONE pass (csrc/pb_flash1.hip) instead of the dQ + dK/dV kernel pair: 0 = never, 1 = the padded
 # (dense) non-causal calls, where it measured 14 % faster (default), 2 = packed non-causal calls too (equal there), 3 = causal calls too (slower)
 _ATTN_BWD1 = int(os.environ.get('PB_ATTN_BWD1', '1'))
+_KV_CUT = 2      # the stacked cross-attention K / V projection is issued as layers 0 .. _KV_CUT - 1 | the rest (forward_hidden)
 
 
 class _HipEvent:
@@ -140,8 +141,13 @@ class Engine:
             add(p + 'wqkv', 3 * d, d); add(p + 'wo', d, d); add(p + 'w1', fe, d); add(p + 'w2', d, fe)
         for l in range(self.ND):
             p = 'dec.%d.' % l
-            add(p + 'wqkv', 3 * d, d); add(p + 'wo', d, d); add(p + 'wq_c', d, d); add(p + 'wkv_c', 2 * d, d)
+            add(p + 'wqkv', 3 * d, d); add(p + 'wo', d, d); add(p + 'wq_c', d, d)
             add(p + 'wo_c', d, d); add(p + 'w1', fd, d); add(p + 'w2', d, fd)
+        # the cross-attention K / V projections of ALL decoder layers form one (ND * 2d, d) matrix: every layer projects the same
+        # encoder output, so forward, input-gradient and weight-gradient are one long GEMM each instead of ND short ones
+        # (tf:modeling_bart.py:227-228, the key_value_states branch). 'dec.<l>.wkv_c' / 'dec.<l>.bkv_c' stay as row-slice aliases.
+        if self.ND:
+            add('dec.wkv_all', self.ND * 2 * d, d)
         if self.mlm is not None:
             add('head.w', ops.VOCAB, d)
         self.n_matrix = cur[0]
@@ -153,8 +159,10 @@ class Engine:
                 p = '%s.%d.' % (side, l)
                 add(p + 'bqkv', 3 * d); add(p + 'bo', d); add(p + 'ln1.w', d); add(p + 'ln1.b', d)
                 if side == 'dec':
-                    add(p + 'bq_c', d); add(p + 'bkv_c', 2 * d); add(p + 'bo_c', d); add(p + 'lnc.w', d); add(p + 'lnc.b', d)
+                    add(p + 'bq_c', d); add(p + 'bo_c', d); add(p + 'lnc.w', d); add(p + 'lnc.b', d)
                 add(p + 'b1', fe if side == 'enc' else fd); add(p + 'b2', d); add(p + 'ln2.w', d); add(p + 'ln2.b', d)
+        if self.ND:
+            add('dec.bkv_all', self.ND * 2 * d)
         if self.mlm is not None:
             add('head.b', ops.VOCAB)
         self.n_total = cur[0]
@@ -181,8 +189,8 @@ class Engine:
                 if side == 'dec':
                     ca = L.encoder_attn
                     out += [(ca.q_proj.weight, p + 'wq_c', 0), (ca.q_proj.bias, p + 'bq_c', 0),
-                            (ca.k_proj.weight, p + 'wkv_c', 0), (ca.v_proj.weight, p + 'wkv_c', d),
-                            (ca.k_proj.bias, p + 'bkv_c', 0), (ca.v_proj.bias, p + 'bkv_c', d),
+                            (ca.k_proj.weight, 'dec.wkv_all', l * 2 * d), (ca.v_proj.weight, 'dec.wkv_all', l * 2 * d + d),
+                            (ca.k_proj.bias, 'dec.bkv_all', l * 2 * d), (ca.v_proj.bias, 'dec.bkv_all', l * 2 * d + d),
                             (ca.out_proj.weight, p + 'wo_c', 0), (ca.out_proj.bias, p + 'bo_c', 0),
                             (L.encoder_attn_layer_norm.weight, p + 'lnc.w', 0), (L.encoder_attn_layer_norm.bias, p + 'lnc.b', 0)]
                 out += [(L.fc1.weight, p + 'w1', 0), (L.fc1.bias, p + 'b1', 0), (L.fc2.weight, p + 'w2', 0), (L.fc2.bias, p + 'b2', 0),
@@ -230,6 +238,8 @@ class Engine:
             self.wf[name] = P32[s.off:s.off + s.numel].view(s.shape)
             self.g[name] = self.G32[s.off:s.off + s.numel].view(s.shape)
             self.w[name] = (self.Pbf[s.off:s.off + s.numel].view(s.shape) if self.code == PB_BF16 else self.wf[name])
+        for dct in (self.w, self.wf, self.g):
+            self._alias_cross_kv(dct)
         # transposed bf16 copies of the layer matrices for the backward's dX = dY W (read K-contiguous, the faster form of the GEMM
         # kernel): same offsets in a second flat buffer, rewritten by one batched launch whenever the shadow changed
         self.wT, self._wT_table, self._wT_tiles = {}, None, 0
@@ -260,6 +270,14 @@ class Engine:
         w = [len(self.pb.e2w[k]) for k in self.pb.e2w]                       # dict order (pretrain.py:185-189)
         self.loss_w = torch.tensor(w, dtype=torch.float32, device=device)
         self.sos16 = torch.tensor(self.pb.sos_word_np, dtype=torch.int16, device=device)
+
+    def _alias_cross_kv(self, dct):
+        """'dec.<l>.wkv_c' (2d, d) / 'dec.<l>.bkv_c' (2d,) = layer l's rows of the stacked cross-attention K / V projection."""
+        if self.ND:
+            d2 = 2 * self.d
+            for l in range(self.ND):
+                dct['dec.%d.wkv_c' % l] = dct['dec.wkv_all'][l * d2:(l + 1) * d2]
+                dct['dec.%d.bkv_c' % l] = dct['dec.bkv_all'][l * d2:(l + 1) * d2]
 
     def refresh_shadow(self, force=False):
         """bf16 weight shadow follows the f32 masters (after load_state_dict / an external optimizer)."""
@@ -316,15 +334,16 @@ class Engine:
             L = dict(qkv=e(T, 3 * d), ctx=e(T, d), a1=e(T, d), y1=e(T, d), m1=f(T), r1=f(T), u=e(T, ff), g=e(T, ff), a2=e(T, d),
                      y2=e(T, d), m2=f(T), r2=f(T), attn=attn_ws())
             if dec:
-                L.update(qc=e(T, d), kvc=e(T, 2 * d), ctxc=e(T, d), ac=e(T, d), yc=e(T, d), mc=f(T), rc=f(T), attnc=attn_ws())
+                L.update(qc=e(T, d), ctxc=e(T, d), ac=e(T, d), yc=e(T, d), mc=f(T), rc=f(T), attnc=attn_ws())
             return L
 
         ws = dict(B=B, S=S, T=T,
                   x_enc=e(T, d), me=f(T), re=f(T), x_dec=e(T, d), md=f(T), rd=f(T),
+                  kvc_all=e(T, max(1, self.ND) * 2 * d), dkv_all=e(T, max(1, self.ND) * 2 * d),      # cross-attention K | V of every decoder layer side by side, and their gradients
                   enc=[layer(False) for _ in range(self.NE)], dec=[layer(True) for _ in range(self.ND)],
                   logits=f(T, ops.VOCAB) if self.mlm is not None else None,
                   scores=None if self.use_flash else f(B, H, S, S), dS=None if self.use_flash else e(B, H, S, S), delta=f(B, H, S),
-                  gy=[e(T, d), e(T, d)], gA=e(T, d), gB=e(T, d), gC=e(T, d), dqkv=e(T, 3 * d), dq=e(T, d), dkv=e(T, 2 * d),
+                  gy=[e(T, d), e(T, d)], gA=e(T, d), gB=e(T, d), gC=e(T, d), dqkv=e(T, 3 * d), dq=e(T, d),
                   du=e(T, max(self.fe, self.fd)), genc=e(T, d), dlogits=e(T, ops.VOCAB) if self.mlm is not None else None,
                   dz=e(2 * T, d) if self.code == PB_BF16 else None, onehot=e(2 * T, ops.TAB_TOTAL) if self.code == PB_BF16 else None)
         ws['Te'] = ws['Td'] = T
@@ -344,13 +363,13 @@ class Engine:
 
             def layer(L, dec):
                 n = Td if dec else Te
-                return {k: (t if k in ('attn', 'attnc') else t[:Te] if k == 'kvc' else t[:n]) for k, t in L.items()}
+                return {k: (t if k in ('attn', 'attnc') else t[:n]) for k, t in L.items()}
 
             v = dict(ws)
             v['_base'] = ws
             v['enc'] = [layer(L, False) for L in ws['enc']]
             v['dec'] = [layer(L, True) for L in ws['dec']]
-            for k in ('x_enc', 'me', 're'):
+            for k in ('x_enc', 'me', 're', 'kvc_all', 'dkv_all'):
                 v[k] = ws[k][:Te]
             for k in ('x_dec', 'md', 'rd'):
                 v[k] = ws[k][:Td]
@@ -504,17 +523,27 @@ class Engine:
             ops.add_ln_fwd(ws['alt_pos'], dec_embeds, wf['dec.lne.w'], wf['dec.lne.b'], pre, ws['md'], ws['rd'], LN_EPS, 0, 0, 0.0)
             if p > 0.0:
                 ops.dropout(pre, y, seed, self._site('dec_emb'), p)
+        # Every decoder layer's cross-attention K / V projection reads the encoder output only: they are ONE GEMM against the stacked
+        # weights, cut in two so that the first layers' share is there when layer 0 asks for it (layers 0 .. 1 | the rest), on the second
+        # stream when there is one (it fills the CUs the decoder's N = d GEMMs leave idle)
+        kvld = self.ND * 2 * d
+        kv_cut = min(_KV_CUT, self.ND)
+
+        def kv_project(l0, l1):
+            ops.gemm(enc_out, self.w['dec.wkv_all'], ws['kvc_all'], M=Te, N=(l1 - l0) * 2 * d, K=d, dtype=self.code, bias=self.wf['dec.bkv_all'][l0 * 2 * d:],
+                     ldc=kvld, b_off=l0 * 2 * d * d, c_off=l0 * 2 * d, dbg=_FWD_GEMM_FLAGS)
         kv_ready = None
-        if (_WGRAD_STREAM & 2) and self._side_stream() is not None:
-            # every decoder layer's cross-attention K/V projection depends on the encoder output only: issue them all on the second
-            # stream now, to fill the CUs the decoder's N = d GEMMs leave idle
+        if (_WGRAD_STREAM & 2) and self._side_stream() is not None and self.ND:
             self._event().wait_on(self._side)
-            kv_ready = []
             with torch.cuda.stream(self._side):
-                for l in range(self.ND):
-                    pf = 'dec.%d.' % l
-                    self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', ws['dec'][l]['kvc'], Te, 2 * d, d)
-                    kv_ready.append(self._event())
+                kv_project(0, kv_cut)
+                kv_ready = [self._event()] * kv_cut
+                if self.ND > kv_cut:
+                    kv_project(kv_cut, self.ND)
+                    kv_ready += [self._event()] * (self.ND - kv_cut)
+        elif self.ND:
+            kv_project(0, self.ND)
+        kv_of = lambda l: ((ws['kvc_all'], l * 2 * d, kvld), (ws['kvc_all'], l * 2 * d + d, kvld))
         sub = pack.sub if pack is not None else None
         sub_layer = None
         for l in range(self.ND):
@@ -535,12 +564,10 @@ class Engine:
                 Lq['attnc'] = L['attnc']
                 sub_layer = Lq
             self._linear(y1, pf + 'wq_c', pf + 'bq_c', Lq['qc'], Tq, d, d)
-            if kv_ready is None:
-                self._linear(enc_out, pf + 'wkv_c', pf + 'bkv_c', L['kvc'], Te, 2 * d, d)
-            else:
+            if kv_ready is not None and (l == 0 or l == kv_cut):
                 kv_ready[l].wait_on(torch.cuda.current_stream())
-            self._attn_fwd((Lq['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d), (Lq['ctxc'], 0, d), emask, False, B, S, S, L['attnc'],
-                           rows=r_x)
+            kx, vx = kv_of(l)
+            self._attn_fwd((Lq['qc'], 0, d), kx, vx, (Lq['ctxc'], 0, d), emask, False, B, S, S, L['attnc'], rows=r_x)
             self._linear(Lq['ctxc'], pf + 'wo_c', pf + 'bo_c', Lq['ac'], Tq, d, d)
             ops.add_ln_fwd(y1, Lq['ac'], wf[pf + 'lnc.w'], wf[pf + 'lnc.b'], Lq['yc'], Lq['mc'], Lq['rc'], LN_EPS, seed, self._site('dec', l, 1), p, row_ids=ids_q)
             self._linear(Lq['yc'], pf + 'w1', pf + 'b1', Lq['g'], Tq, self.fd, d, gelu_aux_out=Lq['u'])
@@ -777,20 +804,25 @@ class Engine:
                     cur = cur[:Tq]
                 gA = self._ffn_ln_bwd(Lq, pf, self.fd, cur, Lq['yc'], seed, self._site('dec', l, 2), p, Tq, row_ids=ids_q)
                 # cross-attention block: y_c = LN(y1 + drop(out_c(attn(q_c(y1), kv_c(enc)))))
-                dq_d, dkv_e, dqkv_d = self._ring('dq')[:Tq], self._ring('dkv')[:Te], self._ring('dqkv')[:Td]
+                dq_d, dqkv_d = self._ring('dq')[:Tq], self._ring('dqkv')[:Td]
+                kvld, dkv_all = self.ND * 2 * d, ws['dkv_all']
+                if l == self.ND - 1:
+                    self._before_write(dkv_all)
                 g1 = gy if cur.data_ptr() != gy.data_ptr() else galt
                 g1q = g1[:Tq]
-                fused = self._attn_block_bwd(Lq, pf, (pf + 'wo_c', pf + 'bo_c'), gA, y1, (Lq['qc'], 0, d), (L['kvc'], 0, 2 * d), (L['kvc'], d, 2 * d),
-                                             (dq_d, 0, d), (dkv_e, 0, 2 * d), (dkv_e, d, 2 * d), Lq['ctxc'], Lq['ac'], L['attnc'],
+                fused = self._attn_block_bwd(Lq, pf, (pf + 'wo_c', pf + 'bo_c'), gA, y1, (Lq['qc'], 0, d), (ws['kvc_all'], l * 2 * d, kvld), (ws['kvc_all'], l * 2 * d + d, kvld),
+                                             (dq_d, 0, d), (dkv_all, l * 2 * d, kvld), (dkv_all, l * 2 * d + d, kvld), Lq['ctxc'], Lq['ac'], L['attnc'],
                                              Lq['mc'], Lq['rc'], wf[pf + 'lnc.w'], g[pf + 'lnc.b'], g[pf + 'lnc.w'], g1q, seed, self._site('dec', l, 1), p, B, S, S, emask, False,
                                              dbias=(g[pf + 'bq_c'], g[pf + 'bkv_c'][:d], g[pf + 'bkv_c'][d:]), T=Tq, rows=r_x, row_ids=ids_q)
                 if not fused:
                     ops.colsum(dq_d, g[pf + 'bq_c'], self.partials, Tq, d)
-                    ops.colsum(dkv_e, g[pf + 'bkv_c'], self.partials, Te, 2 * d)
+                    ops.colsum(dkv_all[:, l * 2 * d:(l + 1) * 2 * d], g[pf + 'bkv_c'], self.partials, Te, 2 * d, ld=kvld)
                 self._wgrad(dq_d, y1, pf + 'wq_c', d, d, Tq)
                 self._dgrad(dq_d, pf + 'wq_c', g1q, Tq, d, d, True)
-                self._wgrad(dkv_e, sv['enc_out'], pf + 'wkv_c', 2 * d, d, Te)
-                self._dgrad(dkv_e, pf + 'wkv_c', genc, Te, d, 2 * d, l != self.ND - 1)
+                if l == 0:
+                    # the key / value side of every layer's cross-attention, in one go: nothing before the encoder's backward reads it
+                    self._wgrad(dkv_all, sv['enc_out'], 'dec.wkv_all', kvld, d, Te)
+                    self._dgrad(dkv_all, 'dec.wkv_all', genc, Te, d, kvld, False)
                 if Tq != Td:
                     # the gradient wrt y1 lives on the loss rows: spread it over the decoder rows (zeros elsewhere) in the buffer `cur` has left
                     full = gy if g1.data_ptr() != gy.data_ptr() else galt
@@ -811,6 +843,8 @@ class Engine:
                 self._dgrad(dqkv_d, pf + 'wqkv', g2, Td, d, 3 * d, True)
                 cur = g2
                 self._ready(pf + 'wqkv', pf + 'w2')
+            if self.ND:
+                self._ready('dec.wkv_all')
             if sv.get('alt'):
                 gpre = cur
                 if p > 0.0:
@@ -942,6 +976,7 @@ class Engine:
         self.g = {}
         for name, s in self.slots.items():
             self.g[name] = self.Gcur[s.off:s.off + s.numel].view(s.shape)
+        self._alias_cross_kv(self.g)
 
     def grad_views_of(self, buf):
         return [buf[self._elem_off(s, r):self._elem_off(s, r) + p.numel()].view(p.shape) for p, (s, r) in zip(self.params, self.param_slots)]
@@ -968,9 +1003,34 @@ class Engine:
 
     def check_ids(self):
         """Synchronises. Raises IndexError if a checked batch held an id outside its embedding table."""
+        self._id_verdicts = []
         if getattr(self, '_id_flag', None) is not None and int(self._id_flag.item()) != 0:
             self._id_flag.zero_()
             raise IndexError('index out of range in self: an Octuple id lies outside its embedding table (sizes %s)' % ops.SEG_SIZES)
+
+    def _queue_id_verdict(self):
+        """The fused step does not drain the stream: the mark of note_ids travels to pinned memory behind an event and is read by
+        _raise_if_bad_ids wherever the host already knows the event has passed (pack_batch's wait in the same call; else the next call)."""
+        pool = getattr(self, '_id_pins', None)
+        if pool is None:
+            pool = self._id_pins = [[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(4)], 0]
+            self._id_verdicts = []
+        pool[1] = (pool[1] + 1) % len(pool[0])
+        pin = pool[0][pool[1]]
+        pin.copy_(self._id_flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._id_verdicts.append((pin, ev))
+        del self._id_verdicts[:-3]
+
+    def _raise_if_bad_ids(self):
+        q = getattr(self, '_id_verdicts', None)
+        while q and q[0][1].query():
+            pin, _ = q.pop(0)
+            if int(pin[0]) != 0:
+                q.clear()
+                self._id_flag.zero_()
+                raise IndexError('index out of range in self: an Octuple id lies outside its embedding table (sizes %s)' % ops.SEG_SIZES)
 
     def _next_seed(self):
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
@@ -999,15 +1059,25 @@ class Engine:
 
     # ------------------------------------------------------------------ fused pre-train step (bench / Pretrainer)
     def loss_and_grads(self, enc16, dec16, tgt16, loss_mask, emask, dmask, train=True, count_hook=None, head_w=None, w_scale=1.0,
-                       argmax_out=None):
+                       argmax_out=None, ids_checked=False):
         """Forward + fused CE/argmax/acc + full backward. Returns the (24,) device tensor of sums
-        {sum ce*m, sum m, sum correct*m} x 8 heads. `count_hook(counts)` may all-reduce the 8 mask counts (DP)."""
+        {sum ce*m, sum m, sum correct*m} x 8 heads. `count_hook(counts)` may all-reduce the 8 mask counts (DP).
+        ids_checked: the caller vouches that every id lies inside its embedding table (ids generated on the device, or a host batch it
+        has validated); otherwise the ids are range-checked here (PianoBart.py:15-16: nn.Embedding raises IndexError; an offending id is
+        replaced by 0 so that no gather leaves its table) and IndexError is raised at the first point where the host knows the verdict
+        without draining the stream: inside this call when the packing plan waits for its row counts, else on the next engine call."""
         B, S = enc16.shape[:2]
         T = B * S
+        self._raise_if_bad_ids()
+        if not ids_checked:
+            self.note_ids(enc16)
+            self.note_ids(dec16)
+            self._queue_id_verdict()
         seed = self._next_seed()
         self._select_grads(False)
         self._tables_ready = False
         pack = self._pack_batch(enc16, dec16, tgt16, loss_mask, emask, dmask) if (_PACK_ROWS and argmax_out is None) else None
+        self._raise_if_bad_ids()
         if pack is not None:
             enc16, dec16, tgt, lm = pack.enc16, pack.dec16, pack.tgt16, pack.loss_mask
             if pack.sub is not None:                                   # the last decoder layer hands over the rows with a loss term only
@@ -1044,6 +1114,7 @@ class Engine:
 
     def optimizer_step(self, lr=2e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=3.0, gscale=1.0):
         """clip_grad_norm_(3.0) + HF AdamW on the flat buffers, refreshing the bf16 shadow (pretrain.py:195-196)."""
+        self._raise_if_bad_ids()
         if self.opt_m is None:
             self.opt_m = torch.zeros_like(self.P32)
             self.opt_v = torch.zeros_like(self.P32)

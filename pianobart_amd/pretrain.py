@@ -245,6 +245,9 @@ class Pretrainer:
                 raise IndexError('index out of range in self: an Octuple id lies outside its embedding table (sizes %s)' % list(self._id_limits))
         ori = ori_seq_batch.to(self.device, non_blocking=True)
         tgt16 = ori.contiguous() if ori.dtype == torch.int16 else ops.ids_to_i16(ori.long() if ori.dtype != torch.int64 else ori)
+        if ori_seq_batch.device.type != 'cpu':                             # a batch that is already on the device: checked there, the verdict is read
+            self.engine.note_ids(tgt16)                                    # without draining the stream (Engine._raise_if_bad_ids); the corrupted and the
+            self.engine._queue_id_verdict()                                # shifted ids derive from these and from in-range specials / random tokens
         B, S = tgt16.shape[:2]
         enc16, loss_mask, _ = self._corrupt(tgt16)
         dec16 = torch.empty_like(tgt16)
@@ -309,7 +312,7 @@ class Pretrainer:
             main.wait_event(ready)
             nxt = next(it, None)
             staged = stage(nxt) if nxt is not None else None            # on the side stream, beside the step below
-            sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=train,
+            sums = eng.loss_and_grads(enc16, dec16, tgt16, loss_mask, emask, dmask, train=train, ids_checked=True,      # prepare_batch validated the host batch
                                       count_hook=self.reducer.reduce_counts if self.reducer else None)
             if train:
                 if self.reducer:

@@ -136,6 +136,11 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
         c = st['counts_h'].numpy().astype(np.int64)
     if not c[:, 3].all():
         return None
+    if int(c[:, 4].sum()) == 0:
+        # no loss position in the whole batch: pretrain.py:116-117 divides 0 by 0 in every head, the loss and EVERY gradient are NaN. The
+        # packed step would run its last layer on zero rows and leave the gradients at 0: such a batch takes the padded step, which mirrors
+        # the reference
+        return None
     (Te, off_e, len_e), (Td, off_d, len_d) = plan_packed_rows(c[:, 0], S), plan_packed_rows(c[:, 2], S)
     if Te + Td > PACK_MIN_GAIN * 2 * T:
         return None

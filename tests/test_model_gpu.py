@@ -556,6 +556,72 @@ def test_head_without_a_loss_position_is_nan_like_the_reference():
     assert torch.isnan(tot_m)
 
 
+@pytest.mark.gpu
+def test_batch_without_any_loss_position_is_nan_like_the_reference_also_under_row_packing():
+    """No loss position in ANY head (pretrain.py:116-117: 0 / 0 eight times): the reference's loss and every parameter gradient are NaN.
+    The packed step would run its last layer on zero rows and leave zero gradients; rowpack.pack_batch sends such a batch down the
+    padded step, so the bf16 engine at a packable shape (head_dim 64, rows to drop) poisons the step exactly like the reference."""
+    _need_gpu()
+    from oracle import pianobart_oracle as O
+    from pianobart_amd import ops
+    kw = dict(max_position_embeddings=256, d_model=128, encoder_layers=1, decoder_layers=2, encoder_ffn_dim=256, decoder_ffn_dim=256,
+              encoder_attention_heads=2, decoder_attention_heads=2, dropout=0.0)
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(**kw), E2W, W2E)).train()
+    randomize_params(o, 5)
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(4, 256, seed=33)
+    loss_mask = torch.zeros_like(loss_mask)
+    tot_o, *_ = O.pretrain_loss(o(enc, dec, emask, dmask), target, loss_mask, E2W)
+    tot_o.backward()
+    assert torch.isnan(tot_o) and all(torch.isnan(p.grad).all() for p in o.mask_lm.parameters())
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    m = PianoBartLM(PianoBart(BartConfig(**kw), E2W, W2E, precision='bf16')).train()
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.cuda()
+    eng = m._get_engine()
+    g = [t.cuda() for t in (enc, dec, loss_mask, emask, dmask, target)]
+    eng.bind(g[0].device)
+    assert float(emask.mean()) < 0.95                                    # rows to drop: with a loss position somewhere this batch WOULD be packed
+    sums = eng.loss_and_grads(ops.ids_to_i16(g[0]), ops.ids_to_i16(g[1]), ops.ids_to_i16(g[5]), g[2].contiguous(), g[3], g[4], train=True).cpu()
+    assert eng.last_rows[0] == 4 * 256                                   # the padded step ran
+    assert float(sums[8:16].sum()) == 0.0
+    torch.cuda.synchronize()
+    for name in ('head.w', 'dec.0.wqkv', 'enc.0.w1', 'dec.wkv_all', 'emb'):
+        assert torch.isnan(eng.g[name]).all(), name
+
+
+@pytest.mark.gpu
+def test_fused_step_checks_caller_supplied_ids():
+    """Engine.loss_and_grads on ids it did not generate (PianoBart.py:15-16: nn.Embedding raises IndexError on an id outside its table):
+    the ids are range-checked on the device, an offending id never reaches a gather, and IndexError is raised where the host learns the
+    verdict -- inside the call when the packing plan waits for its row counts anyway. ids_checked=True (the bench's generated ids, the
+    Pretrainer's validated host batch) skips the check."""
+    _need_gpu()
+    from pianobart_amd import ops
+    m = _lm(128, 128, 1, 128, 2, 9, 'bf16', dropout=0.0).train().cuda()
+    eng = m._get_engine()
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(4, 128, seed=12)]
+    eng.bind(enc.device)
+    args = lambda e, d: (ops.ids_to_i16(e), ops.ids_to_i16(d), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+    eng.loss_and_grads(*args(enc, dec), train=True)                       # clean batch
+    torch.cuda.synchronize()
+    eng._raise_if_bad_ids()
+    for col, bad in ((1, 134), (3, -5)):
+        e = enc.clone(); e[1, 7, col] = bad
+        with pytest.raises(IndexError):
+            eng.loss_and_grads(*args(e, dec), train=True)
+            torch.cuda.synchronize()
+            eng._raise_if_bad_ids()                                      # (a step that did not wait for anything learns it here at the latest)
+        d = dec.clone(); d[2, 5, col] = bad
+        with pytest.raises(IndexError):
+            eng.loss_and_grads(*args(enc, d), train=True)
+            torch.cuda.synchronize()
+            eng._raise_if_bad_ids()
+    sums = eng.loss_and_grads(*args(enc, dec), train=True)                # the mark does not stick
+    torch.cuda.synchronize()
+    eng._raise_if_bad_ids()
+    assert torch.isfinite(sums).all()
+
+
 @pytest.mark.parametrize('precision,train', [('bf16', True), ('bf16', False), ('fp32', True)])
 def test_second_stream_gives_identical_gradients(precision, train):
     """Weight-gradient GEMMs and the cross-attention K/V projections run on a second HIP stream (engine._WGRAD_STREAM): every
