@@ -296,6 +296,41 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
             E._PACK_ROWS = saved
     except Exception as ex:                                            # noqa: BLE001 -- a failed leg must not cost the main line
         out["padded_step"] = {"error": repr(ex)[:200]}
+    # (a') the same step on a batch the pre-training loop itself would build: the reference's 5-way corruption mix (pretrain.py:519-546,
+    # here pb_corrupt, choices 1..5 drawn per sample from a fixed seed) of the SAME clean sequences, decoder input = shift-right, loss mask
+    # and attention masks as Pretrainer.prepare_batch makes them. The headline batch is SURVEY 8(d)'s Bernoulli(0.15) mask, whose sparse loss
+    # rows let the last decoder layer run on a fifth of the rows; the real mix puts a loss term on almost every decoder row.
+    try:
+        import random
+        pb = model.pianobart
+        tgt16 = step.batch[2]
+        rnd = random.Random(1234)
+        ch = torch.tensor([rnd.randint(1, 5) for _ in range(B)], dtype=torch.int32, device=dev)
+        enc_r = torch.empty_like(tgt16)
+        lm_r = torch.empty(B, S, 8, dtype=torch.float32, device=dev)
+        ops.corrupt(tgt16, enc_r, lm_r, ch, None, 0.15, 0x1234ABCD, pb.pad_word_np, pb.mask_word_np, pb.n_tokens)
+        dec_r = torch.empty_like(tgt16)
+        ops.shift_right(tgt16, eng.sos16, dec_r, B, S)
+        pad = int(pb.bar_pad_word)
+        em_r, dm_r = (enc_r[:, :, 0] != pad).float(), (dec_r[:, :, 0] != pad).float()
+
+        def real_step():
+            eng.loss_and_grads(enc_r, dec_r, tgt16, lm_r, em_r, dm_r, train=True, ids_checked=True)
+            eng.optimizer_step(lr=2e-5, gscale=1.0)
+        real_step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            real_step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        Te, Td, _, Ts = eng.last_rows
+        fl = train_flops_live_rows(Te, Td, eng.last_pairs, args.hs, args.layers, args.ffn, Ts=Ts)
+        out["real_mix_step"] = {"ms_per_step": ms, "rows": {"encoder_side": Te, "decoder_side": Td, "last_layer_query_side": Ts, "of": B * S},
+                                "loss_rows_fraction": Ts / float(Td), "step_mfma_frac": fl / (ms * 1e-3) / 1e12 / peak,
+                                "tokens_per_s": B * S / (ms * 1e-3), "corruption_choices": [int(x) for x in ch.cpu()],
+                                "note": "reference corruption mix (pb_corrupt, choices 1..5 per sample, seed 1234) of the same clean sequences; 10 steps"}
+    except Exception as ex:                                            # noqa: BLE001
+        out["real_mix_step"] = {"error": repr(ex)[:200]}
     # RCCL prints its version banner on file descriptor 1 when the first communicator comes up: stdout carries the ONE JSON line and nothing
     # else, so descriptor 1 points at stderr while this leg runs
     sys.stdout.flush()

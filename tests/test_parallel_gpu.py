@@ -231,3 +231,51 @@ def test_reducer_step_at_the_bench_shape(pg):
         assert torch.equal(want, eng.G32), float((want - eng.G32).abs().max() / want.abs().max())
     finally:
         eng.grad_hook = None
+
+
+def test_two_ranks_shares_of_the_global_bench_batch_announce_the_same_exchange(pg):
+    """What an 8-GPU run of bench.py would hand ranks 0 and 5 (configs[2]: ONE global batch of 8 x 32 sequences from seed 1234, dealt by
+    length in snake order: bench.rank_share), stepped here one after the other through the reducer at world size 1: the two ranks keep
+    different rows (different packed shapes), yet they announce the SAME sequence of (lo, hi) gradient ranges -- every RCCL call of a
+    step pairs up across ranks by construction -- the ranges tile the flat buffer once, and the count hook sees the same 8 slots."""
+    import bench
+    from pianobart_amd import ops
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from pianobart_amd.parallel import GradReducer
+    cfg = BartConfig(max_position_embeddings=1024, d_model=768, encoder_layers=12, decoder_layers=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072,
+                     encoder_attention_heads=12, decoder_attention_heads=12, dropout=0.1)
+    m = PianoBartLM(PianoBart(cfg, E2W, W2E, precision='bf16'))
+    randomize_params(m, 41)
+    m = m.train().cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    glob = synth_octuple_batch(8 * 32, 1024, seed=1234)
+    lengths = glob[3].sum(1).numpy()
+    red = GradReducer(eng, 1, mode='bf16')
+    inner_ready, inner_counts = red._on_ready, red.reduce_counts
+    runs = {}
+    try:
+        for rank in (0, 5):
+            idx = torch.tensor(bench.rank_share(lengths, 8, rank), dtype=torch.long)
+            enc, dec, loss_mask, emask, dmask, target = [t[idx].contiguous().cuda() for t in glob]
+            args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+            seen, counts = [], []
+            eng.grad_hook = lambda lo, hi: (seen.append((lo, hi)), inner_ready(lo, hi))[1]
+            hook = lambda c: (counts.append((tuple(c.shape), c.dtype, c.data_ptr())), inner_counts(c))[1]
+            eng._seed = 77
+            eng.loss_and_grads(*args, train=True, count_hook=hook)
+            red.all_reduce_grads()
+            torch.cuda.synchronize()
+            assert torch.isfinite(eng.G32).all()
+            runs[rank] = (seen, counts, eng.last_rows)
+        (s0, c0, r0), (s5, c5, r5) = runs[0], runs[5]
+        assert r0 != r5                                                  # different samples, different packed shapes ...
+        assert abs(r0[0] - r5[0]) < 0.02 * r0[0] and abs(r0[1] - r5[1]) < 0.02 * r0[1]      # ... of nearly equal size: the deal balances the ranks
+        assert s0 == s5 and len(s0) > 20                                 # the same exchange schedule
+        assert c0 == c5 and len(c0) == 1 and c0[0][0] == (8,)           # one all-reduce of the 8 mask counts
+        cover = np.zeros(eng.n_total, dtype=np.int32)
+        for lo, hi in s0:
+            cover[lo:hi] += 1
+        assert (cover == 1).all()
+    finally:
+        eng.grad_hook = None

@@ -9,5 +9,5 @@ import json, os
 lines = open(os.environ['O'] + '/full_bench.json').read().strip().splitlines()
 d = json.loads(lines[-1])
 print(len(lines), 'line(s); ms/step', round(d['ms_per_step'], 2), 'frac', round(d['roofline']['frac'], 3),
-      {k: (d[k].get('ms_per_step') or d[k].get('ms_per_token') or d[k]) for k in ('padded_step', 'dp_mode_step', 'decode')})
+      {k: (d[k].get('ms_per_step') or d[k].get('ms_per_token') or d[k]) for k in ('padded_step', 'real_mix_step', 'dp_mode_step', 'decode')})
 PY
