@@ -843,6 +843,7 @@ struct Decoder {
     float* logits_host = nullptr;          // pinned
     hipEvent_t ev = nullptr;
     int launches = 0, use_graph = 1, ck_cross = 0, nsplit_cross = 0;
+    int steps = 0;                         // tokens decoded since the last reset: the device position must stay inside the caches (plan.S rows)
     size_t lds_attn = 0;
 };
 
@@ -965,6 +966,7 @@ extern "C" int pb_decoder_reset(void* dec, void* caller_stream, int32_t use_grap
     PB_CHECK_HIP(hipEventRecord(D->ev, (hipStream_t)caller_stream));
     PB_CHECK_HIP(hipStreamWaitEvent(D->stream, D->ev, 0));
     PB_CHECK_HIP(hipMemsetAsync(D->pos, 0xff, 4, D->stream));           // -1
+    D->steps = 0;
     D->use_graph = use_graph;
     if (use_graph && !D->exec) {
         PB_CHECK_HIP(hipStreamSynchronize(D->stream));
@@ -995,6 +997,9 @@ extern "C" int pb_decoder_reset(void* dec, void* caller_stream, int32_t use_grap
 extern "C" int pb_decoder_step(void* dec, const int16_t* tok8, float* logits_out) {
     Decoder* D = (Decoder*)dec;
     PB_REQUIRE(D && tok8 && logits_out, "pb_decoder_step: null argument");
+    PB_REQUIRE(D->steps < D->plan.S, "pb_decoder_step: position %d is outside the K/V caches and the position table (S = %d): call pb_decoder_reset for a new prompt",
+               D->steps, D->plan.S);
+    ++D->steps;
     for (int k = 0; k < 8; ++k) D->tok_host[k] = tok8[k];
     if (D->use_graph && D->exec) {
         PB_CHECK_HIP(hipGraphLaunch(D->exec, D->stream));

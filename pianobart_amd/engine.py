@@ -1247,7 +1247,10 @@ class Engine:
             # PB_DECODE_GRAPH=-1 keeps the round-2 loop below (A/B)
             dec = ctypes.c_void_p()
             self.last_decode = None
-            if _DECODE_GRAPH >= 0 and _DECODE_SPLIT and int(LIB.query('pb_decoder_create', pref, ctypes.byref(dec))) == 0:
+            rc_dec = int(LIB.query('pb_decoder_create', pref, ctypes.byref(dec))) if (_DECODE_GRAPH >= 0 and _DECODE_SPLIT) else 1
+            if rc_dec < 0:                                              # 1 = the fused kernels do not cover this shape (the loop below does); < 0 is an error
+                raise PBError('pb_decoder_create failed (%d): %s' % (rc_dec, LIB.load().pb_last_error().decode()))
+            if rc_dec == 0:
                 try:
                     LIB.call('pb_decoder_reset', dec, stream, _DECODE_GRAPH)
                     tok_np = np.asarray(pb.sos_word_np, dtype=np.int16).copy()

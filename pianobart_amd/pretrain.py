@@ -230,7 +230,16 @@ class Pretrainer:
         pb = self.pianobart
         if choices is None:
             choices = [random.randint(1, 5) for _ in range(B)]        # the reference's dispatcher draw (pretrain.py:520)
-        ch = torch.tensor(choices, dtype=torch.int32, device=self.device)
+        # the per-sample choices go up through a small pinned ring: torch.tensor(list, device=...) is a pageable, blocking copy, and the
+        # batch pipeline stages batch i + 1 on a side stream precisely so as not to wait for the device
+        ring = getattr(self, '_choice_pins', None)
+        if ring is None or ring[0][0].numel() < B:
+            ring = self._choice_pins = [[torch.empty(max(B, 64), dtype=torch.int32).pin_memory() for _ in range(4)], 0]
+        ring[1] = (ring[1] + 1) % len(ring[0])
+        pin = ring[0][ring[1]][:B]
+        pin.copy_(torch.as_tensor(choices, dtype=torch.int32))
+        ch = torch.empty(B, dtype=torch.int32, device=self.device)
+        ch.copy_(pin, non_blocking=True)
         out = torch.empty_like(ids16)
         lm = torch.empty(B, S, 8, dtype=torch.float32, device=self.device)
         self._step_seed = (self._step_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
@@ -264,6 +273,11 @@ class Pretrainer:
             """The log lines of one step (pretrain.py:198-207) from its 24 sums: the one device -> host read of the step."""
             nonlocal total_acc, total_losses, nb
             s = sums.double().numpy()
+            if (s[8:16] == 0).any() or not np.isfinite(s[0:8]).all():
+                # pretrain.py:117 divides by the head's mask count: a head without a loss position (or a non-finite loss) makes the loss and
+                # every gradient NaN, here as in the reference -- and AdamW then carries the NaN in its moments for good. Say so, loudly.
+                sys.stderr.write('[pianobart_amd] WARNING: loss-mask counts %s, loss sums %s: this step poisons the parameters with NaN exactly as the '
+                                 'reference does (pretrain.py:116-117); the run cannot recover from it\n' % (s[8:16].tolist(), s[0:8].tolist()))
             losses = s[0:8] / s[8:16]
             accs = s[16:24] / s[8:16]
             total_loss = float((losses * self._w).sum() / self._w.sum())
@@ -303,6 +317,7 @@ class Pretrainer:
             ev.record(main)
             return pin, ev
 
+        eng._pack_prefetch.clear()                                      # requests of an epoch that ended early (an exception between stage and step)
         it = iter(training_data)
         first = next(it, None)
         staged = stage(first) if first is not None else None

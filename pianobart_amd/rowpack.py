@@ -54,16 +54,39 @@ def dispatch_order(cost, H):
     return pairs.astype(np.int32)
 
 
-def _mask_key(loss_mask, emask, dmask):
-    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (loss_mask, emask, dmask))
+_TICKET = [0]
+
+
+def _issue_ticket(loss_mask, emask, dmask):
+    """A prefetch request and the batch it was made for are matched by a ticket, not by addresses: the kernels write the masks through raw
+    pointers (no version bump) and the caching allocator hands the next batch the same addresses. The ticket queues up on the
+    three tensor OBJECTS; the step that consumes the batch takes the front one off."""
+    _TICKET[0] += 1
+    for t in (loss_mask, emask, dmask):
+        q = getattr(t, '_pb_tickets', None)
+        if q is None:
+            q = t._pb_tickets = []
+        q.append(_TICKET[0])
+    return _TICKET[0]
+
+
+def _take_ticket(loss_mask, emask, dmask):
+    """The front ticket the three tensors share (popped), or None if they carry none / disagree."""
+    qs = [getattr(t, '_pb_tickets', None) for t in (loss_mask, emask, dmask)]
+    if any(not q for q in qs) or len({q[0] for q in qs}) != 1:
+        for q in qs:
+            if q:
+                q.clear()
+        return None
+    return [q.pop(0) for q in qs][0]
 
 
 def prefetch_counts(eng, loss_mask, emask, dmask, stream=None):
     """Ask for the per-sequence row counts of a batch the caller will hand to Engine.loss_and_grads NEXT, so that pack_batch finds them on
     the host instead of draining the step's stream for them (one kernel over the masks + a 1 KiB copy). `stream`: a stream on which the
     three mask tensors are ready (e.g. the one that produced them); default = a private stream that waits for everything the current
-    stream has been given so far. The tensors must not be modified between this call and the step (checked by their version counters:
-    a mismatch just falls back to the synchronous path)."""
+    stream has been given so far. The tensors must not be modified between this call and the step; request and batch are matched by a
+    ticket that travels on the tensor objects (a batch without the right ticket just takes the synchronous path)."""
     B, S = emask.shape[:2]
     if not (eng.use_flash and eng.hd in (64, 96, 128) and eng.code == PB_BF16 and (B * S) % PACK_TILE == 0 and eng.mlm is not None):
         return
@@ -85,7 +108,7 @@ def prefetch_counts(eng, loss_mask, emask, dmask, stream=None):
         pf['counts_h'][k].copy_(pf['counts'][k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(st)
-    eng._pack_prefetch.append(dict(key=_mask_key(loss_mask, emask, dmask), event=ev, counts_h=pf['counts_h'][k]))
+    eng._pack_prefetch.append(dict(ticket=_issue_ticket(loss_mask, emask, dmask), event=ev, counts_h=pf['counts_h'][k]))
 
 
 def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
@@ -110,10 +133,15 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
                                      enc16=torch.empty(T, 8, dtype=torch.int16, device=dev), dec16=torch.empty(T, 8, dtype=torch.int16, device=dev),
                                      tgt16=torch.empty(T, 8, dtype=torch.int16, device=dev), lm=torch.empty(T, 8, dtype=torch.float32, device=dev))
     lm3 = loss_mask.reshape(B, S, 8)
-    pf = eng._pack_prefetch.pop(0) if eng._pack_prefetch else None
-    if pf is not None and pf['key'] != _mask_key(loss_mask, emask, dmask):
-        pf = None
-        eng._pack_prefetch.clear()                       # requests for some other batch: the caller changed its mind
+    ticket = _take_ticket(loss_mask, emask, dmask)
+    pf = None
+    while eng._pack_prefetch and ticket is not None:
+        cand = eng._pack_prefetch.pop(0)
+        if cand['ticket'] == ticket:
+            pf = cand
+            break                                        # older requests (batches that never reached a step) are dropped on the way
+    if ticket is None:
+        eng._pack_prefetch.clear()                       # a batch nobody announced: whatever is queued belongs to batches that will not come
     if pf is not None:
         # the per-sequence counts of this batch were requested ahead of time (prefetch_counts): the host has them, or waits for that one
         # small copy only -- the step's stream is never drained, so the launches of this step queue up behind the previous one
