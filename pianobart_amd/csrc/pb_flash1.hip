@@ -581,17 +581,31 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
         constexpr int kt = decltype(ktt)::value;
         const int key = k0 + wave * 64 + kt * 16 + lr;
         const bool kvis = key < kvis_end && (!p.key_mask || p.key_mask[(long)b * p.Sk + (key < p.Sk ? key : 0)] != 0.f);
-        bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HDT + g * 4;
-        bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT + g * 4;
-        static_for<0, 4>([&](auto dtt) {
-            constexpr int dt = decltype(dtt)::value;
-            f32x4 vk = agpr_get<A_DK + 4 * (kt * 4 + dt)>() * p.scale, vv = agpr_get<A_DV + 4 * (kt * 4 + dt)>();
-            if (!kvis) { vk = f32x4{0.f, 0.f, 0.f, 0.f}; vv = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // 16 bytes per lane and store: the lanes of the four 16-lane rows hold columns 4 g .. 4 g + 3 of a tile; one v_permlane16_swap per dword
+        // hands rows 0 / 2 their odd neighbour's half of column tile dt0 and rows 1 / 3 their even neighbour's half of column tile dt1, so a lane
+        // ends with 8 consecutive columns (the store tail is paid per instruction: 16 stores per lane instead of 32)
+        bf16_t* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HDT + (g >> 1) * 8;
+        bf16_t* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT + (g >> 1) * 8;
+        static_for<0, 2>([&](auto dpp) {
+            constexpr int dt0 = 2 * decltype(dpp)::value, dt1 = dt0 + 1;
+            f32x4 vk0 = agpr_get<A_DK + 4 * (kt * 4 + dt0)>() * p.scale, vv0 = agpr_get<A_DV + 4 * (kt * 4 + dt0)>();
+            f32x4 vk1 = agpr_get<A_DK + 4 * (kt * 4 + dt1)>() * p.scale, vv1 = agpr_get<A_DV + 4 * (kt * 4 + dt1)>();
+            if (!kvis) { vk0 = vv0 = vk1 = vv1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            csk[dt0] += vk0; csv[dt0] += vv0; csk[dt1] += vk1; csv[dt1] += vv1;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            auto pair16 = [&](const f32x4& x, const f32x4& y) {
+                const u32x2 xu = __builtin_bit_cast(u32x2, to_bf4(x)), yu = __builtin_bit_cast(u32x2, to_bf4(y));
+                const auto s0 = __builtin_amdgcn_permlane16_swap(xu[0], yu[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(xu[1], yu[1], false, false);
+                const u32x4 r = {s0[0], s1[0], s0[1], s1[1]};
+                return r;
+            };
+            const u32x4 rk = pair16(vk0, vk1), rv = pair16(vv0, vv1);
             if (key < p.Sk) {
-                *reinterpret_cast<bf16x4*>(DK + dt * 16) = to_bf4(vk);
-                *reinterpret_cast<bf16x4*>(DV + dt * 16) = to_bf4(vv);
+                const int col = ((g & 1) ? dt1 : dt0) * 16;
+                *reinterpret_cast<u32x4*>(DK + col) = rk;
+                *reinterpret_cast<u32x4*>(DV + col) = rv;
             }
-            csk[dt] += vk; csv[dt] += vv;
         });
     });
 #ifdef PB_FA1_STAMPS
