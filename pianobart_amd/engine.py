@@ -44,8 +44,9 @@ _FWD_GEMM_FLAGS = int(os.environ.get('PB_FWD_GEMM_FLAGS', '32768'))      # PB_GE
 # dead-row compaction of the fused pre-train step (Engine._pack_batch): PB_PACK_ROWS=0 keeps every step dense
 _PACK_ROWS = int(os.environ.get('PB_PACK_ROWS', '1'))
 # head_dim-64 attention backward in ONE pass (csrc/pb_flash1.hip) instead of the dQ + dK/dV kernel pair: 0 = never, 1 = the padded
-# (dense) non-causal calls, where it measured 14 % faster (default), 2 = packed non-causal calls too (equal there), 3 = causal calls too (slower)
-_ATTN_BWD1 = int(os.environ.get('PB_ATTN_BWD1', '1'))
+# (dense) non-causal calls only (11 - 14 % faster per call), 2 = packed non-causal calls too (default: 3 % faster per call alone, 0.9 ms
+# of the 59 ms step in a same-box A/B), 3 = causal calls too (slower: a key block's waves idle through the masked half of the diagonal)
+_ATTN_BWD1 = int(os.environ.get('PB_ATTN_BWD1', '2'))
 _KV_CUT = 2      # the stacked cross-attention K / V projection is issued as layers 0 .. _KV_CUT - 1 | the rest (forward_hidden)
 
 
