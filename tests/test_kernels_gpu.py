@@ -455,3 +455,123 @@ def test_deferred_reductions_match_immediate(ops):
         for r, o in zip(ref, got):
             assert torch.equal(r, o), (arena_floats, entries, mis, float((r - o).abs().max()))
     assert all(float(r.abs().max()) > 0 for r in ref)
+
+
+@pytest.mark.parametrize('causal', [False, True])
+@pytest.mark.parametrize('S', [64, 200, 333, 520, 1100])
+@pytest.mark.parametrize('layout', ['qkv', 'cross'])
+def test_one_pass_attention_backward(ops, causal, S, layout):
+    """pb_flash_bwd1 (head_dim 64: 256 keys per workgroup, dK / dV in accumulators, dQ through bf16 slabs) vs an fp64 reference:
+    key-padding masks with holes, a padded tail, a sample without any visible key, causal, sequence lengths that are no multiple of any
+    tile (1, 2, 3 and 5 key blocks), q / k / v inside one qkv buffer or in separate q and (wide) kv buffers like the cross-attention of
+    the stacked K / V projection; the q / k / v bias gradients come from the same launch. Bounds as for the kernel pair."""
+    from pianobart_amd._lib import LIB
+    hd, B, H = 64, 3, 2
+    if causal and layout == 'cross':
+        pytest.skip('the decoder self-attention is the only causal call')
+    g = torch.Generator(device='cuda').manual_seed(S + 7 * causal)
+    d = H * hd
+    scale = hd ** -0.5
+    if layout == 'qkv':
+        buf = (torch.randn(B, S, 3 * d, device='cuda', generator=g) * 1.5).to(torch.bfloat16)
+        ql, kl, vl = (buf, 0, 3 * d, S * 3 * d), (buf, d, 3 * d, S * 3 * d), (buf, 2 * d, 3 * d, S * 3 * d)
+        leaf = buf
+    else:
+        qb = (torch.randn(B, S, d, device='cuda', generator=g) * 1.5).to(torch.bfloat16)
+        kvb = (torch.randn(B, S, 6 * d, device='cuda', generator=g) * 1.5).to(torch.bfloat16)        # layer 1 of three stacked K | V projections
+        ql, kl, vl = (qb, 0, d, S * d), (kvb, 2 * d, 6 * d, S * 6 * d), (kvb, 3 * d, 6 * d, S * 6 * d)
+    km = (torch.rand(B, S, device='cuda', generator=g) > 0.25).float()
+    km[0, 0] = 0
+    km[1, S // 2:] = 0
+    km[2] = 0                                                             # nothing visible: zero rows, zero gradients
+    kmax = torch.empty(B, dtype=torch.int32, device='cuda')
+    ops.key_extent(km, kmax)
+    out = torch.empty(B, S, d, device='cuda', dtype=torch.bfloat16)
+    lse = torch.empty(B, H, S, device='cuda')
+    ops.flash_fwd(ql, kl, vl, (out, 0, d, S * d), lse, km, B, H, S, S, hd, scale, causal, kmax=kmax)
+    if layout == 'qkv':
+        qd = buf.double().requires_grad_(True)
+        q4, k4, v4 = (qd[..., i * d:(i + 1) * d].reshape(B, S, H, hd).permute(0, 2, 1, 3) for i in range(3))
+    else:
+        qd, kvd = qb.double().requires_grad_(True), kvb.double().requires_grad_(True)
+        q4 = qd.reshape(B, S, H, hd).permute(0, 2, 1, 3)
+        k4, v4 = (kvd[..., i * d:(i + 1) * d].reshape(B, S, H, hd).permute(0, 2, 1, 3) for i in (2, 3))
+    vis = (km != 0)[:, None, None, :].expand(B, H, S, S)
+    if causal:
+        vis = vis & torch.ones(S, S, dtype=torch.bool, device='cuda').tril()
+    s = (q4 @ k4.transpose(2, 3) * scale).masked_fill(~vis, float('-inf'))
+    p = torch.nan_to_num(torch.where(vis.any(-1, keepdim=True), torch.softmax(s, -1), torch.zeros_like(s)), nan=0.0)
+    ref = (p @ v4).permute(0, 2, 1, 3).reshape(B, S, d)
+    dout = torch.randn(B, S, d, device='cuda', generator=g).to(torch.bfloat16)
+    ref.backward(dout.double())
+    delta = torch.empty(B, H, S, device='cuda')
+    db = [torch.full((d,), 0.25, device='cuda') for _ in range(3)]
+    dbws = torch.empty(int(LIB.query('pb_flash_bias_ws_floats', B, H, S, S, hd)), device='cuda')
+    if layout == 'qkv':
+        dbuf = torch.full((B, S, 3 * d), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dq, dk, dv = (dbuf, 0, 3 * d, S * 3 * d), (dbuf, d, 3 * d, S * 3 * d), (dbuf, 2 * d, 3 * d, S * 3 * d)
+    else:
+        dqb = torch.full((B, S, d), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dkvb = torch.zeros(B, S, 6 * d, device='cuda', dtype=torch.bfloat16)
+        dq, dk, dv = (dqb, 0, d, S * d), (dkvb, 2 * d, 6 * d, S * 6 * d), (dkvb, 3 * d, 6 * d, S * 6 * d)
+    ops.flash_bwd1(ql, kl, vl, (out, 0, d, S * d), dout, lse, km, dq, dk, dv, delta, B, H, S, S, hd, scale, causal, kmax=kmax, dbias=db, dbias_ws=dbws)
+    if layout == 'qkv':
+        got, want = dbuf.double(), qd.grad
+    else:
+        got = torch.cat([dqb.double(), dkvb[..., 2 * d:4 * d].double()], -1)
+        want = torch.cat([qd.grad, kvd.grad[..., 2 * d:4 * d]], -1)
+        assert float(dkvb[..., :2 * d].abs().max()) == 0.0 and float(dkvb[..., 4 * d:].abs().max()) == 0.0       # the neighbours' columns are untouched
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 3e-2, err
+    assert float(got[2].abs().max()) == 0.0                               # the sample without a visible key
+    cs = want.reshape(B * S, 3 * d).sum(0)
+    for i in range(3):
+        assert float((db[i].double() - 0.25 - cs[i * d:(i + 1) * d]).abs().max() / cs.abs().max()) < 2e-2, i
+    dsum = (dout.double() * out.double()).reshape(B, S, H, hd).sum(-1).permute(0, 2, 1)
+    assert float((delta.double() - dsum).abs().max()) < 1e-4 * max(1.0, float(dsum.abs().max()))
+
+
+def test_dispatch_order_changes_no_result(ops):
+    """bh_order (the order in which a packed attention grid takes the (batch, head) pairs, rowpack.dispatch_order: longest first, dealt in
+    snake order over the XCDs) only re-orders the work: forward, kernel-pair backward and one-pass backward give bit-identical outputs
+    with and without it. Ragged packed batch, head_dim 64."""
+    from pianobart_amd._lib import LIB
+    from pianobart_amd.rowpack import dispatch_order
+    hd, B, H, S = 64, 8, 4, 600
+    d = H * hd
+    gen = torch.Generator().manual_seed(3)
+    qlen = torch.randint(S // 3, S + 1, (B,), generator=gen)
+    kvis = (qlen - torch.randint(0, 30, (B,), generator=gen)).clamp(min=1)
+    off = torch.cat([torch.zeros(1, dtype=torch.long), qlen.cumsum(0)[:-1]])
+    T = int(qlen.sum())
+    i32 = lambda x: x.to(torch.int32).cuda()
+    order = torch.from_numpy(dispatch_order((qlen * kvis).numpy(), H)).cuda()
+    assert sorted(order.tolist()) == list(range(B * H))
+    g = torch.Generator(device='cuda').manual_seed(1)
+    qkv = (torch.randn(T, 3 * d, device='cuda', generator=g) * 0.7).to(torch.bfloat16)
+    dout = torch.randn(T, d, device='cuda', generator=g).to(torch.bfloat16)
+    q, k, v = (qkv, 0, 3 * d), (qkv, d, 3 * d), (qkv, 2 * d, 3 * d)
+    res = []
+    for o in (None, order):
+        rows = ops.PackedRows(i32(off), i32(qlen), i32(off), i32(qlen), i32(kvis), int(qlen.max()), int(qlen.max()), 'enc', order=o)
+        out = torch.full((T, d), float('nan'), device='cuda', dtype=torch.bfloat16)
+        lse = torch.zeros(B, H, rows.Sq_max, device='cuda')
+        ops.flash_fwd_packed(q, k, v, (out, 0, d), lse, rows, B, H, hd, hd ** -0.5, False)
+        grads = []
+        for one in (False, True):
+            dqkv = torch.full((T, 3 * d), float('nan'), device='cuda', dtype=torch.bfloat16)
+            delta = torch.zeros(B, H, rows.Sq_max, device='cuda')
+            db = [torch.zeros(d, device='cuda') for _ in range(3)]
+            ws = torch.empty(int(LIB.query('pb_flash_bias_ws_floats', B, H, rows.Sq_max, rows.Sk_max, hd)), device='cuda')
+            args = (q, k, v, (out, 0, d), dout, lse, (dqkv, 0, 3 * d), (dqkv, d, 3 * d), (dqkv, 2 * d, 3 * d), delta, rows, B, H, hd, hd ** -0.5, False)
+            if one:
+                ops.flash_bwd1_packed(*args, T, dbias=db, dbias_ws=ws)
+            else:
+                ops.flash_bwd_packed(*args, dbias=db, dbias_ws=ws)
+            torch.cuda.synchronize()
+            grads += [dqkv, torch.stack(db)]
+        res.append([out, lse] + grads)
+    for a, b_ in zip(*res):
+        assert torch.isfinite(b_).all() and torch.equal(a, b_)
+

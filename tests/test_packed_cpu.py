@@ -26,3 +26,18 @@ def test_plan_edge_cases():
     assert Tp == 256 and length.tolist() == [64, 64, 64, 64]
     Tp, off, length = plan_packed_rows([60, 10, 10, 10], 64, 64)        # 90 live -> 128 rows; 38 fillers: 4 to seq 0, 34 to seq 1
     assert Tp == 128 and length.tolist() == [64, 44, 10, 10] and off.tolist() == [0, 64, 108, 118]
+
+
+def test_dispatch_order_host_side():
+    """rowpack.dispatch_order: a permutation of the pairs, all heads of a sequence adjacent in cost order, the 8 XCD columns of the dealt
+    table carry equal sums to within one pair."""
+    import numpy as np
+    from pianobart_amd.rowpack import dispatch_order
+    rng = np.random.default_rng(0)
+    B, H = 32, 12
+    cost = rng.integers(512, 1025, B).astype(np.float64) ** 2
+    o = dispatch_order(cost, H)
+    assert sorted(o.tolist()) == list(range(B * H))
+    per_xcd = np.array([cost[o[x::8] // H].sum() for x in range(8)])
+    assert per_xcd.max() - per_xcd.min() <= cost.max()
+    assert cost[o[0] // H] == cost.max()

@@ -15,4 +15,5 @@ dq = (dqkv, 0, 3 * d, S * 3 * d); dk = (dqkv, d, 3 * d, S * 3 * d); dv = (dqkv, 
 for _ in range(3):
     ops.flash_fwd(q, k, v, oo, lse, None, B, H, S, S, hd, hd ** -0.5, False)
     ops.flash_bwd(q, k, v, oo, do, lse, None, dq, dk, dv, delta, B, H, S, S, hd, hd ** -0.5, False)
+    ops.flash_bwd1(q, k, v, oo, do, lse, None, dq, dk, dv, delta, B, H, S, S, hd, hd ** -0.5, False)
 torch.cuda.synchronize()
