@@ -156,6 +156,8 @@ class StepProbe:
               'ce_fwd_bwd': 'loss', 'mask_count': 'loss', 'loss_coef': 'loss', 'grad_sqnorm': 'optimizer', 'clip_coef': 'optimizer',
               'adamw_step': 'optimizer', 'fill_f32': 'optimizer', 'cast_f32_to_bf16': 'optimizer', 'defer_flush': 'rows', 'key_extent': 'rows',
               'softmax_fwd': 'attention', 'softmax_bwd': 'attention', 'flash_fwd_packed': 'attention', 'flash_bwd_packed': 'attention',
+              'flash_bwd1': 'attention', 'flash_bwd1_packed': 'attention', 'transpose_batch_bf16': 'optimizer', 'rowmap_build_sub': 'rows',
+              'scatter_rows16': 'rows', 'ce_rows': 'loss', 'ids_check': 'rows', 'sum_rows_bf16': 'optimizer', 'cast_bf16_to_f32': 'optimizer',
               'rowmap_count': 'rows', 'rowmap_build': 'rows', 'gather_rows16': 'rows', 'pos_grad_packed': 'rows'}
 
     def __init__(self, ops, pairs=None):
@@ -169,13 +171,13 @@ class StepProbe:
                                           ('*gelu\'', kw.get('gelu_grad_aux_in') is not None), ('+=', kw.get('accum', False)),
                                           ('+colsum', kw.get('colsum_out') is not None), (' splitk%d' % kw.get('splitk', 1), kw.get('splitk', 1) > 1)) if on)
             return 'gemm %s %dx%dx%d%s' % (lay, kw['M'], kw['N'], kw['K'], epi), fl
-        if name in ('flash_fwd', 'flash_bwd'):
+        if name in ('flash_fwd', 'flash_bwd', 'flash_bwd1'):                 # flash_bwd1*: the one-pass backward, flash_bwd*'s argument order
             off = 6 if name == 'flash_fwd' else 11
             B, H, Sq, Sk, hd = a[off:off + 5]
             causal = a[off + 6]
             fl = 4.0 * B * H * Sq * Sk * hd * (0.5 if causal else 1.0) * (1.0 if name == 'flash_fwd' else 2.5)
             return '%s B%d H%d S%dx%d hd%d%s' % (name, B, H, Sq, Sk, hd, ' causal' if causal else ''), fl
-        if name in ('flash_fwd_packed', 'flash_bwd_packed'):
+        if name in ('flash_fwd_packed', 'flash_bwd_packed', 'flash_bwd1_packed'):
             off = 5 if name == 'flash_fwd_packed' else 10
             rows, B, H, hd = a[off:off + 4]
             causal = a[off + 5]
