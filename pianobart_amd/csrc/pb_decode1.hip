@@ -99,23 +99,6 @@ __device__ __forceinline__ void stgf(float* p, float v) { *(D1_GLOBAL float*)p =
 __device__ __forceinline__ unsigned ld_sc1(const void* p) {
     return __hip_atomic_load((const D1_GLOBAL unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// sc1 loads of data another participant produced in this launch (plain loads may hit a stale line of the per-CU cache, and
-// buffer_inv sc1 costs 7 us: profiles/r04_xcd_probe.txt). Issue any number -- UNCONDITIONALLY: a branch around an issue could leave a
-// register copy between the issue and the wait, which would copy the register before the data has landed -- then sc1_wait() them.
-__device__ __forceinline__ void sc1_issue(u4v& v, const void* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"((const D1_GLOBAL void*)p) : "memory");
-}
-__device__ __forceinline__ void sc1_issue(u2v& v, const void* p) {
-    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"((const D1_GLOBAL void*)p) : "memory");
-}
-__device__ __forceinline__ void sc1_wait(u4v& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) :: "memory"); }
-__device__ __forceinline__ void sc1_wait(u4v& a, u4v& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) :: "memory"); }
-__device__ __forceinline__ void sc1_wait(u4v& a, u4v& b, u4v& c, u4v& d, u4v& e) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) :: "memory");
-}
-__device__ __forceinline__ void sc1_wait(u2v& a, u2v& b, u2v& c, u2v& d, u2v& e, u2v& f, u2v& g, u2v& h) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) :: "memory");
-}
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_bf(float a, float b) {
