@@ -843,7 +843,7 @@ struct Decoder {
     float* logits_host = nullptr;          // pinned
     hipEvent_t ev = nullptr;
     int launches = 0, use_graph = 1, ck_cross = 0, nsplit_cross = 0;
-    int one_xcd = 0;                       // 1: the token is pb_decode1.hip's persistent kernel on one XCD (use_graph = 2 and the shape is covered)
+    int one_xcd = 0;                       // the token is pb_decode1.hip's persistent kernel: 1 = on one XCD (use_graph = 2), 2 = on all XCDs (use_graph = 3), when the shape is covered
     pb_decode_plan* plan_dev = nullptr;    // device copy of the plan for that kernel
     unsigned* sync = nullptr;              // its barrier words
     void* mail = nullptr;                  // the rows its participants hand each other
@@ -874,7 +874,7 @@ static int decoder_issue(Decoder* D, hipStream_t st, int* count) {
     SegOff9 so;
     for (int k = 0; k < 9; ++k) so.off[k] = p->tab_off[k];
     if (D->one_xcd) {
-        if (pb_decode1_launch(p, D->plan_dev, D->pos, D->tok_dev, D->sync, D->mail, 0, st)) return -1;
+        if (pb_decode1_launch(p, D->plan_dev, D->pos, D->tok_dev, D->sync, D->mail, D->one_xcd == 2 ? -1 : 0, st)) return -1;
         *count = 1;
         return 0;
     }
@@ -933,7 +933,7 @@ extern "C" int pb_decoder_create(const pb_decode_plan* plan, void** out) {
     Decoder* D = new Decoder();
     D->plan = *plan;
     if (hipStreamCreateWithFlags(&D->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&D->ev, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&D->pos, 64) != hipSuccess || hipMalloc(&D->tok_dev, 64) != hipSuccess || hipMalloc(&D->sync, 256) != hipSuccess ||
+        hipMalloc(&D->pos, 64) != hipSuccess || hipMalloc(&D->tok_dev, 64) != hipSuccess || hipMalloc(&D->sync, 2048) != hipSuccess ||
         hipMalloc(&D->plan_dev, sizeof(pb_decode_plan)) != hipSuccess ||
         hipMemcpy(D->plan_dev, plan, sizeof(pb_decode_plan), hipMemcpyHostToDevice) != hipSuccess ||
         hipHostMalloc(&D->tok_host, 64, hipHostMallocDefault) != hipSuccess ||
@@ -980,11 +980,12 @@ extern "C" int pb_decoder_reset(void* dec, void* caller_stream, int32_t use_grap
     PB_CHECK_HIP(hipEventRecord(D->ev, (hipStream_t)caller_stream));
     PB_CHECK_HIP(hipStreamWaitEvent(D->stream, D->ev, 0));
     PB_CHECK_HIP(hipMemsetAsync(D->pos, 0xff, 4, D->stream));           // -1
-    PB_CHECK_HIP(hipMemsetAsync(D->sync, 0, 256, D->stream));
+    PB_CHECK_HIP(hipMemsetAsync(D->sync, 0, 2048, D->stream));
     D->steps = 0;
-    PB_REQUIRE(!D->exec || (use_graph == 2) == (D->one_xcd != 0), "pb_decoder_reset: a decoder keeps the form (use_graph 1 or 2) of its first prompt");
-    D->one_xcd = use_graph == 2 && pb_decode1_supported(&D->plan);
-    if (D->one_xcd && !D->mail) PB_CHECK_HIP(hipMalloc(&D->mail, (size_t)pb_decode1_mail_bytes(&D->plan)));
+    const int form = (use_graph == 2 && pb_decode1_supported(&D->plan, 0)) ? 1 : (use_graph == 3 && pb_decode1_supported(&D->plan, 1)) ? 2 : 0;
+    PB_REQUIRE(!D->exec || form == D->one_xcd, "pb_decoder_reset: a decoder keeps the form (use_graph 1, 2 or 3) of its first prompt");
+    D->one_xcd = form;
+    if (form && !D->mail) PB_CHECK_HIP(hipMalloc(&D->mail, (size_t)pb_decode1_mail_bytes(&D->plan, form == 2)));
     D->use_graph = use_graph;
     if (use_graph && !D->exec) {
         PB_CHECK_HIP(hipStreamSynchronize(D->stream));
@@ -1031,8 +1032,8 @@ extern "C" int pb_decoder_step(void* dec, const int16_t* tok8, float* logits_out
     PB_CHECK_HIP(hipStreamSynchronize(D->stream));
     if (D->one_xcd) {
         const unsigned first = *reinterpret_cast<const volatile unsigned*>(D->logits_host);
-        PB_REQUIRE(first != PB_DECODE1_POISON, "pb_decoder_step: a barrier of the one-XCD decode kernel lost an arrival (position %d): the workgroups of the launch "
-                   "were not all resident on one XCD; use pb_decoder_reset(use_graph = 1)", D->steps - 1);
+        PB_REQUIRE(first != PB_DECODE1_POISON, "pb_decoder_step: a barrier of the persistent decode kernel lost an arrival (position %d): its workgroups "
+                   "were not all resident where it expects them; use pb_decoder_reset(use_graph = 1)", D->steps - 1);
     }
     for (int k = 0; k < D->plan.vocab; ++k) logits_out[k] = D->logits_host[k];
     return 0;

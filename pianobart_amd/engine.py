@@ -26,7 +26,7 @@ _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second 
 _WG_TARGET = 192 if _WGRAD_STREAM & 1 else 256            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
 _NO_DEFER = False                  # settled (round 2): True reduces every bias / LayerNorm gradient right behind its producer
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
-_DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop, 2 = one persistent kernel per token on one XCD (pb_decode1.hip: measured slower, profiles/r04_decode_one_xcd.txt)
+_DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop, 2 / 3 = one persistent kernel per token on one XCD / on all XCDs (pb_decode1.hip: both measured slower, profiles/r04_decode_persistent.txt)
 _NO_FUSED_BIAS = False             # settled (round 2): True takes the bias gradients out of the GEMM / attention epilogues
 
 LN_EPS = 1e-5

@@ -780,12 +780,13 @@ def test_graph_decode_equals_the_per_launch_decode(monkeypatch, d, heads, S):
 
 
 @pytest.mark.parametrize('d,heads,S,ffn,layers', [(256, 4, 200, 512, 2), (256, 2, 96, 512, 2), (512, 8, 72, 512, 2), (1024, 8, 40, 512, 2), (768, 12, 130, 3072, 3)])
-def test_one_xcd_decode_kernel_equals_the_graph_decode(monkeypatch, d, heads, S, ffn, layers):
-    """Round 4, opt-in (PB_DECODE_GRAPH=2): one token = ONE persistent kernel on the 32 workgroups of one XCD (pb_decode1.hip: barriers
-    through that XCD's L2, every row handed from phase to phase at an address of its own) against the graph of 6 launches per layer:
-    the same tokens fed, the logits row of every step equal to bf16 rounding (the sums are ordered differently), bit-repeatable, one
-    launch per token, and no barrier timed out. head_dim 64 and 128, 1 .. 4 column blocks, key splits 8 and 16, self-attention over
-    1 .. 200 cached rows."""
+@pytest.mark.parametrize('mode', [2, 3])
+def test_one_xcd_decode_kernel_equals_the_graph_decode(monkeypatch, d, heads, S, ffn, layers, mode):
+    """Round 4, opt-in: one token = ONE persistent kernel (pb_decode1.hip) -- PB_DECODE_GRAPH=2: on the 32 workgroups of one XCD (barriers
+    through that XCD's L2, every row handed from phase to phase at an address of its own), =3: on 128 workgroups over all 8 XCDs (two-level
+    barrier, sc1 accesses for the exchanged rows) -- against the graph of 6 launches per layer: the same tokens fed, the logits row of
+    every step equal to bf16 rounding (the sums are ordered differently), bit-repeatable, one launch per token, and no barrier timed
+    out. head_dim 64 and 128, 1 .. 4 column blocks, key splits 4 .. 16, self-attention over 1 .. 200 cached rows."""
     _need_gpu()
     from pianobart_amd import engine as E
     m = _lm(S, d, layers, ffn, heads, 31, 'bf16').eval()
@@ -811,8 +812,8 @@ def test_one_xcd_decode_kernel_equals_the_graph_decode(monkeypatch, d, heads, S,
         return rows, eng.last_decode
 
     g, info_g = run(1)
-    o, info_o = run(2)
-    o2, _ = run(2)
+    o, info_o = run(mode)
+    o2, _ = run(mode)
     assert info_o['launches_per_token'] == 1 and info_o['graph'] and info_o['tokens'] == S, info_o
     assert info_g['launches_per_token'] == 6 * layers + 2
     worst = 0.0
@@ -821,5 +822,5 @@ def test_one_xcd_decode_kernel_equals_the_graph_decode(monkeypatch, d, heads, S,
         assert torch.equal(o[i], o2[i]), i
         keep = g[i] > -20
         worst = max(worst, _rel(o[i][keep], g[i][keep]))
-    print('one-XCD decode kernel vs graph decode d=%d hd=%d S=%d: worst logits rel %.2e' % (d, d // heads, S, worst))
+    print('persistent decode kernel (form %d) vs graph decode d=%d hd=%d S=%d: worst logits rel %.2e' % (mode, d, d // heads, S, worst))
     assert worst < 2e-2

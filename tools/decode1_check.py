@@ -34,13 +34,15 @@ for S, d, L, ffn, heads in shapes:
         eng.generate(enc, emask, feed)
         return rows, eng.last_decode
     g, ig = run(1)
-    o, io = run(2)
-    o2, io2 = run(2)
-    worst = 0.0
-    for i in range(min(len(g), len(o))):
-        keep = g[i] > -20
-        worst = max(worst, float((o[i][keep] - g[i][keep]).abs().max() / g[i][keep].abs().max()))
-    same = all(torch.equal(a, b) for a, b in zip(o, o2))
-    print('S=%d d=%d L=%d ffn=%d H=%d: rows %d/%d  worst logits rel %.2e  repeatable %s | graph %.3f ms/token (%d launches)  one-XCD %.3f / %.3f ms/token (%d launches)'
-          % (S, d, L, ffn, heads, len(o), len(g), worst, same, ig['loop_ms'] / ig['tokens'], ig['launches_per_token'], io['loop_ms'] / io['tokens'], io2['loop_ms'] / io2['tokens'],
-             io['launches_per_token']), flush=True)
+    line = 'S=%d d=%d L=%d ffn=%d H=%d: graph %.3f ms/token (%d launches)' % (S, d, L, ffn, heads, ig['loop_ms'] / ig['tokens'], ig['launches_per_token'])
+    for mode, name in ((2, 'one XCD'), (3, 'all XCDs')):
+        o, io = run(mode)
+        o2, io2 = run(mode)
+        worst = 0.0
+        for i in range(min(len(g), len(o))):
+            keep = g[i] > -20
+            worst = max(worst, float((o[i][keep] - g[i][keep]).abs().max() / g[i][keep].abs().max()))
+        same = all(torch.equal(a, b) for a, b in zip(o, o2))
+        line += ' | %s: %.3f / %.3f ms/token (%d launch), rows %d/%d, worst logits rel %.2e, repeatable %s' % (
+            name, io['loop_ms'] / io['tokens'], io2['loop_ms'] / io2['tokens'], io['launches_per_token'], len(o), len(g), worst, same)
+    print(line, flush=True)

@@ -22,7 +22,7 @@ rows = []
 def feed(row):
     rows.append(1)
     return forced[len(rows) - 1].clone() if len(rows) <= N else torch.tensor([256, 128, 129, 256, 128, 32, 254, 49])
-E._DECODE_GRAPH = 2
+E._DECODE_GRAPH = int(os.environ.get('MODE', '2'))
 m._get_engine().generate(enc, emask, feed)
 info = m._get_engine().last_decode
 print(info)
