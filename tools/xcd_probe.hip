@@ -171,7 +171,7 @@ int main() {
         }
     }
     // (b)
-    for (int poll = 2; poll < 3; ++poll) for (int th : {256, 1024}) for (int npart : {32, 64}) for (int mode = 0; mode < 3; ++mode) {
+    for (int poll = 0; poll < 3; ++poll) for (int th : {256, 1024}) for (int npart : {32, 64}) for (int mode = 0; mode < 3; ++mode) {
         const int n = 2000; float best = 1e9f; unsigned herr[4] = {0, 0, 0, 0};
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipMemset(cnt, 0, 4096)); CK(hipMemset(err, 0, 16)); CK(hipMemset(slots, 0xff, 2 * 4096 * 4));
