@@ -2,7 +2,9 @@
 """bench.py -- PianoBART pre-train step throughput on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N>1, either way: (a) python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+  (the ranks check WORLD_SIZE == N), or (b) plain `python bench.py --gpus N`: the process starts that torchrun job as a child
+  (launch_ranks: it never touches the GPU itself) and relays rank 0's line; fewer than N GPUs on the node -> non-zero exit, no line.
 
 A "step" = one pass of the hot path over one resident synthetic Octuple batch: forward (train mode,
 dropout 0.1 active) -> fused 8-head CE/argmax/acc -> full backward -> [RCCL gradient all-reduce] ->
@@ -420,6 +422,46 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, device_count=None, run=None, out=None):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: this process becomes a LAUNCHER. It never imports
+    pianobart_amd and never initialises the GPU (torch.cuda.device_count() only counts); it starts
+        python -m torch.distributed.run --nnodes 1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>
+    as a CHILD process (one rank per GPU over RCCL, the reference's nn.DataParallel replaced: pretrain.py:63-65), relays rank 0's ONE
+    JSON line to stdout and returns the child's exit code. A box with fewer than N GPUs is refused loudly: the line must never
+    say n_gpus 1 for a --gpus N request. `device_count`, `run` and `out` are injection points for the CPU test of this logic."""
+    import subprocess
+    have = torch.cuda.device_count() if device_count is None else device_count
+    if have < n:
+        sys.stderr.write('bench.py: --gpus %d requested but this node shows %d GPU(s): refusing to run (no silent fallback to fewer ranks)\n' % (n, have))
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes', '1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = (run or subprocess.run)(cmd, stdout=subprocess.PIPE, text=True, env=env)          # stderr passes through
+    lines = [l for l in (r.stdout or '').splitlines() if l.startswith('{')]
+    out = out or sys.stdout
+    if lines:
+        try:
+            rec = json.loads(lines[-1])
+        except ValueError:
+            rec = None
+        if rec is not None and r.returncode == 0 and rec.get('n_gpus') != n:
+            sys.stderr.write('bench.py: the ranks reported n_gpus %r for --gpus %d\n' % (rec.get('n_gpus'), n))
+            return 3
+        out.write(lines[-1] + '\n'); out.flush()
+    elif r.returncode == 0:
+        sys.stderr.write('bench.py: the %d ranks exited 0 without a JSON line\n' % n)
+        return 4
+    return r.returncode
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == '--cpu-baseline-child':
         return cpu_baseline_child(json.loads(sys.argv[2]), int(sys.argv[3]))
@@ -441,7 +483,11 @@ def main():
     ap.add_argument('--mode', default='pretrain', choices=['pretrain', 'decode'], help='decode = BASELINE configs[3]: KV-cached generate, B=1')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:               # plain `python bench.py --gpus N`: start the N ranks as a child job
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0)); local_rank = int(os.environ.get('LOCAL_RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree (refusing to report a line for another N)' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path): torch.cuda.is_available() is False')
     torch.cuda.set_device(local_rank)
@@ -514,6 +560,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    rccl_ranks = 1
+    if world > 1 or args.force_reducer:                              # what the collective library itself says about the job's size
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
     ms_per_step = dt / args.steps * 1e3
     tokens = B * S * world * args.steps
     value = tokens / dt
@@ -582,7 +633,7 @@ def main():
         loss = float(((s[0:8] / s[8:16]) * w8).sum() / w8.sum())
         rec = {
             "metric": "Octuple tokens/sec/GPU (seq=1024, 12L/768d) pretrain step; %MFMA peak",
-            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "tokens/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median_hip_events": ms_median, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "tokens_per_s_per_gpu": value / world,
