@@ -301,7 +301,7 @@ if __name__ == '__main__':
     fns = dict(vocab=g_vocab, g1=g1_forward, g4=g4_grads, g6=g6_gen_mask, g7=g7_sampling, g8=g8_generate,
                g9=g9_state_dict, g10=g10_cfg2_spot)
     for w in which:
-        if w in ('g11', 'g12', 'g13'):
+        if w in ('g11', 'g12', 'g13', 'g14'):
             continue
         print('==', w)
         fns[w]()
@@ -472,3 +472,80 @@ def g13_octuple_midi():
 
 if __name__ == '__main__' and 'g13' in sys.argv[1:]:
     g13_octuple_midi()
+
+
+def g14_generation_trainer():
+    """G14: the REAL reference `finetune_generation.GenerationTrainer` (finetune_generation.py:57-272) on a seeded tiny
+    model, CPU: one `iteration` in test mode (mode 2: loss, accuracies, the argmax ids `all_output`), one in valid mode and one in
+    train mode on a single batch (the per-head CE values the reference's `compute_loss` returns, the value `clip_grad_norm_` reports
+    = the gradient norm before clipping, and a few named gradients). Only quantities that do not depend on the optimizer flavour are
+    stored (`transformers.AdamW` 4.29.2 is absent here, SURVEY a-11): the train-mode loader holds ONE batch, so nothing is computed
+    after the update. `y_shift = x` (finetune_generation.py:155) and the head weights 0.3 / 1.5 / 1 (:239-250) are exercised as the
+    reference runs them, not as a formula restated in the test. The oracle forward is asserted against the same run first."""
+    import contextlib
+    import finetune_generation as ref_fg          # reference (needs the `shapesimilarity` stand-in registered at the top: FAD is a host metric)
+    S, d, L, f, h = 64, 64, 1, 128, 4
+    hf_cfg, o_cfg = cfg_pair(S, d, L, f, h, dropout=0.0)
+    x = synth_batch(4, S, seed=31)[5]
+    y = synth_batch(4, S, seed=32)[5]
+    o = O.PianoBartLM(O.PianoBart(o_cfg, E2W, W2E))
+    O_randomize(o, 13)
+    rpb = ref_pb.PianoBart(hf_cfg, E2W, W2E)
+    rlm = ref_model.PianoBartLM(rpb)
+    rlm.load_state_dict(o.state_dict(), strict=True)
+    tr = ref_fg.GenerationTrainer(rpb, [(x, y)], [(x, y)], [(x, y)], 1e-3, (4, S, 8), True, [0], model=rlm)
+    ce_log = []
+    orig_cl = tr.compute_loss
+    tr.compute_loss = lambda p, t, m: (lambda v: (ce_log.append(float(v)), v)[1])(orig_cl(p, t, m))
+    out = {'x': x.to(torch.int16), 'y': y.to(torch.int16), 'sd': np.array(sd_checksum(o.state_dict()))}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        loss, accs, fb, fa, all_output = tr.test()
+    out['test_loss'], out['test_accs'], out['test_all_output'] = loss, np.array(accs), all_output.to(torch.int16)
+    out['test_head_ce'] = np.array(ce_log[-8:], dtype=np.float64)
+    out['test_stdout'] = np.array([l for l in buf.getvalue().splitlines() if l.startswith(('Loss:', 'Acc:'))])
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        vloss, vaccs, _, _ = tr.valid()
+    assert vloss == loss and vaccs == accs
+    # the oracle on the same inputs (y_shift = x, masks from the bar column)
+    mask = (x[:, :, 0] != 256).float()
+    with torch.no_grad():
+        yh = o.eval()(x, x, mask, mask)
+    assert torch.equal(torch.stack([t.argmax(-1) for t in yh], -1), all_output.long()), 'oracle argmax differs from the reference trainer'
+    for i in range(8):
+        ce = torch.nn.functional.cross_entropy(yh[i].permute(0, 2, 1), y[..., i], reduction='none')
+        assert abs(float((ce * mask).sum() / mask.sum()) - ce_log[i]) < 2e-5 * ce_log[i], (i, ce_log[i])
+    # train mode, ONE batch: values before the update
+    grads = {}
+
+    def clip_spy(params, max_norm):
+        params = list(params)
+        for (k, _), p in zip(tr.model.named_parameters(), params):
+            if p.grad is not None:
+                grads[k] = p.grad.detach().clone()
+        return torch.nn.utils.clip_grad_norm_(params, max_norm)
+    saved = ref_fg.clip_grad_norm_
+    ref_fg.clip_grad_norm_ = clip_spy
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            tloss, taccs, _, _ = tr.train()
+    finally:
+        ref_fg.clip_grad_norm_ = saved
+    gnorm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))
+    names = ['mask_lm.proj.3.weight', 'mask_lm.proj.0.bias', 'pianobart.bart.decoder.layers.0.fc1.weight', 'pianobart.bart.encoder.layers.0.self_attn.q_proj.weight',
+             'pianobart.word_emb.3.lut.weight', 'pianobart.encoder_linear.weight', 'pianobart.bart.decoder.layernorm_embedding.weight', 'pianobart.bart.decoder.embed_positions.weight']
+    out['train_loss'], out['train_accs'], out['train_head_ce'] = tloss, np.array(taccs), np.array(ce_log[-8:], dtype=np.float64)
+    out['train_gnorm'] = float(gnorm)
+    out['train_grad_names'] = np.array(names)
+    for i, k in enumerate(names):
+        out['train_grad_%d' % i] = grads[k]
+    out['train_stdout'] = np.array([l for l in buf.getvalue().splitlines() if l.startswith(('Loss:', 'Acc:'))])
+    assert tloss == loss, (tloss, loss)                       # dropout 0: train-mode forward = eval-mode forward
+    print('G14 test loss', loss, 'accs', accs, 'gnorm', float(gnorm), 'head ce', [round(v, 5) for v in ce_log[:8]])
+    print(out['test_stdout'][0]); print(out['train_stdout'][0])
+    save('g14_generation_trainer.npz', **out)
+
+
+if __name__ == '__main__' and 'g14' in sys.argv[1:]:
+    g14_generation_trainer()

@@ -462,6 +462,29 @@ def pretrain_loss(logits, target, loss_mask, e2w):
     return total, losses, accs, torch.stack(arg, dim=-1)
 
 
+GENERATION_HEAD_WEIGHT = [1.0, 1.0, 0.3, 1.5, 1.0, 1.0, 0.3, 0.3]     # finetune_generation.py:241-248, index = head i
+
+
+def generation_step(model, x, y, e2w, pad_bar=256):
+    """GenerationTrainer.iteration for one batch, finetune_generation.py:144-250: decoder input = the encoder input itself
+    (`y_shift = x`, :155), both attention masks = (bar column != PAD) (:150-159), argmax per head (:164-170), accuracy over the
+    decoder mask (:188-193), per-head CE averaged over the decoder mask (compute_loss, :92-97) times the head weight (:239-248),
+    total = sum(loss_i * n_tok_i) / sum(n_tok) with n_tok in dict order (:237,249-250).
+    Returns total, the 8 UNWEIGHTED CE values, the 8 accuracies, argmax ids (B,S,8). Pinned by G14."""
+    mask = (x[:, :, 0] != pad_bar).float()
+    yh = model(x, x, mask, mask)
+    n_tok = loss_weights(e2w)
+    ce_all, accs, arg = [], [], []
+    for i in range(8):
+        ce = F.cross_entropy(yh[i].permute(0, 2, 1), y[..., i], reduction='none')
+        ce_all.append(torch.sum(ce * mask) / torch.sum(mask))
+        a = torch.from_numpy(np.argmax(yh[i].detach().cpu().numpy(), axis=-1)).to(y.device)
+        arg.append(a)
+        accs.append(torch.sum((y[..., i] == a).float() * mask) / torch.sum(mask))
+    total = sum(l * wt * n for l, wt, n in zip(ce_all, GENERATION_HEAD_WEIGHT, n_tok)) / sum(n_tok)
+    return total, ce_all, accs, torch.stack(arg, dim=-1)
+
+
 def hf_adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-6,
                   weight_decay=0.01, correct_bias=True):
     """transformers 4.29.2 AdamW.step (SURVEY a-11): eps added to sqrt(v) *before* bias

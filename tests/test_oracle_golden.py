@@ -174,3 +174,30 @@ def test_g6_decision_trace_carries_all_randomness():
     for c in single + batch:
         out, lm = apply_decisions_numpy(c)
         assert np.array_equal(out, c['masked']) and np.array_equal(lm, c['pos']), c['choice']
+
+
+def test_g14_generation_trainer_step():
+    """G14 = the real reference GenerationTrainer (finetune_generation.py:118-272) run by oracle/make_goldens.py: loss, per-head CE,
+    accuracies, argmax ids in test mode; gradient norm (what its clip_grad_norm_ reports) and named gradients of a train-mode batch."""
+    z = np.load(os.path.join(GOLD, 'g14_generation_trainer.npz'))
+    m = O.PianoBartLM(O.PianoBart(_cfg(64, 64, 1, 128, 4, dropout=0.0), E2W, W2E))
+    randomize_params(m, 13)
+    assert sd_checksum(m.state_dict()) == str(z['sd'])
+    x, y = torch.from_numpy(z['x']).long(), torch.from_numpy(z['y']).long()
+    with torch.no_grad():
+        total, ce, accs, arg = O.generation_step(m.eval(), x, y, E2W)
+    assert abs(round(float(total), 4) - float(z['test_loss'])) < 1.5e-4
+    assert np.allclose([float(c) for c in ce], z['test_head_ce'], rtol=2e-5)
+    assert np.allclose([round(float(a), 4) for a in accs], z['test_accs'], atol=1.01e-4)
+    assert np.array_equal(arg.numpy(), z['test_all_output'].astype(np.int64))
+    # the line the reference prints carries the WEIGHTED per-head losses (0.3 / 1.5 / 1)
+    printed = [float(v) for v in str(z['test_stdout'][0]).split('loss:')[1].split(',')]
+    assert np.allclose(printed, np.array([float(c) for c in ce]) * np.array(O.GENERATION_HEAD_WEIGHT), atol=2e-6 + 2e-5 * max(printed))
+    m.train()
+    total, ce, accs, arg = O.generation_step(m, x, y, E2W)
+    total.backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    assert abs(gn - float(z['train_gnorm'])) < 5e-4 * gn
+    for i, k in enumerate(z['train_grad_names']):
+        assert _rel(grads[str(k)], torch.from_numpy(z['train_grad_%d' % i])) < 5e-4, k
