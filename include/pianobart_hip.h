@@ -20,7 +20,7 @@ extern "C" {
 #define PB_F32 0
 #define PB_BF16 1
 
-#define PB_ABI_VERSION 5   /* 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
+#define PB_ABI_VERSION 6   /* 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
 int pb_abi_version(void);
 const char* pb_last_error(void);
 
@@ -197,6 +197,9 @@ int pb_flash_bwd_packed(const void* q, const void* k, const void* v, const void*
  * q_rows = rows of the q tensor), a second kernel adds a row's slabs in f32 in block order and rounds once. Deterministic.
  * Replaces the autograd backward of tf:modeling_bart.py:115-140 like K4. */
 int64_t pb_flash_bwd1_ws_bytes(int64_t rows, int32_t H, int32_t hd, int32_t Sk_max);
+/* 1 if the one-pass kernel takes the shape (head_dim 64, Sq_max <= 6144: its per-sequence -lse / -delta tables live in LDS; dQ slabs
+ * <= 8 GiB), else 0: call pb_flash_bwd / pb_flash_bwd_packed. rows = rows of the q side (dense: B * Sq). */
+int32_t pb_flash_bwd1_supported(int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t rows, int32_t H);
 int pb_flash_bwd1(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                   const float* key_mask, const int32_t* kmax, void* dq, void* dk, void* dv, float* delta,
                   int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss,

@@ -90,8 +90,8 @@ class _Lib:
                 fn.restype = restype
                 fn.argtypes = argtypes
             ver = dll.pb_abi_version()
-            if ver != 5:
-                raise PBError('ABI version mismatch: library %d, binding 5' % ver)
+            if ver != 6:
+                raise PBError('ABI version mismatch: library %d, binding 6' % ver)
             self._dll = dll
         return self._dll
 

@@ -754,6 +754,14 @@ extern "C" int64_t pb_flash_bwd1_ws_bytes(int64_t rows, int32_t H, int32_t hd, i
     return (int64_t)((Sk_max + KB1 - 1) / KB1) * rows * H * hd * 2;
 }
 
+// 1 when pb_flash_bwd1 / pb_flash_bwd1_packed can take the shape: head_dim 64, the per-sequence -lse / -delta tables of Sq_max queries fit the
+// 160 KiB of LDS beside the tile ring (Sq_max <= 6144) and the bf16 dQ slabs stay under 8 GiB; else 0: the caller keeps the dQ + dK/dV pair.
+extern "C" int32_t pb_flash_bwd1_supported(int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t rows, int32_t H) {
+    if (hd != 64 || Sq_max <= 0 || Sk_max <= 0 || rows <= 0 || H <= 0 || H > 128) return 0;
+    if ((size_t)OFF_TAB + (size_t)((Sq_max + 63) / 64) * 64 * 8 > 160 * 1024) return 0;
+    return pb_flash_bwd1_ws_bytes(rows, H, hd, Sk_max) <= ((int64_t)8 << 30) ? 1 : 0;
+}
+
 // One-pass backward, head_dim 64. vl = {q_off, q_len, k_off, k_len} (packed rows) or NULL (dense: batch strides). Same contract as
 // pb_flash64_bwd plus the slab workspace `ws` (pb_flash_bwd1_ws_bytes) and q_rows = rows of the q side (packed) / B * Sq (dense).
 int pb_flash1_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, const float* key_mask,
@@ -785,11 +793,8 @@ int pb_flash1_bwd(const void* q, const void* k, const void* v, const void* o, co
     }
     const size_t lds = (size_t)OFF_TAB + (size_t)((Sq + 63) / 64) * 64 * 8;
     PB_REQUIRE(lds <= 160 * 1024, "pb_flash_bwd1: Sq=%d needs %zu bytes of LDS", Sq, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fa1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // every launch, like the other kernels: the attribute is per device, and a process may drive several
+    PB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fa1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int rpb = 64;
     hipLaunchKernelGGL(fa1_delta_kernel, dim3((Sq + rpb - 1) / rpb, B), dim3(256), 0, stream, a, rpb);
     PB_LAUNCH_CHECK();

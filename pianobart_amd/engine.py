@@ -420,6 +420,9 @@ class Engine:
                     self._fbws = torch.empty(need, dtype=torch.float32, device=self.device)
                 wsb = self._fbws
             one_pass = hd == 64 and _ATTN_BWD1 >= (3 if causal else 2 if rows is not None else 1)
+            if one_pass:       # its -lse / -delta tables of a whole sequence live in LDS: beyond 6144 queries the dQ + dK/dV pair takes the call
+                one_pass = bool(LIB.query('pb_flash_bwd1_supported', rows.Sq_max if rows is not None else Sq, rows.Sk_max if rows is not None else Sk,
+                                          hd, q[0].shape[0] if rows is not None else B * Sq, H))
             if rows is not None:
                 if one_pass:
                     ops.flash_bwd1_packed(q, k, v, out, dout[0], save['lse'], dq, dk, dv, ws['delta'], rows, B, H, hd, hd ** -0.5, causal, q[0].shape[0],

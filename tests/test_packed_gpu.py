@@ -548,3 +548,42 @@ def test_one_pass_backward_in_the_padded_step(ops, monkeypatch):
     for name, sl in eng.slots.items():
         a, b_ = out[0][1][sl.off:sl.off + sl.numel], out[1][1][sl.off:sl.off + sl.numel]
         assert float((a - b_).norm()) <= 2e-2 * float(a.norm()) + 1e-6, name
+
+
+def test_one_pass_backward_hands_sequences_beyond_6144_rows_to_the_kernel_pair(ops, monkeypatch):
+    """the one-pass attention backward keeps a sequence's -lse / -delta tables in LDS and takes at most 6144 queries; the default
+    dispatch (PB_ATTN_BWD1=2) must give longer sequences to the dQ + dK/dV pair instead of failing. S = 6400, dense and packed step."""
+    from pianobart_amd import engine as E
+    from pianobart_amd._lib import LIB, PBError
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab, randomize_params, synth_octuple_batch
+    assert LIB.query('pb_flash_bwd1_supported', 6144, 6144, 64, 6144, 1) == 1 and LIB.query('pb_flash_bwd1_supported', 6400, 6400, 64, 6400, 1) == 0
+    e2w, w2e = load_vocab()
+    B, S, d = 1, 6400, 64
+    cfg = BartConfig(max_position_embeddings=S, d_model=d, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=128, decoder_ffn_dim=128,
+                     encoder_attention_heads=1, decoder_attention_heads=1, dropout=0.0)
+    m = PianoBartLM(PianoBart(cfg, e2w, w2e, precision='bf16'))
+    randomize_params(m, 3)
+    m = m.train().cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(B, S, seed=9, min_len=S - 40)]
+    args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+    out = {}
+    for pack in (0, 1):
+        for mode in (0, 2):                                               # never one-pass | the default
+            monkeypatch.setattr(E, '_PACK_ROWS', pack)
+            monkeypatch.setattr(E, '_ATTN_BWD1', mode)
+            sums = eng.loss_and_grads(*args, train=True).clone()
+            torch.cuda.synchronize()
+            out[pack, mode] = (sums, eng.Gcur.clone())
+        assert torch.equal(out[pack, 0][0], out[pack, 2][0]) and torch.equal(out[pack, 0][1], out[pack, 2][1])   # the same kernels ran
+        assert torch.isfinite(out[pack, 2][1]).all() and float(out[pack, 2][1].abs().max()) > 0
+    # the kernel itself still refuses the shape, loudly
+    q = torch.zeros(B, S, 3 * d, device='cuda', dtype=torch.bfloat16)
+    o = torch.zeros(B, S, d, device='cuda', dtype=torch.bfloat16)
+    lse = torch.zeros(B, 1, S, device='cuda')
+    with pytest.raises(PBError):
+        ops.flash_bwd1((q, 0, 3 * d, S * 3 * d), (q, d, 3 * d, S * 3 * d), (q, 2 * d, 3 * d, S * 3 * d), (o, 0, d, S * d), o, lse, None,
+                       (q, 0, 3 * d, S * 3 * d), (q, d, 3 * d, S * 3 * d), (q, 2 * d, 3 * d, S * 3 * d), torch.zeros(B, 1, S, device='cuda'),
+                       B, 1, S, S, 64, 0.125, False)
