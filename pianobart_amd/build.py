@@ -6,9 +6,10 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(HERE, 'build')
-LIB = os.path.join(HERE, 'libpianobart_hip.so')
+CSRC = os.environ.get('PB_CSRC') or os.path.join(HERE, 'csrc')      # PB_CSRC: another source tree (an older commit's csrc/ for a same-box A/B)
+# PB_LIB_OUT: build a second (diagnostic / A-B) library beside the product one: its objects go to <PB_LIB_OUT>.obj
+LIB = os.environ.get('PB_LIB_OUT') or os.path.join(HERE, 'libpianobart_hip.so')
+OBJ = (LIB + '.obj') if os.environ.get('PB_LIB_OUT') else os.path.join(HERE, 'build')
 ARCH = 'gfx950'
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc parks them in AGPRs
 # and every VALU touch of an accumulator (softmax rescale, epilogues) costs a v_accvgpr_read/write pair.

@@ -29,6 +29,12 @@ void pb_set_error(const char* fmt, ...);
     } while (0)
 #define PB_LAUNCH_CHECK() PB_CHECK_HIP(hipGetLastError())
 
+// ---- compile-time loop: f(IntTag<I>{}) for I = I0 .. N-1 (literal register numbers, immediate wait counts) -------
+template <int V> struct IntTag { static constexpr int value = V; };
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IntTag<I>{}); static_for<I + 1, N>(f); }
+}
+
 // ---- scalar conversions -------------------------------------------------------
 __device__ __forceinline__ float to_f(float x) { return x; }
 __device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }

@@ -47,10 +47,6 @@ struct Fa1Args {
 constexpr int A_DK = 0, A_DV = 64, A_KF = 128, A_VF = 160, A_KT = 192;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <int V> struct IntTag { static constexpr int value = V; };
-template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(IntTag<I>{}); static_for<I + 1, N>(f); }
-}
 template <int R> __device__ __forceinline__ void agpr_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "i"(R)); }
 template <int R> __device__ __forceinline__ void agpr_put(const bf16x8& v) {                 // a[R:R+3] = v
     const u32x4 u = __builtin_bit_cast(u32x4, v);

@@ -23,6 +23,7 @@
 #include "pb_common.h"
 #include "pb_api_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -42,6 +43,9 @@ struct Gemm2Args {
     // to tail_slabs (item-major, 256 x BN floats each) and are summed, finished and stored by tail_finish_kernel.
     int n_full, tail_split, tail_kc;
     float* tail_slabs;
+#ifdef PB_G3_STAMPS
+    unsigned long long* stamps;           // diagnostic build only (1024 x 8 x 16 u32 slots): per-wave cycle sums of the persistent loop's sections (tools/gemm_stamps.py)
+#endif
 };
 
 __device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
@@ -262,6 +266,106 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
     }
 }
 
+// Read-modify-write epilogues of the 256 x 256 ping-pong kernel (round 5): dU = (dY W2) * gelu'(U) reads a bf16 operand tile, the residual
+// accumulation C += (dY W) reads C itself. Left to hipcc, every 16-byte read of epilogue_regs is followed by s_waitcnt vmcnt(0): 16 dependent
+// memory round trips per wave and tile, each of which also drains the stores in front of it (tools/gemm_stamps.py: the epilogue of the dfc2
+// tile 18.0 us against 5.1 us for a store-only one, 9.5 us for +=). Here the reads are inline-asm loads the compiler does not track, PFD of
+// them in flight ahead of their use (into the A / B fragment registers, dead by now), the stores are asm too, and every wait is a COUNTED
+// vmcnt: loads, stores and the next item's DMA pieces retire in issue order, so "all but the N youngest" names exactly the load a chunk
+// needs. Interior tiles only (no bounds), bf16 C; everything else keeps epilogue_regs.
+//   MODE 1: C = (alpha acc + bias) * aux_in (+ column sums of the stored values)      MODE 2: C += alpha acc + bias
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr int PFD = 6;                            // 8 would spill 2 VGPRs next to the column-sum accumulators (a scratch access is a vmcnt operation too)
+// address = wave-uniform 64-bit base in SGPRs + one 32-bit lane offset + an immediate: no 64-bit vector arithmetic per chunk
+template <int IMM> __device__ __forceinline__ void pf_load(u32x4& d, unsigned voff, const char* sbase, bool nt) {
+    if (nt) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int IMM> __device__ __forceinline__ void pf_store(unsigned voff, const char* sbase, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");   // s_nop: a vector write of the data registers needs 2 wait states behind a 128-bit store (hipcc pads only its own)
+}
+__device__ __forceinline__ const char* sgpr_ptr(const void* q) {
+    const unsigned long long a = (unsigned long long)q;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    // an SGPR fresh from v_readfirstlane needs 5 wait states before a global_* instruction reads it as its base; hipcc pads that for
+    // its own instructions only, not for the ones inside an asm string (cdna_hip_programming.md 5.7 item 2): without the nops the first
+    // load of the epilogue went to a stale address (memory access fault)
+    asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+// operations issued after load `c` when chunk c is about to consume it: the schedule is  L0 .. L(PFD-1) | { wait c; S c; L (c + PFD) } for c = 0 .. 15
+constexpr int pf_younger(int c) {
+    int n = 0;
+    if (c < PFD) { n += PFD - 1 - c; for (int k = 0; k < c; ++k) n += 1 + (k + PFD < 16 ? 1 : 0); }
+    else for (int k = c - PFD + 1; k < c; ++k) n += 1 + (k + PFD < 16 ? 1 : 0);
+    return n;
+}
+template <int N> __device__ __forceinline__ void pf_wait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N) : "memory"); }
+template <int MODE, bool CS>
+__device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias, float* cs_row) {
+    const int lr = lane & 15, lg = lane >> 4;
+    const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
+    // chunk (i, jp) of the wave's 128 x 64 tile: rows i * 16 + lr, columns jp * 32 + cb .. + 7
+    const char* cbase = sgpr_ptr(reinterpret_cast<bf16_t*>(p.C) + coff + (long)mw * p.ldc + nw);
+    const char* sbase = MODE == 1 ? sgpr_ptr(p.aux_in + (long)mw * p.ldaux + nw) : cbase;
+    const unsigned cvoff = (unsigned)(lr * (int)p.ldc + cb) * 2u, svoff = MODE == 1 ? (unsigned)(lr * (int)p.ldaux + cb) * 2u : cvoff;
+    const long sstep = 32 * (MODE == 1 ? p.ldaux : p.ldc), cstep = 32 * p.ldc;          // bytes per 16 rows
+    f32x4 bv[2][2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        bv[jp][0] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[jp][1] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                   // the bias reads (LDS) are the only thing hipcc may wait for in here
+    u32x4 pf[PFD];
+    static_for<0, PFD>([&](auto cc) { constexpr int c = decltype(cc)::value; pf_load<(c & 1) * 64>(pf[c], svoff, sbase + (c >> 1) * sstep, MODE == 1); });
+    f32x4 cs[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
+    static_for<0, 16>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, i = c >> 1, jp = c & 1;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xa = acc[i][2 * jp][r], xb = acc[i][2 * jp + 1][r];
+            auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+            v0[r] = __uint_as_float(sw[0]);
+            v1[r] = __uint_as_float(sw[1]);
+        }
+        v0 = v0 * p.alpha + bv[jp][0];
+        v1 = v1 * p.alpha + bv[jp][1];
+        pf_wait<pf_younger(c)>(pf[c % PFD]);
+        const u32x4 w = pf[c % PFD];
+        const f32x4 u0 = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+        const f32x4 u1 = {__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u), __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xffff0000u)};
+        if constexpr (MODE == 1) { v0 *= u0; v1 *= u1; } else { v0 += u0; v1 += u1; }
+        const bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+        pf_store<jp * 64>(cvoff, cbase + i * cstep, __builtin_bit_cast(u32x4, r));
+        if constexpr (c + PFD < 16) pf_load<((c + PFD) & 1) * 64>(pf[c % PFD], svoff, sbase + ((c + PFD) >> 1) * sstep, MODE == 1);
+        if constexpr (CS) { cs[jp][0] += v0; cs[jp][1] += v1; }
+    });
+    if constexpr (CS) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = cs[jp][hh][e];
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+                    cs[jp][hh][e] = v;
+                }
+        if (lr == 0) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                *reinterpret_cast<f32x4*>(cs_row + nw + jp * 32 + cb) = cs[jp][0];
+                *reinterpret_cast<f32x4*>(cs_row + nw + jp * 32 + cb + 4) = cs[jp][1];
+            }
+        }
+    }
+}
+
 // One-barrier kernel. WM x WN waves, each TM x TN MFMA tiles of 16x16: block tile BM = 16*WM*TM by BN = 16*WN*TN.
 // Measured: the 128x128 main loop is bound by the L2 -> LDS load path (64 FLOP per loaded byte, ~1 PF ceiling); with two
 // workgroups per CU one's store tail overlaps the other's main loop, which is why it still serves the narrow outputs.
@@ -390,6 +494,11 @@ __device__ __forceinline__ void tr_wait_ab(s16x4 (&ta)[4][2][2], s16x4 (&tb)[2][
 }
 #undef TRW4
 
+#ifdef PB_G3_STAMPS
+#define G3_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); g3_acc[i] += now_ - g3_last; g3_last = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define G3_STAMP(i)
+#endif
 template <bool A_KC, bool B_KC, int TNW>
 __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     // TNW = column tiles (16 wide) per wave: 4 -> 256 x 256 block tile; 3 -> 256 x 192 (N = 768: 512 tiles = 2 full rounds of 256 CUs
@@ -504,23 +613,32 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         if (nk > 1) { G3_ISSUE_A(1, 0); G3_ISSUE_B(1, 1); }                                                       \
     } while (0)
     int bslot = 0;
+#ifdef PB_G3_STAMPS
+    unsigned g3_acc[6] = {0, 0, 0, 0, 0, 0}, g3_last = (unsigned)__builtin_amdgcn_s_memtime();     // 32-bit cycle sums: a launch is < 2^32 cycles
+    const unsigned g3_t0 = g3_last;
+    unsigned g3_items = 0;
+#endif
     G3_PROLOGUE();
     int pend = 0;                                                    // store instructions this wave left in flight behind the prologue
+    G3_STAMP(0);                                                     // [0] first prologue: addressing + DMA issue
     while (true) {
         // K-tile 0 of this item must have landed. vmcnt counts loads, stores and DMA pieces in ONE in-order queue, and behind
         // K-tile 0's pieces sit the 4 pieces of K-tile 1 and the `pend` stores of the previous item's epilogue (exactly 16 / 32
         // per wave when that tile was interior and store-only; 0 = "unknown", which waits for the stores too): leave them flying.
         if (nk > 1) {
-            if (pend == 32) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
+            if (pend == 36) { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+            else if (pend == 32) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
             else if (pend == 16) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
             else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         } else {
-            if (pend == 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
+            if (pend == 36) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
+            else if (pend == 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
             else if (pend == 16) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
             else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         }
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
+        G3_STAMP(1);                                                 // [1] wait for K-tile 0 (+ the stagger barrier)
         for (int kt = 0; kt < nk; ++kt) {
             const int sl = kt & 1;
             // phase 0: quadrant (0,0)
@@ -558,6 +676,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #undef G3_MID
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
+        G3_STAMP(2);                                                 // [2] K loop
         // all LDS reads of this item are complete: both slots are free for the next item's first pieces
         const int em0 = m0, en0 = n0;
         const float* ebias = reinterpret_cast<const float*>(smem + 2 * SLOT + bslot * 1024) + wc * GSB;
@@ -569,7 +688,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             item(L);
             G3_PROLOGUE();
         }
+        G3_STAMP(3);                                                 // [3] next item's addressing + DMA issue
         const bool etail = p.tail_split > 1 && eL >= p.n_full;       // the finished item was one K range of a tail tile
+        bool epf = false;                                            // the item took a prefetching epilogue: 16 loads + 16 stores (+ 4 column-sum stores) per wave
         if (etail) {
             // a tail item dumps its accumulators in register order (1 KiB per wave instruction); tail_finish_kernel knows the layout
             float* dst = p.tail_slabs + (long)(eL - p.n_full) * (256 * BNT) + wave * (8 * TNW * 256) + lane * 4;
@@ -578,9 +699,22 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #pragma unroll
                 for (int j = 0; j < TNW; ++j) *reinterpret_cast<f32x4*>(dst + (i * TNW + j) * 256) = acc[i][j] * p.alpha;
         } else if (!(p.flags & 128)) {                                 // bit 7: profiling build without the epilogue
-            epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias,
-                                  p.cs_ws ? p.cs_ws + (long)((em0 >> 8) * 2 + wr) * p.N : nullptr);
+            float* cs_row = p.cs_ws ? p.cs_ws + (long)((em0 >> 8) * 2 + wr) * p.N : nullptr;
+            if constexpr (A_KC && B_KC && TNW == 4) {
+                const int rmw = p.flags & (PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD);
+                const bool inner = em0 + 256 <= p.M && en0 + BNT <= p.N;
+                if (inner && rmw == PB_GEMM_MUL_GELU_GRAD && cs_row) { epilogue_pf<1, true>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row); epf = true; }
+                else if (inner && rmw == PB_GEMM_MUL_GELU_GRAD) { epilogue_pf<1, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
+                else if (inner && rmw == PB_GEMM_ACCUM && !cs_row) { epilogue_pf<2, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
+                else epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
+            } else {
+                epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
+            }
         }
+        G3_STAMP(4);                                                 // [4] epilogue: arithmetic + store (and load) issue
+#ifdef PB_G3_STAMPS
+        ++g3_items;
+#endif
         if (!more) break;
         if (etail) {
             pend = 8 * TNW == 32 ? 32 : 0;                            // 8 x TNW plain 16-byte stores per wave
@@ -589,12 +723,24 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             const bool plain = !(p.flags & (PB_GEMM_ACCUM | PB_GEMM_MUL_GELU_GRAD | 128));
             pend = (interior && plain) ? (((p.flags & PB_GEMM_C_F32) || (p.flags & PB_GEMM_GELU)) ? 32 : 16) : 0;
             if (((p.flags & PB_GEMM_C_F32) && (p.flags & PB_GEMM_GELU)) || p.cs_ws) pend = 0;
+            if (epf) pend = p.cs_ws ? 36 : 32;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#ifdef PB_G3_STAMPS
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G3_STAMP(5);                                                 // [5] drain: the last item's stores
+        if (lane == 0 && blockIdx.x < 1024) {                            // one 16-word slot per wave, plain stores (same-address atomics would serialize the tail)
+            unsigned* slot = reinterpret_cast<unsigned*>(p.stamps) + ((size_t)blockIdx.x * 8 + wave) * 16;
+            for (int i = 0; i < 6; ++i) slot[i] = g3_acc[i];
+            slot[6] = g3_items; slot[7] = 1u; slot[8] = (unsigned)__builtin_amdgcn_s_memtime() - g3_t0;
+        }
+    }
+#endif
 #undef G3_PROLOGUE
 #undef G3_ISSUE_A
 #undef G3_ISSUE_B
@@ -714,6 +860,10 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2; a.sC1 = d->sC1; a.sC2 = d->sC2;
     a.sCz = (long)d->M * d->N;
     a.alpha = d->alpha; a.cs_ws = nullptr;
+#ifdef PB_G3_STAMPS
+    a.stamps = nullptr;
+    if (const char* e = getenv("PB_G3_STAMP_PTR")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
     a.flags = nsplit > 1 ? (d->flags & ~PB_GEMM_ACCUM) : d->flags;          // split-K: the slabs are overwritten, the accumulation into C happens in the reduce
 
     // Tile / kernel choice, from same-process A/B runs of every cfg-2 shape (tools/gemm_ab.py, T = 32768 tokens):

@@ -1,0 +1,9 @@
+#!/bin/bash
+# gpurun with retries while the pool has no free slot (exit code 3: nothing charged):  tools/gpu.sh <timeout-seconds> '<command>'
+T=$1; shift
+for i in $(seq 1 40); do
+  /usr/local/graft/bin/gpurun --timeout $T -- "$@"; rc=$?
+  if [ $rc -ne 3 ]; then exit $rc; fi
+  sleep 45
+done
+exit 3
