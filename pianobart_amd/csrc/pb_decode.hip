@@ -843,10 +843,6 @@ struct Decoder {
     float* logits_host = nullptr;          // pinned
     hipEvent_t ev = nullptr;
     int launches = 0, use_graph = 1, ck_cross = 0, nsplit_cross = 0;
-    int one_xcd = 0;                       // the token is pb_decode1.hip's persistent kernel: 1 = on one XCD (use_graph = 2), 2 = on all XCDs (use_graph = 3), when the shape is covered
-    pb_decode_plan* plan_dev = nullptr;    // device copy of the plan for that kernel
-    unsigned* sync = nullptr;              // its barrier words
-    void* mail = nullptr;                  // the rows its participants hand each other
     int steps = 0;                         // tokens decoded since the last reset: the device position must stay inside the caches (plan.S rows)
     size_t lds_attn = 0;
 };
@@ -873,11 +869,6 @@ static int decoder_issue(Decoder* D, hipStream_t st, int* count) {
     int n = 0;
     SegOff9 so;
     for (int k = 0; k < 9; ++k) so.off[k] = p->tab_off[k];
-    if (D->one_xcd) {
-        if (pb_decode1_launch(p, D->plan_dev, D->pos, D->tok_dev, D->sync, D->mail, D->one_xcd == 2 ? -1 : 0, st)) return -1;
-        *count = 1;
-        return 0;
-    }
     hipLaunchKernelGGL(dec_embed_kernel, dim3(1), dim3(256), 0, st, D->tok_dev, p->ptab, so, p->lin_b, p->pos, p->lne_w, p->lne_b, (bf16_t*)p->x, D->pos, d, 1e-5f);
     PB_LAUNCH_CHECK(); ++n;
     char* x = (char*)p->x; char* alt = (char*)p->y2;
@@ -933,9 +924,7 @@ extern "C" int pb_decoder_create(const pb_decode_plan* plan, void** out) {
     Decoder* D = new Decoder();
     D->plan = *plan;
     if (hipStreamCreateWithFlags(&D->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&D->ev, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&D->pos, 64) != hipSuccess || hipMalloc(&D->tok_dev, 64) != hipSuccess || hipMalloc(&D->sync, 2048) != hipSuccess ||
-        hipMalloc(&D->plan_dev, sizeof(pb_decode_plan)) != hipSuccess ||
-        hipMemcpy(D->plan_dev, plan, sizeof(pb_decode_plan), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&D->pos, 64) != hipSuccess || hipMalloc(&D->tok_dev, 64) != hipSuccess ||
         hipHostMalloc(&D->tok_host, 64, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(&D->logits_host, sizeof(float) * (size_t)plan->vocab, hipHostMallocDefault) != hipSuccess) {
         pb_set_error("pb_decoder_create: allocation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -962,9 +951,6 @@ extern "C" int pb_decoder_destroy(void* dec) {
     if (D->ev) (void)hipEventDestroy(D->ev);
     if (D->pos) (void)hipFree(D->pos);
     if (D->tok_dev) (void)hipFree(D->tok_dev);
-    if (D->sync) (void)hipFree(D->sync);
-    if (D->mail) (void)hipFree(D->mail);
-    if (D->plan_dev) (void)hipFree(D->plan_dev);
     if (D->tok_host) (void)hipHostFree(D->tok_host);
     if (D->logits_host) (void)hipHostFree(D->logits_host);
     if (D->stream) (void)hipStreamDestroy(D->stream);
@@ -980,12 +966,7 @@ extern "C" int pb_decoder_reset(void* dec, void* caller_stream, int32_t use_grap
     PB_CHECK_HIP(hipEventRecord(D->ev, (hipStream_t)caller_stream));
     PB_CHECK_HIP(hipStreamWaitEvent(D->stream, D->ev, 0));
     PB_CHECK_HIP(hipMemsetAsync(D->pos, 0xff, 4, D->stream));           // -1
-    PB_CHECK_HIP(hipMemsetAsync(D->sync, 0, 2048, D->stream));
     D->steps = 0;
-    const int form = (use_graph == 2 && pb_decode1_supported(&D->plan, 0)) ? 1 : (use_graph == 3 && pb_decode1_supported(&D->plan, 1)) ? 2 : 0;
-    PB_REQUIRE(!D->exec || form == D->one_xcd, "pb_decoder_reset: a decoder keeps the form (use_graph 1, 2 or 3) of its first prompt");
-    D->one_xcd = form;
-    if (form && !D->mail) PB_CHECK_HIP(hipMalloc(&D->mail, (size_t)pb_decode1_mail_bytes(&D->plan, form == 2)));
     D->use_graph = use_graph;
     if (use_graph && !D->exec) {
         PB_CHECK_HIP(hipStreamSynchronize(D->stream));
@@ -1030,11 +1011,6 @@ extern "C" int pb_decoder_step(void* dec, const int16_t* tok8, float* logits_out
         PB_CHECK_HIP(hipMemcpyAsync(D->logits_host, D->plan.logits, sizeof(float) * (size_t)D->plan.vocab, hipMemcpyDeviceToHost, D->stream));
     }
     PB_CHECK_HIP(hipStreamSynchronize(D->stream));
-    if (D->one_xcd) {
-        const unsigned first = *reinterpret_cast<const volatile unsigned*>(D->logits_host);
-        PB_REQUIRE(first != PB_DECODE1_POISON, "pb_decoder_step: a barrier of the persistent decode kernel lost an arrival (position %d): its workgroups "
-                   "were not all resident where it expects them; use pb_decoder_reset(use_graph = 1)", D->steps - 1);
-    }
     for (int k = 0; k < D->plan.vocab; ++k) logits_out[k] = D->logits_host[k];
     return 0;
 }

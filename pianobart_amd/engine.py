@@ -26,7 +26,7 @@ _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second 
 _WG_TARGET = 192 if _WGRAD_STREAM & 1 else 256            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
 _NO_DEFER = False                  # settled (round 2): True reduces every bias / LayerNorm gradient right behind its producer
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
-_DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop, 2 / 3 = one persistent kernel per token on one XCD / on all XCDs (pb_decode1.hip: both measured slower, profiles/r04_decode_persistent.txt)
+_DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop (the persistent-kernel forms of round 4, measured slower, left the library in round 5: tools/decode1/, profiles/r04_decode_persistent.txt)
 _NO_FUSED_BIAS = False             # settled (round 2): True takes the bias gradients out of the GEMM / attention epilogues
 
 LN_EPS = 1e-5
@@ -985,6 +985,42 @@ class Engine:
     def grad_views_of(self, buf):
         return [buf[self._elem_off(s, r):self._elem_off(s, r) + p.numel()].view(p.shape) for p, (s, r) in zip(self.params, self.param_slots)]
 
+    def optimizer_state(self, model):
+        """The AdamW moments keyed by `model`'s parameter names (CPU copies), not as the flat buffers: the order of the slots in the
+        flat layout is an implementation detail that has changed between commits, parameter names have not."""
+        self.finish_updates()
+        out = {'step': self.step_count, 'exp_avg': None, 'exp_avg_sq': None}
+        if self.opt_m is not None:
+            by_id = {id(p): i for i, p in enumerate(self.params)}
+            mv, vv = self.grad_views_of(self.opt_m), self.grad_views_of(self.opt_v)
+            names = [(k, by_id[id(p)]) for k, p in model.named_parameters() if id(p) in by_id]
+            out['exp_avg'] = {k: mv[i].detach().cpu().clone() for k, i in names}
+            out['exp_avg_sq'] = {k: vv[i].detach().cpu().clone() for k, i in names}
+        return out
+
+    def load_optimizer_state(self, model, state):
+        """Inverse of optimizer_state; refuses a state whose parameter names or shapes do not match this model."""
+        self.finish_updates()
+        self.step_count = int(state.get('step', 0))
+        if state.get('exp_avg') is None:
+            self.opt_m = self.opt_v = None
+            return
+        if not isinstance(state['exp_avg'], dict):
+            raise PBError('optimizer state holds flat moment buffers without a layout (written before round 5): they cannot be matched to the '
+                          'parameters safely; resume without them')
+        if self.opt_m is None:
+            self.opt_m = torch.zeros_like(self.P32); self.opt_v = torch.zeros_like(self.P32)
+        by_id = {id(p): i for i, p in enumerate(self.params)}
+        mv, vv = self.grad_views_of(self.opt_m), self.grad_views_of(self.opt_v)
+        names = {k: by_id[id(p)] for k, p in model.named_parameters() if id(p) in by_id}
+        if set(names) != set(state['exp_avg']) or set(names) != set(state['exp_avg_sq']):
+            raise PBError('optimizer state does not match the model: %d parameters here, %d in the state' % (len(names), len(state['exp_avg'])))
+        with torch.no_grad():
+            for k, i in names.items():
+                if tuple(state['exp_avg'][k].shape) != tuple(mv[i].shape):
+                    raise PBError('optimizer state: shape of %s is %s, the model has %s' % (k, tuple(state['exp_avg'][k].shape), tuple(mv[i].shape)))
+                mv[i].copy_(state['exp_avg'][k]); vv[i].copy_(state['exp_avg_sq'][k])
+
     # ------------------------------------------------------------------ module-level (autograd) entry points
     def _prep_inputs(self, enc_ids, dec_ids, emask, dmask):
         if enc_ids.device != self.device:
@@ -999,7 +1035,9 @@ class Engine:
 
     def note_ids(self, ids16):
         """Enqueue the range check of (..., 8) Octuple ids (PianoBart.py:15-16: nn.Embedding raises IndexError on an id outside its
-        table); the verdict is read by check_ids() at a point where the host waits for the device anyway."""
+        table); the verdict is read by check_ids() at a point where the host waits for the device anyway. NOTE: the kernel rewrites an
+        offending id to 0 IN PLACE (int16 inputs are not copied), so that the gathers queued behind it stay inside their tables; a batch
+        that trips the check is followed by IndexError, so the rewritten tensor is never a silently different input."""
         if getattr(self, '_id_flag', None) is None or self._id_flag.device != ids16.device:
             self._id_flag = torch.zeros(1, dtype=torch.int32, device=ids16.device)
             self._id_lim = torch.tensor(ops.SEG_SIZES, dtype=torch.int32, device=ids16.device)
@@ -1027,9 +1065,14 @@ class Engine:
         self._id_verdicts.append((pin, ev))
         del self._id_verdicts[:-3]
 
-    def _raise_if_bad_ids(self):
+    def _raise_if_bad_ids(self, wait=False):
+        """wait: block until every queued verdict has landed (optimizer_step: nn.Embedding raises BEFORE any update, PianoBart.py:15-16, so the
+        update must not be enqueued for a batch whose verdict is still out; the range check is the first kernel of its step, the wait ends
+        long before the step does, and only callers that hand over unchecked ids ever queue one)."""
         q = getattr(self, '_id_verdicts', None)
-        while q and q[0][1].query():
+        while q and (wait or q[0][1].query()):
+            if wait:
+                q[0][1].synchronize()
             pin, _ = q.pop(0)
             if int(pin[0]) != 0:
                 q.clear()
@@ -1118,7 +1161,7 @@ class Engine:
 
     def optimizer_step(self, lr=2e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=3.0, gscale=1.0):
         """clip_grad_norm_(3.0) + HF AdamW on the flat buffers, refreshing the bf16 shadow (pretrain.py:195-196)."""
-        self._raise_if_bad_ids()
+        self._raise_if_bad_ids(wait=True)
         if self.opt_m is None:
             self.opt_m = torch.zeros_like(self.P32)
             self.opt_v = torch.zeros_like(self.P32)

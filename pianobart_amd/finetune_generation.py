@@ -150,8 +150,7 @@ class GenerationTrainer:
         eng = self.engine
         state = {'epoch': epoch + 1, 'state_dict': {k: v.detach().cpu() for k, v in self.model.state_dict().items()}, 'valid_acc': valid_acc,
                  'valid_loss': valid_loss, 'train_loss': train_loss, 'train_acc': train_acc,
-                 'optimizer': {'step': eng.step_count, 'lr': self.lr, 'exp_avg': None if eng.opt_m is None else eng.opt_m.cpu(),
-                               'exp_avg_sq': None if eng.opt_v is None else eng.opt_v.cpu()}}
+                 'optimizer': dict(eng.optimizer_state(self.model), lr=self.lr)}            # moments keyed by parameter name
         torch.save(state, filename)
         if is_best:
             shutil.copyfile(filename, filename.split('.')[0] + '_best.ckpt')

@@ -205,12 +205,9 @@ class Pretrainer:
         return self.iteration(self.valid_data, self.max_seq_len, train=False)
 
     def save_checkpoint(self, epoch, best_acc, valid_acc, valid_loss, train_loss, is_best, filename):
-        """pretrain.py:96-110: same dict keys; 'state_dict' holds PianoBart only; optimizer = flat HF-AdamW state."""
+        """pretrain.py:96-110: same dict keys; 'state_dict' holds PianoBart only; optimizer = HF-AdamW state, moments keyed by parameter name."""
         eng = self.engine
-        eng.finish_updates()                                    # a pipelined parameter update may still be writing the moments
-        opt = {'step': eng.step_count, 'lr': self.lr, 'betas': (0.9, 0.999), 'eps': 1e-6, 'weight_decay': 0.01,
-               'exp_avg': None if eng.opt_m is None else eng.opt_m.detach().cpu(),
-               'exp_avg_sq': None if eng.opt_v is None else eng.opt_v.detach().cpu()}
+        opt = dict(eng.optimizer_state(self.model), lr=self.lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01)   # waits for a pipelined update
         state = {'epoch': epoch + 1, 'state_dict': {k: v.detach().cpu() for k, v in self.pianobart.state_dict().items()},
                  'best_acc': best_acc, 'valid_acc': valid_acc, 'valid_loss': valid_loss, 'train_loss': train_loss, 'optimizer': opt}
         torch.save(state, filename)

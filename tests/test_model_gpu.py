@@ -777,50 +777,3 @@ def test_graph_decode_equals_the_per_launch_decode(monkeypatch, d, heads, S):
     # a second prompt through a fresh decoder of the same engine: nothing is left over from the first
     g2, _ = run(1)
     assert all(torch.equal(a, b) for a, b in zip(g, g2))
-
-
-@pytest.mark.parametrize('d,heads,S,ffn,layers', [(256, 4, 200, 512, 2), (256, 2, 96, 512, 2), (512, 8, 72, 512, 2), (1024, 8, 40, 512, 2), (768, 12, 130, 3072, 3)])
-@pytest.mark.parametrize('mode', [2, 3])
-def test_one_xcd_decode_kernel_equals_the_graph_decode(monkeypatch, d, heads, S, ffn, layers, mode):
-    """Round 4, opt-in: one token = ONE persistent kernel (pb_decode1.hip) -- PB_DECODE_GRAPH=2: on the 32 workgroups of one XCD (barriers
-    through that XCD's L2, every row handed from phase to phase at an address of its own), =3: on 128 workgroups over all 8 XCDs (two-level
-    barrier, sc1 accesses for the exchanged rows) -- against the graph of 6 launches per layer: the same tokens fed, the logits row of
-    every step equal to bf16 rounding (the sums are ordered differently), bit-repeatable, one launch per token, and no barrier timed
-    out. head_dim 64 and 128, 1 .. 4 column blocks, key splits 4 .. 16, self-attention over 1 .. 200 cached rows."""
-    _need_gpu()
-    from pianobart_amd import engine as E
-    m = _lm(S, d, layers, ffn, heads, 31, 'bf16').eval()
-    with torch.no_grad():
-        for i, p0 in enumerate([256, 128, 129, 256, 128, 32, 254, 49]):
-            m.mask_lm.proj[i].bias[p0:] = -30.0
-    m = m.cuda()
-    enc = synth_octuple_batch(1, S, seed=8, min_len=S - 9)[5].cuda()
-    emask = (enc[:, :, 0] != 256).float()
-    forced = synth_octuple_batch(1, S, seed=23, min_len=S)[5][0]
-    forced[-1] = forced[-2]
-    eng = m._get_engine()
-
-    def run(mode):
-        monkeypatch.setattr(E, '_DECODE_GRAPH', mode)
-        rows = []
-
-        def feed(row):
-            rows.append(row.clone())
-            return forced[len(rows) - 1].clone()
-        out = eng.generate(enc, emask, feed)
-        assert torch.equal(out[0].cpu(), forced)
-        return rows, eng.last_decode
-
-    g, info_g = run(1)
-    o, info_o = run(mode)
-    o2, _ = run(mode)
-    assert info_o['launches_per_token'] == 1 and info_o['graph'] and info_o['tokens'] == S, info_o
-    assert info_g['launches_per_token'] == 6 * layers + 2
-    worst = 0.0
-    for i in range(S):
-        assert torch.isfinite(o[i]).all()
-        assert torch.equal(o[i], o2[i]), i
-        keep = g[i] > -20
-        worst = max(worst, _rel(o[i][keep], g[i][keep]))
-    print('persistent decode kernel (form %d) vs graph decode d=%d hd=%d S=%d: worst logits rel %.2e' % (mode, d, d // heads, S, worst))
-    assert worst < 2e-2

@@ -143,6 +143,54 @@ def test_generation_trainer_step_matches_the_reference_trainer_g14(capsys):
     assert l1 < tloss                                                     # the update went downhill
 
 
+def test_optimizer_state_is_keyed_by_parameter_name_and_resumes_bit_for_bit():
+    """the AdamW moments travel keyed by state_dict names (the flat layout is an implementation detail): two steps, save, one more
+    step -- against a FRESH model that loads the weights and the named moments and takes the same third step: identical parameters. A state
+    with flat buffers (older commits) or foreign names is refused."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from pianobart_amd import ops
+    from pianobart_amd._lib import PBError
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import randomize_params
+    kw = dict(max_position_embeddings=64, d_model=64, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=128,
+              decoder_ffn_dim=128, encoder_attention_heads=1, decoder_attention_heads=1, dropout=0.0)
+    enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(2, 64, seed=3)]
+    args = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+
+    def fresh():
+        m = PianoBartLM(PianoBart(BartConfig(**kw), E2W, W2E, precision='bf16'))
+        randomize_params(m, 5)
+        m = m.train().cuda()
+        eng = m._get_engine(); eng.bind(torch.device('cuda', 0))
+        return m, eng
+
+    def step(eng):
+        eng.loss_and_grads(*args, train=True, ids_checked=True)
+        eng.optimizer_step(lr=1e-3)
+    m, eng = fresh()
+    step(eng); step(eng)
+    st = eng.optimizer_state(m)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    assert st['step'] == 2 and set(st['exp_avg']) == {k for k, _ in m.named_parameters() if not k.endswith('shared.weight')}
+    assert all(st['exp_avg'][k].shape == p.shape for k, p in m.named_parameters() if k in st['exp_avg'])
+    step(eng); torch.cuda.synchronize()
+    want = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m2, eng2 = fresh()
+    m2.load_state_dict(sd, strict=True)
+    eng2.bind(torch.device('cuda', 0)); eng2.refresh_shadow(force=True)
+    eng2.load_optimizer_state(m2, st)
+    step(eng2); torch.cuda.synchronize()
+    got = m2.state_dict()
+    for k in want:
+        assert torch.equal(want[k], got[k].cpu()), k
+    with pytest.raises(PBError):
+        eng2.load_optimizer_state(m2, {'step': 2, 'exp_avg': torch.zeros(8), 'exp_avg_sq': torch.zeros(8)})
+    bad = dict(st, exp_avg={('x.' + k): v for k, v in st['exp_avg'].items()})
+    with pytest.raises(PBError):
+        eng2.load_optimizer_state(m2, bad)
+
+
 def test_mmap_int16_shard_feeds_the_same_batch_as_the_int64_path(tmp_path):
     """a memory-mapped int16 shard -> DataLoader -> Pretrainer.prepare_batch gives bit-identical device tensors to the
     reference-format int64 array path (same corruption seed), and the ids reach the device as int16 without a conversion kernel."""
