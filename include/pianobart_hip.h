@@ -20,7 +20,7 @@ extern "C" {
 #define PB_F32 0
 #define PB_BF16 1
 
-#define PB_ABI_VERSION 6   /* 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
+#define PB_ABI_VERSION 7   /* 7 (round 5): + PB_GEMM_ROWDOT / rowdot_out in pb_gemm_desc, delta_rows in pb_flash_bwd1*; 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
 int pb_abi_version(void);
 const char* pb_last_error(void);
 
@@ -44,6 +44,7 @@ const char* pb_last_error(void);
                                     occupy the idle CUs (f32 partials, finished by a second small launch); a cost model decides.
                                     Pays for a caller that runs one GEMM at a time (N = 768 at 26 624 rows: +13-17 %): the training
                                     step asks for it in forward; in backward its second stream already fills those CUs     */
+#define PB_GEMM_ROWDOT 131072     /* C = result as usual, and per 64-column group the row sums of C * aux_in go to rowdot_out (see pb_gemm_desc) */
 #define PB_GEMM_ROW_SPLIT 65536  /* 256x256 kernel: the M tiles of the full rounds of the persistent grid stay with it, the remaining rows go to a
                                     second launch of the 128x128 kernel (no partials). Measured (round 3): -1.8 % on the one-stream step
                                     together with nothing else, +-0 on the shipped two-stream step (its second stream already fills the CUs a
@@ -64,6 +65,10 @@ typedef struct pb_gemm_desc {
                                          cotangent, e.g. db1 from dU): taken from the epilogue registers of the 256x256 kernel, by a
                                          pb_colsum pass over C otherwise. Needs colsum_ws; single batch, no split-K */
     float* colsum_ws;                 /* workspace of pb_gemm_colsum_ws_floats(M, N) floats */
+    float* rowdot_out; int64_t ld_rowdot; /* PB_GEMM_ROWDOT (ABI 7): rowdot_out[(n / 64) * ld_rowdot + m] = sum over columns 64 (n / 64) .. + 63 of
+                                         bf16(C[m][.]) * aux_in[m][.], f32 -- with C = dO (the input gradient of the attention output
+                                         projection) and aux_in = O this is the delta = rowsum(dO * O) per head that pb_flash_bwd1* reads
+                                         (delta_rows). NT layout, M and N multiples of 256, bf16, no other epilogue; refused otherwise */
 } pb_gemm_desc;
 int pb_gemm(const pb_gemm_desc* d, void* stream);
 int64_t pb_gemm_colsum_ws_floats(int32_t M, int32_t N);
@@ -195,6 +200,8 @@ int pb_flash_bwd_packed(const void* q, const void* k, const void* v, const void*
  * products and one exp pass per (query, key) pair instead of 7 and 2). dQ is summed over the key blocks without atomics: block j
  * writes its partial into bf16 slab j of dq_ws (pb_flash_bwd1_ws_bytes(rows of the q side, H, hd, Sk_max) bytes; packed rows:
  * q_rows = rows of the q tensor), a second kernel adds a row's slabs in f32 in block order and rounds once. Deterministic.
+ * delta_rows (ABI 7, may be NULL): delta = rowsum(dO * O) per head as [H][rows of the q side] (dense: row = b * Sq + s), e.g. written by the
+ * PB_GEMM_ROWDOT epilogue of the GEMM that produced dO; NULL = the call computes it itself into `delta` (B, H, Sq) with one more launch.
  * Replaces the autograd backward of tf:modeling_bart.py:115-140 like K4. */
 int64_t pb_flash_bwd1_ws_bytes(int64_t rows, int32_t H, int32_t hd, int32_t Sk_max);
 /* 1 if the one-pass kernel takes the shape (head_dim 64, Sq_max <= 6144: its per-sequence -lse / -delta tables live in LDS; dQ slabs
@@ -206,14 +213,14 @@ int pb_flash_bwd1(const void* q, const void* k, const void* v, const void* o, co
                   int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss,
                   int64_t dq_sb, int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss,
                   float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws,
-                  void* dq_ws, void* stream);
+                  void* dq_ws, const float* delta_rows, void* stream);
 int pb_flash_bwd1_packed(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                          void* dq, void* dk, void* dv, float* delta, const int32_t* q_off, const int32_t* q_len,
                          const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H,
                          int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss,
                          int64_t dq_ss, int64_t dk_ss, int64_t dv_ss, float scale, int32_t causal,
                          float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* dq_ws, int64_t q_rows,
-                         const int32_t* bh_order, void* stream);
+                         const int32_t* bh_order, const float* delta_rows, void* stream);
 
 /* ---- row maps for the packed step (pb_rowmap.hip) ------------------------------------------------
  * pb_rowmap_count: counts (B,8) int32 = {encoder rows visible as keys (emask != 0), decoder rows visible as keys (dmask != 0),

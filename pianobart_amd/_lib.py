@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('PB_LIB_PATH') or os.path.join(HERE, 'libpianobart_hip
 
 PB_F32, PB_BF16 = 0, 1
 GEMM_ACCUM, GEMM_C_F32, GEMM_GELU, GEMM_MUL_GELU_GRAD = 1, 2, 4, 8
+GEMM_ROWDOT = 131072
 
 
 class GemmDesc(ctypes.Structure):
@@ -28,7 +29,8 @@ class GemmDesc(ctypes.Structure):
                 ('sC1', ctypes.c_int64), ('sC2', ctypes.c_int64),
                 ('alpha', ctypes.c_float), ('_pad2', ctypes.c_float),
                 ('splitk', ctypes.c_int32), ('_pad3', ctypes.c_int32), ('slabs', ctypes.c_void_p),
-                ('colsum_out', ctypes.c_void_p), ('colsum_ws', ctypes.c_void_p)]
+                ('colsum_out', ctypes.c_void_p), ('colsum_ws', ctypes.c_void_p),
+                ('rowdot_out', ctypes.c_void_p), ('ld_rowdot', ctypes.c_int64)]
 
 
 class DecodeLayer(ctypes.Structure):
@@ -90,8 +92,8 @@ class _Lib:
                 fn.restype = restype
                 fn.argtypes = argtypes
             ver = dll.pb_abi_version()
-            if ver != 6:
-                raise PBError('ABI version mismatch: library %d, binding 6' % ver)
+            if ver != 7:
+                raise PBError('ABI version mismatch: library %d, binding 7' % ver)
             self._dll = dll
         return self._dll
 

@@ -29,6 +29,7 @@ struct Fa1Args {
     Fa64Args a;
     bf16_t* slab;                              // dQ partial of key block j: slab + j * slab_stride, rows as the q rows, row stride H * 64
     long slab_stride, slab_sb;                 // slab_sb: batch stride of a slab (dense layout; unused with packed rows)
+    const float* delta_rows; long delta_ld;    // optional: delta[h * delta_ld + row of the q side] (made by pb_gemm's PB_GEMM_ROWDOT epilogue) instead of a.delta (B, H, Sq)
     unsigned* stamps;                          // diagnostic build only (-DPB_FA1_STAMPS): 16 per-phase cycle sums + 1 step count, added by every wave
 };
 
@@ -189,12 +190,13 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     float* ldsND = ldsNL + nt * 64;
     float* ldsVis = reinterpret_cast<float*>(smem + OFF_DS);               // 1 / 0 per key of the block (the dS buffers are not in use yet)
     const long li0 = ((long)b * p.H + h) * lse_ld;
+    const float* dsrc = pin.delta_rows ? pin.delta_rows + (long)h * pin.delta_ld + (pin.a.vl_q_off ? (long)pin.a.vl_q_off[b] : (long)b * pin.a.Sq) : p.delta + li0;
     float tl[4], td[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = it0 * 64 + t + i * FT;
         tl[i] = q < p.Sq ? p.lse[li0 + q] : INFINITY;
-        td[i] = q < p.Sq ? p.delta[li0 + q] : 0.f;
+        td[i] = q < p.Sq ? dsrc[q] : 0.f;
     }
     const int key_t = k0 + t;                                              // FT = KB1 = 256: one key per thread
     const float vis_t = (key_t < kvis_end && (!p.key_mask || p.key_mask[(long)b * p.Sk + key_t] != 0.f)) ? 1.f : 0.f;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     for (int q = it0 * 64 + t + 4 * FT; q < nt * 64; q += FT) {            // sequences beyond 1024 queries: the rest, one round trip per 256
         const float ls = q < p.Sq ? p.lse[li0 + q] : INFINITY;
         ldsNL[q] = ls == INFINITY ? -INFINITY : -ls * LOG2E;
-        ldsND[q] = q < p.Sq ? -p.delta[li0 + q] : 0.f;
+        ldsND[q] = q < p.Sq ? -dsrc[q] : 0.f;
     }
     ldsVis[t] = vis_t;
     PSTAMP(1);
@@ -763,8 +765,10 @@ extern "C" int32_t pb_flash_bwd1_supported(int32_t Sq_max, int32_t Sk_max, int32
 int pb_flash1_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, const float* key_mask,
                   const int* kmax, void* dq, void* dk, void* dv, int B, int H, int Sq, int Sk, long q_sb, long q_ss, long k_sb, long k_ss, long v_sb,
                   long v_ss, long o_sb, long o_ss, long dq_sb, long dq_ss, long dk_sb, long dk_ss, long dv_sb, long dv_ss, float scale,
-                  int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* ws, long q_rows, hipStream_t stream, const int* const* vl) {
+                  int causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws, void* ws, long q_rows, hipStream_t stream, const int* const* vl,
+                  const float* delta_rows) {
     Fa1Args A = {};
+    A.delta_rows = delta_rows; A.delta_ld = q_rows;
     Fa64Args& a = A.a;
     if (vl) { a.vl_q_off = vl[0]; a.vl_q_len = vl[1]; a.vl_k_off = vl[2]; a.vl_k_len = vl[3]; a.bh_order = vl[4]; }
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dout = (const bf16_t*)dout;
@@ -792,8 +796,10 @@ int pb_flash1_bwd(const void* q, const void* k, const void* v, const void* o, co
     // every launch, like the other kernels: the attribute is per device, and a process may drive several
     PB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fa1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int rpb = 64;
-    hipLaunchKernelGGL(fa1_delta_kernel, dim3((Sq + rpb - 1) / rpb, B), dim3(256), 0, stream, a, rpb);
-    PB_LAUNCH_CHECK();
+    if (!delta_rows) {                                                     // the caller's GEMM epilogue has not made the row sums: one pass over dO and O
+        hipLaunchKernelGGL(fa1_delta_kernel, dim3((Sq + rpb - 1) / rpb, B), dim3(256), 0, stream, a, rpb);
+        PB_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(fa1_bwd_kernel, dim3(nkb * H * B), dim3(FT), lds, stream, A);
     PB_LAUNCH_CHECK();
     const int G = H * 8;
@@ -811,14 +817,14 @@ extern "C" int pb_flash_bwd1(const void* q, const void* k, const void* v, const 
                              int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb,
                              int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb, int64_t dq_ss, int64_t dk_sb, int64_t dk_ss,
                              int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws,
-                             void* dq_ws, void* stream_) {
+                             void* dq_ws, const float* delta_rows, void* stream_) {
     PB_REQUIRE(hd == 64, "pb_flash_bwd1: head_dim %d (64 only)", hd);
     PB_REQUIRE(q_ss % 8 == 0 && k_ss % 8 == 0 && v_ss % 8 == 0 && o_ss % 8 == 0 && dq_ss % 8 == 0 && dk_ss % 8 == 0 && dv_ss % 8 == 0 &&
                q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0 && dq_sb % 8 == 0, "pb_flash_bwd1: strides must be multiples of 8 elements");
     if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return 0;
     return pb_flash1_bwd(q, k, v, o, dout, lse, delta, key_mask, kmax, dq, dk, dv, B, H, Sq, Sk, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss,
                          dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss, scale, causal & 1, dbias_q, dbias_k, dbias_v, dbias_ws, dq_ws, (long)B * Sq,
-                         (hipStream_t)stream_, nullptr);
+                         (hipStream_t)stream_, nullptr, delta_rows);
 }
 
 extern "C" int pb_flash_bwd1_packed(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
@@ -826,7 +832,7 @@ extern "C" int pb_flash_bwd1_packed(const void* q, const void* k, const void* v,
                                     const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd,
                                     int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss, int64_t dq_ss, int64_t dk_ss, int64_t dv_ss,
                                     float scale, int32_t causal, float* dbias_q, float* dbias_k, float* dbias_v, float* dbias_ws,
-                                    void* dq_ws, int64_t q_rows, const int32_t* bh_order, void* stream_) {
+                                    void* dq_ws, int64_t q_rows, const int32_t* bh_order, const float* delta_rows, void* stream_) {
     PB_REQUIRE(hd == 64, "pb_flash_bwd1_packed: head_dim %d (64 only)", hd);
     PB_REQUIRE(q_ss % 8 == 0 && k_ss % 8 == 0 && v_ss % 8 == 0 && o_ss % 8 == 0 && dq_ss % 8 == 0 && dk_ss % 8 == 0 && dv_ss % 8 == 0,
                "pb_flash_bwd1_packed: strides must be multiples of 8 elements");
@@ -834,5 +840,5 @@ extern "C" int pb_flash_bwd1_packed(const void* q, const void* k, const void* v,
     if (B <= 0 || H <= 0 || Sq_max <= 0 || Sk_max <= 0) return 0;
     const int* vl[5] = {q_off, q_len, k_off, k_len, bh_order};
     return pb_flash1_bwd(q, k, v, o, dout, lse, delta, nullptr, k_vis, dq, dk, dv, B, H, Sq_max, Sk_max, 0, q_ss, 0, k_ss, 0, v_ss, 0, o_ss,
-                         0, dq_ss, 0, dk_ss, 0, dv_ss, scale, causal & 1, dbias_q, dbias_k, dbias_v, dbias_ws, dq_ws, q_rows, (hipStream_t)stream_, vl);
+                         0, dq_ss, 0, dk_ss, 0, dv_ss, scale, causal & 1, dbias_q, dbias_k, dbias_v, dbias_ws, dq_ws, q_rows, (hipStream_t)stream_, vl, delta_rows);
 }

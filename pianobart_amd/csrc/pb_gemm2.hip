@@ -38,6 +38,7 @@ struct Gemm2Args {
     int nb2; long sA1, sA2, sB1, sB2, sC1, sC2, sCz;
     float alpha; int flags; int tiles_m, tiles_n, nsplit;
     float* cs_ws;                         // column-sum partials (2 tiles_m rows of N floats) or NULL
+    float* rowdot; long ld_rowdot;        // PB_GEMM_ROWDOT: rowdot[(n / 64) * ld_rowdot + m] = sum over the 64-column group of C[m][.] * aux_in[m][.]
     // tail split (gemm3_kernel, nsplit == 1): work items 0 .. n_full - 1 are whole tiles; the tiles of the last, partly filled
     // round of the persistent grid are cut into tail_split K ranges each, one work item per range, whose f32 partial tiles go
     // to tail_slabs (item-major, 256 x BN floats each) and are summed, finished and stored by tail_finish_kernel.
@@ -274,6 +275,8 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
 // vmcnt: loads, stores and the next item's DMA pieces retire in issue order, so "all but the N youngest" names exactly the load a chunk
 // needs. Interior tiles only (no bounds), bf16 C; everything else keeps epilogue_regs.
 //   MODE 1: C = (alpha acc + bias) * aux_in (+ column sums of the stored values)      MODE 2: C += alpha acc + bias
+//   MODE 3: C = alpha acc + bias, and rowdot[column group of 64][row] = sum over the group of bf16(C) * aux_in: the delta = rowsum(dO * O) per
+//           head of the attention backward, taken where dO is made (the out-projection's input gradient) instead of by a pass over dO and O
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr int PFD = 6;                            // 8 would spill 2 VGPRs next to the column-sum accumulators (a scratch access is a vmcnt operation too)
 // address = wave-uniform 64-bit base in SGPRs + one 32-bit lane offset + an immediate: no 64-bit vector arithmetic per chunk
@@ -294,10 +297,11 @@ __device__ __forceinline__ const char* sgpr_ptr(const void* q) {
     return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 // operations issued after load `c` when chunk c is about to consume it: the schedule is  L0 .. L(PFD-1) | { wait c; S c; L (c + PFD) } for c = 0 .. 15
-constexpr int pf_younger(int c) {
+// (MODE 3 adds one more store, the row sums of a 16-row group, behind the store of every odd chunk)
+constexpr int pf_younger(int c, int mode) {
     int n = 0;
-    if (c < PFD) { n += PFD - 1 - c; for (int k = 0; k < c; ++k) n += 1 + (k + PFD < 16 ? 1 : 0); }
-    else for (int k = c - PFD + 1; k < c; ++k) n += 1 + (k + PFD < 16 ? 1 : 0);
+    if (c < PFD) { n += PFD - 1 - c; for (int k = 0; k < c; ++k) n += 1 + (k + PFD < 16 ? 1 : 0) + ((mode == 3 && (k & 1)) ? 1 : 0); }
+    else for (int k = c - PFD + 1; k < c; ++k) n += 1 + (k + PFD < 16 ? 1 : 0) + ((mode == 3 && (k & 1)) ? 1 : 0);
     return n;
 }
 template <int N> __device__ __forceinline__ void pf_wait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N) : "memory"); }
@@ -307,9 +311,9 @@ __device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][
     const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
     // chunk (i, jp) of the wave's 128 x 64 tile: rows i * 16 + lr, columns jp * 32 + cb .. + 7
     const char* cbase = sgpr_ptr(reinterpret_cast<bf16_t*>(p.C) + coff + (long)mw * p.ldc + nw);
-    const char* sbase = MODE == 1 ? sgpr_ptr(p.aux_in + (long)mw * p.ldaux + nw) : cbase;
-    const unsigned cvoff = (unsigned)(lr * (int)p.ldc + cb) * 2u, svoff = MODE == 1 ? (unsigned)(lr * (int)p.ldaux + cb) * 2u : cvoff;
-    const long sstep = 32 * (MODE == 1 ? p.ldaux : p.ldc), cstep = 32 * p.ldc;          // bytes per 16 rows
+    const char* sbase = MODE != 2 ? sgpr_ptr(p.aux_in + (long)mw * p.ldaux + nw) : cbase;
+    const unsigned cvoff = (unsigned)(lr * (int)p.ldc + cb) * 2u, svoff = MODE != 2 ? (unsigned)(lr * (int)p.ldaux + cb) * 2u : cvoff;
+    const long sstep = 32 * (MODE != 2 ? p.ldaux : p.ldc), cstep = 32 * p.ldc;          // bytes per 16 rows
     f32x4 bv[2][2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
@@ -318,7 +322,10 @@ __device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                                   // the bias reads (LDS) are the only thing hipcc may wait for in here
     u32x4 pf[PFD];
-    static_for<0, PFD>([&](auto cc) { constexpr int c = decltype(cc)::value; pf_load<(c & 1) * 64>(pf[c], svoff, sbase + (c >> 1) * sstep, MODE == 1); });
+    float rd = 0.f;
+    const char* rbase = MODE == 3 ? sgpr_ptr(p.rowdot + (long)(nw >> 6) * p.ld_rowdot + mw) : nullptr;      // + 16 rows = 64 bytes per row group
+    const unsigned rvoff = (unsigned)lr * 4u;
+    static_for<0, PFD>([&](auto cc) { constexpr int c = decltype(cc)::value; pf_load<(c & 1) * 64>(pf[c], svoff, sbase + (c >> 1) * sstep, MODE != 2); });
     f32x4 cs[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
     static_for<0, 16>([&](auto cc) {
         constexpr int c = decltype(cc)::value, i = c >> 1, jp = c & 1;
@@ -332,14 +339,29 @@ __device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][
         }
         v0 = v0 * p.alpha + bv[jp][0];
         v1 = v1 * p.alpha + bv[jp][1];
-        pf_wait<pf_younger(c)>(pf[c % PFD]);
+        pf_wait<pf_younger(c, MODE)>(pf[c % PFD]);
         const u32x4 w = pf[c % PFD];
         const f32x4 u0 = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
         const f32x4 u1 = {__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u), __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xffff0000u)};
-        if constexpr (MODE == 1) { v0 *= u0; v1 *= u1; } else { v0 += u0; v1 += u1; }
+        if constexpr (MODE == 1) { v0 *= u0; v1 *= u1; } else if constexpr (MODE == 2) { v0 += u0; v1 += u1; }
         const bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
         pf_store<jp * 64>(cvoff, cbase + i * cstep, __builtin_bit_cast(u32x4, r));
-        if constexpr (c + PFD < 16) pf_load<((c + PFD) & 1) * 64>(pf[c % PFD], svoff, sbase + ((c + PFD) >> 1) * sstep, MODE == 1);
+        if constexpr (MODE == 3) {
+            // the products use the ROUNDED values, as a pass over the stored tensor would; a row's 64 columns lie in the two chunks of 4 lanes
+            float s8 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s8 = fmaf((float)r[e], u0[e], s8); s8 = fmaf((float)r[4 + e], u1[e], s8); }
+            if constexpr (jp == 0) rd = s8;
+            else {
+                float s = rd + s8;
+                auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+                s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+                auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+                s = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+                asm volatile("global_store_dword %0, %1, %2" :: "v"(rvoff), "v"(s), "s"(rbase + i * 64) : "memory");    // every lane of a row holds the sum: 4 lanes write the same word
+            }
+        }
+        if constexpr (c + PFD < 16) pf_load<((c + PFD) & 1) * 64>(pf[c % PFD], svoff, sbase + ((c + PFD) >> 1) * sstep, MODE != 2);
         if constexpr (CS) { cs[jp][0] += v0; cs[jp][1] += v1; }
     });
     if constexpr (CS) {
@@ -626,12 +648,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         // K-tile 0's pieces sit the 4 pieces of K-tile 1 and the `pend` stores of the previous item's epilogue (exactly 16 / 32
         // per wave when that tile was interior and store-only; 0 = "unknown", which waits for the stores too): leave them flying.
         if (nk > 1) {
-            if (pend == 36) { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+            if (pend == 40) { asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); }
+            else if (pend == 36) { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
             else if (pend == 32) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
             else if (pend == 16) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
             else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         } else {
-            if (pend == 36) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
+            if (pend == 40) { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+            else if (pend == 36) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
             else if (pend == 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
             else if (pend == 16) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
             else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -690,7 +714,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         }
         G3_STAMP(3);                                                 // [3] next item's addressing + DMA issue
         const bool etail = p.tail_split > 1 && eL >= p.n_full;       // the finished item was one K range of a tail tile
-        bool epf = false;                                            // the item took a prefetching epilogue: 16 loads + 16 stores (+ 4 column-sum stores) per wave
+        bool epf = false, epf3 = false;                              // the item took a prefetching epilogue: 16 loads + 16 stores (+ 4 column-sum stores, or + 8 row-sum stores) per wave
         if (etail) {
             // a tail item dumps its accumulators in register order (1 KiB per wave instruction); tail_finish_kernel knows the layout
             float* dst = p.tail_slabs + (long)(eL - p.n_full) * (256 * BNT) + wave * (8 * TNW * 256) + lane * 4;
@@ -701,11 +725,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         } else if (!(p.flags & 128)) {                                 // bit 7: profiling build without the epilogue
             float* cs_row = p.cs_ws ? p.cs_ws + (long)((em0 >> 8) * 2 + wr) * p.N : nullptr;
             if constexpr (A_KC && B_KC && TNW == 4) {
-                const int rmw = p.flags & (PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD);
+                const int rmw = p.flags & (PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | PB_GEMM_ROWDOT);
                 const bool inner = em0 + 256 <= p.M && en0 + BNT <= p.N;
                 if (inner && rmw == PB_GEMM_MUL_GELU_GRAD && cs_row) { epilogue_pf<1, true>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row); epf = true; }
                 else if (inner && rmw == PB_GEMM_MUL_GELU_GRAD) { epilogue_pf<1, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
                 else if (inner && rmw == PB_GEMM_ACCUM && !cs_row) { epilogue_pf<2, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
+                else if (rmw == PB_GEMM_ROWDOT) { epilogue_pf<3, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf3 = true; }   // the host admits whole tiles only
                 else epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
             } else {
                 epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
@@ -724,6 +749,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             pend = (interior && plain) ? (((p.flags & PB_GEMM_C_F32) || (p.flags & PB_GEMM_GELU)) ? 32 : 16) : 0;
             if (((p.flags & PB_GEMM_C_F32) && (p.flags & PB_GEMM_GELU)) || p.cs_ws) pend = 0;
             if (epf) pend = p.cs_ws ? 36 : 32;
+            if (epf3) pend = 40;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -860,6 +886,17 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2; a.sC1 = d->sC1; a.sC2 = d->sC2;
     a.sCz = (long)d->M * d->N;
     a.alpha = d->alpha; a.cs_ws = nullptr;
+    a.rowdot = nullptr; a.ld_rowdot = 0;
+    if (d->flags & PB_GEMM_ROWDOT) {
+        // only the form the attention backward asks for: whole 256 x 256 tiles of the NT ping-pong kernel, bf16 C, an operand tile to
+        // multiply with, no other epilogue -- anything else is refused loudly (the caller then runs the row-sum pass itself)
+        if (!(a_kc && b_kc) || nsplit != 1 || d->M % 256 || d->N % 256 || c32 || !d->aux_in || !d->rowdot_out || d->ld_rowdot < d->M || d->colsum_out ||
+            (d->flags & (PB_GEMM_ACCUM | PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | PB_GEMM_TILE128 | 2048)) || (d->nb1 > 1) || (d->nb2 > 1) || d->M < 256) {
+            pb_set_error("pb_gemm: PB_GEMM_ROWDOT needs the NT layout, M and N multiples of 256, bf16 C, aux_in, rowdot_out / ld_rowdot and no other epilogue");
+            return -2;
+        }
+        a.rowdot = d->rowdot_out; a.ld_rowdot = d->ld_rowdot;
+    }
 #ifdef PB_G3_STAMPS
     a.stamps = nullptr;
     if (const char* e = getenv("PB_G3_STAMP_PTR")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
@@ -871,7 +908,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // NN dfc1 937 vs 899, TN w1 930 vs 820 (one-barrier 256x256) -- and 128x128 tiles (2 workgroups per CU) below that and for
     // the small split-K wgrads (768 x 768: 692 vs 620 TF). TN callers pass PB_GEMM_TILE256 together with their split-K factor.
     const bool big = !(d->flags & PB_GEMM_TILE128) && d->M >= 256 && d->N >= 256 &&
-                     ((d->flags & PB_GEMM_TILE256) || (nsplit == 1 && d->M >= 2048 && d->N >= 512));
+                     ((d->flags & (PB_GEMM_TILE256 | PB_GEMM_ROWDOT)) || (nsplit == 1 && d->M >= 2048 && d->N >= 512));
     // (A 256 x 192 instantiation -- 512 tiles = 2 full rounds at N = 768, T = 32768 -- measured +4-6 % back to back and -1.5 ms on the whole
     // step in round 2: every A row panel is then streamed by 4 column tiles instead of 3. It lost its A/B and was removed in round 3.)
     constexpr bool wide192 = false;
@@ -879,6 +916,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // layouts (NN dgrad without the transposed weight copies) take the one-barrier 256 x 256 kernel: their ping-pong
     // instantiations kept two VGPRs in scratch around the K loop (code-object metadata) and are not built any more.
     const bool pingpong = big && !(d->flags & 2048) && a_kc == b_kc;
+    if ((d->flags & PB_GEMM_ROWDOT) && !pingpong) { pb_set_error("pb_gemm: PB_GEMM_ROWDOT is implemented by the 256 x 256 ping-pong kernel only"); return -2; }
     const int BMs = big ? 256 : 128, BNs = big ? (wide192 ? 192 : 256) : 128;
     a.tiles_m = (d->M + BMs - 1) / BMs; a.tiles_n = (d->N + BNs - 1) / BNs;
     a.nsplit = nsplit;
@@ -892,7 +930,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     } while (0)
     bool cs_fused = false;
     a.n_full = 0; a.tail_split = 1; a.tail_kc = 0; a.tail_slabs = nullptr;
-    if (pingpong && (d->flags & PB_GEMM_TAIL_SPLIT) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 && !d->colsum_out &&
+    if (pingpong && (d->flags & PB_GEMM_TAIL_SPLIT) && !(d->flags & PB_GEMM_ROWDOT) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 && !d->colsum_out &&
         !(d->flags & (PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | 128))) {
         // The persistent grid runs ceil(tiles / CUs) rounds; a last round that fills only part of the chip (N = 768: 312 tiles =
         // 1.22 rounds at 26 624 rows, 384 = 1.5 at 32 768) costs a whole one. Cut those tiles' K range so that they occupy the CUs
@@ -930,7 +968,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     // 1.53 nk + 6.5, a round of the 128 x 128 kernel 0.75 nk + 4 (one workgroup per CU) or 1.0 nk + 4 (two), a kernel boundary 2.
     Gemm2Args rest;
     bool row_split = false;
-    if (pingpong && a.tail_split == 1 && (d->flags & PB_GEMM_ROW_SPLIT) && !(d->flags & (4096 | 128)) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 &&
+    if (pingpong && a.tail_split == 1 && (d->flags & PB_GEMM_ROW_SPLIT) && !(d->flags & (4096 | 128 | PB_GEMM_ROWDOT)) && !wide192 && nsplit == 1 && nb1 * a.nb2 == 1 &&
         !d->colsum_out && d->M % 8 == 0) {
         const int ncu = pb_num_cus(), ntile = a.tiles_m * a.tiles_n, rounds = ntile / ncu, rem = ntile % ncu, nkt = d->K / BK;
         if (rounds >= 1 && rem > 0) {

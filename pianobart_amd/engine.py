@@ -26,6 +26,7 @@ _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second 
 _WG_TARGET = 192 if _WGRAD_STREAM & 1 else 256            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
 _NO_DEFER = False                  # settled (round 2): True reduces every bias / LayerNorm gradient right behind its producer
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
+_ROWDOT = int(os.environ.get('PB_ROWDOT', '1'))                                  # 1 = delta of the one-pass attention backward from the out-projection dgrad's epilogue (0: a separate pass)
 _DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop (the persistent-kernel forms of round 4, measured slower, left the library in round 5: tools/decode1/, profiles/r04_decode_persistent.txt)
 _NO_FUSED_BIAS = False             # settled (round 2): True takes the bias gradients out of the GEMM / attention epilogues
 
@@ -405,8 +406,17 @@ class Engine:
         ops.gemm(P, vt, ot, M=Sq, N=hd, K=Sk, dtype=self.code, b_kc=False, lda=Sk, ldb=vl, ldc=ol, nb1=B, nb2=H,
                  sA=(H * Sq * Sk, Sq * Sk), sB=(Sk * vl, hd), sC=(Sq * ol, hd), b_off=vo, c_off=oo)
 
-    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save, out=None, key_mask=None, causal=False, dbias=None, rows=None):
-        """dbias = (gq, gk, gv) bias-gradient vectors: filled here when the attention kernels can do it (returns True), else left to the caller."""
+    def _one_pass_bwd(self, causal, rows, B, Sq, Sk, q_rows):
+        """Whether the attention backward of this call is the one-pass kernel (head_dim 64; PB_ATTN_BWD1; its -lse / -delta tables of a whole
+        sequence live in LDS: beyond 6144 queries the dQ + dK/dV pair takes the call)."""
+        if not (self.use_flash and self.hd == 64 and _ATTN_BWD1 >= (3 if causal else 2 if rows is not None else 1)):
+            return False
+        return bool(LIB.query('pb_flash_bwd1_supported', rows.Sq_max if rows is not None else Sq, rows.Sk_max if rows is not None else Sk,
+                              self.hd, q_rows, self.H))
+
+    def _attn_bwd(self, dout, q, k, v, dq, dk, dv, B, Sq, Sk, save, out=None, key_mask=None, causal=False, dbias=None, rows=None, delta_rows=None):
+        """dbias = (gq, gk, gv) bias-gradient vectors: filled here when the attention kernels can do it (returns True), else left to the caller.
+        delta_rows: rowsum(dO * O) per head, [H][rows], already made by the GEMM that produced dout (PB_GEMM_ROWDOT); one-pass kernel only."""
         H, hd = self.H, self.hd
         ws = self._cur_ws
         if self.use_flash:
@@ -419,14 +429,12 @@ class Engine:
                 if getattr(self, '_fbws', None) is None or self._fbws.numel() < need:
                     self._fbws = torch.empty(need, dtype=torch.float32, device=self.device)
                 wsb = self._fbws
-            one_pass = hd == 64 and _ATTN_BWD1 >= (3 if causal else 2 if rows is not None else 1)
-            if one_pass:       # its -lse / -delta tables of a whole sequence live in LDS: beyond 6144 queries the dQ + dK/dV pair takes the call
-                one_pass = bool(LIB.query('pb_flash_bwd1_supported', rows.Sq_max if rows is not None else Sq, rows.Sk_max if rows is not None else Sk,
-                                          hd, q[0].shape[0] if rows is not None else B * Sq, H))
+            one_pass = self._one_pass_bwd(causal, rows, B, Sq, Sk, q[0].shape[0] if rows is not None else B * Sq)
+            assert one_pass or delta_rows is None
             if rows is not None:
                 if one_pass:
                     ops.flash_bwd1_packed(q, k, v, out, dout[0], save['lse'], dq, dk, dv, ws['delta'], rows, B, H, hd, hd ** -0.5, causal, q[0].shape[0],
-                                          dbias=dbias if fuse else None, dbias_ws=wsb)
+                                          dbias=dbias if fuse else None, dbias_ws=wsb, delta_rows=delta_rows)
                 else:
                     ops.flash_bwd_packed(q, k, v, out, dout[0], save['lse'], dq, dk, dv, ws['delta'], rows, B, H, hd, hd ** -0.5, causal,
                                          dbias=dbias if fuse else None, dbias_ws=wsb)
@@ -434,7 +442,7 @@ class Engine:
             (ops.flash_bwd1 if one_pass else ops.flash_bwd)(
                 ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
                 ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal, kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None,
-                dbias=dbias if fuse else None, dbias_ws=wsb)
+                dbias=dbias if fuse else None, dbias_ws=wsb, **({'delta_rows': delta_rows} if one_pass else {}))
             return fuse
         dP, dS, P = ws['scores'], ws['dS'], save['P']
         (qt, qo, ql), (kt, ko, kl), (vt, vo, vl) = q, k, v
@@ -761,9 +769,25 @@ class Engine:
         ops.add_ln_bwd(gy, x_in, a, lnw, mean, rstd, gout, da, lnw_g, lnb_g, g[bo], self.partials, False, seed, site, p, row_ids=row_ids)
         gb = gB if p > 0 else gout
         self._wgrad(gb, ctx, wo, d, d, T)
-        self._dgrad(gb, wo, gC, T, d, d, False)
+        # the one-pass attention backward needs delta = rowsum(dO * O) per head: dO is made right here, so the row sums come out of this GEMM's
+        # epilogue (PB_GEMM_ROWDOT: the O tile rides in as the epilogue's operand) instead of a pass over dO and O in front of the attention kernel
+        delta_rows = None
+        if _ROWDOT and self.code == PB_BF16 and T % 256 == 0 and d % 256 == 0 and self.wT.get(wo) is not None and \
+                self._one_pass_bwd(causal, rows, B, Sq, Sk, q[0].shape[0] if rows is not None else B * Sq):
+            ldr = q[0].shape[0] if rows is not None else B * Sq           # = the q_rows the attention call reports: row stride of the [H][rows] table
+            assert ldr >= T
+            delta_rows = self._delta_rows(ldr)
+            self._dgrad(gb, wo, gC, T, d, d, False, rowdot=(ctx, delta_rows, ldr))
+        else:
+            self._dgrad(gb, wo, gC, T, d, d, False)
         return self._attn_bwd((gC, 0, d), q, k, v, dq, dk, dv, B, Sq, Sk, attn_save, out=(ctx, 0, d), key_mask=key_mask, causal=causal, dbias=dbias,
-                              rows=rows)
+                              rows=rows, delta_rows=delta_rows)
+
+    def _delta_rows(self, T):
+        buf = getattr(self, '_drows', None)
+        if buf is None or buf.numel() < self.H * T:
+            buf = self._drows = torch.empty(self.H * T, dtype=torch.float32, device=self.device)
+        return buf[:self.H * T]
 
     def backward(self, gy_dec, gy_enc_extra=None):
         """gy_dec: grad wrt decoder output (T,d) storage dtype (None for encoder-only). Writes all parameter gradients

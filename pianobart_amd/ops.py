@@ -7,7 +7,7 @@ import os
 import torch
 
 from ._lib import (LIB, PB_BF16, PB_F32, GemmDesc, PBError, GEMM_ACCUM, GEMM_C_F32, GEMM_GELU,
-                   GEMM_MUL_GELU_GRAD)
+                   GEMM_MUL_GELU_GRAD, GEMM_ROWDOT)
 
 SEG_SIZES = [262, 134, 135, 262, 134, 38, 260, 55]          # PianoBart.classes order
 SEG_OFF = [0]
@@ -54,8 +54,9 @@ _ENV_GEMM_FLAGS = int(os.environ.get('PB_GEMM_FLAGS', '0'))
 def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, ldc=None, bias=None, alpha=1.0,
          accum=False, c_f32=False, gelu_aux_out=None, gelu_grad_aux_in=None, ldaux=0, nb1=1, nb2=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, splitk=1, slabs=None, force_v1=False, tile128=False, tile256=False, dbg=0,
-         colsum_out=None, colsum_ws=None):
-    """C[m,n] (+)= epi(alpha * sum_k A(m,k) B(n,k)). a_off/b_off/c_off are element offsets into the tensors."""
+         colsum_out=None, colsum_ws=None, rowdot=None):
+    """C[m,n] (+)= epi(alpha * sum_k A(m,k) B(n,k)). a_off/b_off/c_off are element offsets into the tensors.
+    rowdot = (aux (M, N) storage dtype, out (N / 64, ld) f32, ld): PB_GEMM_ROWDOT, out[n / 64][m] = sum over the 64-column group of C * aux."""
     d = GemmDesc()
     esz = 2 if dtype == PB_BF16 else 4
     d.A = A.data_ptr() + a_off * esz
@@ -72,6 +73,9 @@ def gemm(A, B, C, *, M, N, K, dtype, a_kc=True, b_kc=True, lda=None, ldb=None, l
     d.slabs = slabs.data_ptr() if (splitk > 1 and slabs is not None) else None
     d.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
     d.colsum_ws = colsum_ws.data_ptr() if colsum_ws is not None else None
+    if rowdot is not None:
+        d.aux_in, d.rowdot_out, d.ld_rowdot = rowdot[0].data_ptr(), rowdot[1].data_ptr(), rowdot[2]
+        d.flags |= GEMM_ROWDOT
     d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, nb1, nb2
     d.lda = lda if lda is not None else (K if a_kc else M)
     d.ldb = ldb if ldb is not None else (K if b_kc else N)
@@ -282,7 +286,7 @@ def _flash1_ws(nbytes, device):
     return ws
 
 
-def flash_bwd1(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal, kmax=None, dbias=None, dbias_ws=None):
+def flash_bwd1(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal, kmax=None, dbias=None, dbias_ws=None, delta_rows=None):
     """pb_flash_bwd1: flash_bwd's arguments and results, one pass over the (key block, query tile) pairs (head_dim 64)."""
     (qt, qo, qs, qb), (kt, ko, ks, kb), (vt, vo, vs, vb), (ot, oo, os_, ob) = q, k, v, o
     (dqt, dqo, dqs, dqb), (dkt, dko, dks, dkb), (dvt, dvo, dvs, dvb) = dq, dk, dv
@@ -291,10 +295,10 @@ def flash_bwd1(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk,
     LIB.call('pb_flash_bwd1', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), _p(key_mask), _p(kmax), pp(dqt, dqo),
              pp(dkt, dko), pp(dvt, dvo), _p(delta), B, H, Sq, Sk, hd, qb, qs, kb, ks, vb, vs, ob, os_, dqb, dqs, dkb, dks, dvb, dvs,
              scale, int(causal), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
-             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(ws), _stream())
+             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(ws), _p(delta_rows), _stream())
 
 
-def flash_bwd1_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, scale, causal, q_rows, dbias=None, dbias_ws=None):
+def flash_bwd1_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, scale, causal, q_rows, dbias=None, dbias_ws=None, delta_rows=None):
     """pb_flash_bwd1_packed: flash_bwd_packed's arguments and results in one pass; q_rows = rows of the q-side tensors."""
     (qt, qo, qs), (kt, ko, ks), (vt, vo, vs), (ot, oo, os_) = q, k, v, o
     (dqt, dqo, dqs), (dkt, dko, dks), (dvt, dvo, dvs) = dq, dk, dv
@@ -303,7 +307,7 @@ def flash_bwd1_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, 
     LIB.call('pb_flash_bwd1_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), pp(dqt, dqo), pp(dkt, dko), pp(dvt, dvo),
              _p(delta), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off), _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd,
              qs, ks, vs, os_, dqs, dks, dvs, scale, int(causal), _p(dbias[0]) if dbias else None, _p(dbias[1]) if dbias else None,
-             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(ws), q_rows, _p(rows.order), _stream())
+             _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _p(ws), q_rows, _p(rows.order), _p(delta_rows), _stream())
 
 
 def rowmap_count(emask, dmask, loss_mask, counts):

@@ -17,13 +17,13 @@ def test_header_parses_and_library_exports_all():
     dll = ctypes.CDLL(_lib.LIB_PATH)
     for name in decls:
         assert hasattr(dll, name), 'library does not export %s' % name
-    assert _lib.LIB.query('pb_abi_version') == 6
+    assert _lib.LIB.query('pb_abi_version') == 7
     assert _lib.LIB.query('pb_ln_partials_floats', 768) == 512 * 3 * 768
 
 
 def test_gemm_desc_layout_matches_header():
-    # 6 pointers + 10 int32 + 10 int64 + 2 floats + 2 int32 + 1 pointer
-    assert ctypes.sizeof(_lib.GemmDesc) == 6 * 8 + 10 * 4 + 10 * 8 + 2 * 4 + 2 * 4 + 8 + 2 * 8
+    # 6 pointers + 10 int32 + 10 int64 + 2 floats + 2 int32 + 1 pointer + colsum out / ws + rowdot out / ld
+    assert ctypes.sizeof(_lib.GemmDesc) == 6 * 8 + 10 * 4 + 10 * 8 + 2 * 4 + 2 * 4 + 8 + 2 * 8 + 2 * 8
 
 
 def test_ops_refuse_cpu_tensors():

@@ -575,3 +575,58 @@ def test_dispatch_order_changes_no_result(ops):
     for a, b_ in zip(*res):
         assert torch.isfinite(b_).all() and torch.equal(a, b_)
 
+
+
+@pytest.mark.parametrize('M,N,K,bias', [(512, 256, 128, False), (2048, 768, 768, False), (1280, 512, 192, True)])
+def test_gemm_rowdot_epilogue(ops, M, N, K, bias):
+    """PB_GEMM_ROWDOT (round 5): C = A B^T (+ bias) as usual, and out[n / 64][m] = sum over the 64-column group of bf16(C[m][.]) * aux[m][.] --
+    the delta = rowsum(dO * O) per head of the attention backward, taken from the epilogue registers of the GEMM that makes dO. Against
+    fp64 on the ROUNDED C (what a pass over the stored tensor sees), one and several work items per workgroup; refused off the whole-tile form."""
+    from pianobart_amd._lib import PBError
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    A = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16)
+    B = torch.randn(N, K, device='cuda', generator=g).to(torch.bfloat16)
+    aux = torch.randn(M, N, device='cuda', generator=g).to(torch.bfloat16)
+    b = torch.randn(N, device='cuda', generator=g) if bias else None
+    C = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    ld = M + 64
+    out = torch.full((N // 64, ld), float('nan'), device='cuda')
+    ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, bias=b, rowdot=(aux, out, ld))
+    ref = A.double() @ B.double().t() + (b.double() if bias else 0)
+    assert float((C.double() - ref).abs().max() / ref.abs().max()) < 6e-3
+    C2 = torch.empty_like(C)
+    ops.gemm(A, B, C2, M=M, N=N, K=K, dtype=ops.PB_BF16, bias=b)
+    assert torch.equal(C, C2)                                             # the same C as without the extra output
+    want = (C.double() * aux.double()).reshape(M, N // 64, 64).sum(-1).t()
+    got = out[:, :M].double()
+    assert torch.isfinite(got).all() and torch.isnan(out[:, M:]).all()
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max()) + 1e-4
+    with pytest.raises(PBError):                                          # a ragged row count is not the whole-tile form
+        ops.gemm(A[:M - 8], B, C[:M - 8], M=M - 8, N=N, K=K, dtype=ops.PB_BF16, rowdot=(aux, out, ld))
+
+
+def test_one_pass_backward_takes_delta_rows(ops):
+    """pb_flash_bwd1 with delta_rows = [H][B * S] row sums made elsewhere (the GEMM epilogue) gives the gradients of the call that computes
+    delta itself, bit for bit when the table holds the same numbers."""
+    hd, B, H, S = 64, 2, 3, 320
+    d = H * hd
+    g = torch.Generator(device='cuda').manual_seed(5)
+    buf = (torch.randn(B, S, 3 * d, device='cuda', generator=g) * 1.2).to(torch.bfloat16)
+    ql, kl, vl = (buf, 0, 3 * d, S * 3 * d), (buf, d, 3 * d, S * 3 * d), (buf, 2 * d, 3 * d, S * 3 * d)
+    km = (torch.rand(B, S, device='cuda', generator=g) > 0.2).float()
+    kmax = torch.empty(B, dtype=torch.int32, device='cuda'); ops.key_extent(km, kmax)
+    out = torch.empty(B, S, d, device='cuda', dtype=torch.bfloat16); lse = torch.empty(B, H, S, device='cuda')
+    ops.flash_fwd(ql, kl, vl, (out, 0, d, S * d), lse, km, B, H, S, S, hd, hd ** -0.5, False, kmax=kmax)
+    dout = torch.randn(B, S, d, device='cuda', generator=g).to(torch.bfloat16)
+    res = []
+    for use_rows in (False, True):
+        delta = torch.zeros(B, H, S, device='cuda')
+        dbuf = torch.full((B, S, 3 * d), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dq, dk, dv = (dbuf, 0, 3 * d, S * 3 * d), (dbuf, d, 3 * d, S * 3 * d), (dbuf, 2 * d, 3 * d, S * 3 * d)
+        rows = None
+        if use_rows:                                                      # [H][B * S] from the first call's (B, H, S) table
+            rows = res[0][1].permute(1, 0, 2).reshape(H, B * S).contiguous()
+        ops.flash_bwd1(ql, kl, vl, (out, 0, d, S * d), dout, lse, km, dq, dk, dv, delta, B, H, S, S, hd, hd ** -0.5, False, kmax=kmax, delta_rows=rows)
+        res.append((dbuf.clone(), delta.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.isfinite(res[0][0]).all()
+    assert float(res[1][1].abs().max()) == 0.0                            # the second call did not run the delta pass
