@@ -23,6 +23,7 @@ from . import ops, rowpack
 from ._lib import LIB, PB_BF16, PB_F32, PBError
 
 _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second HIP stream, bits: 1 = weight-gradient GEMMs, 2 = cross-attention K/V projections, 4 = backward GEMMs as ordinary grids (0: everything on one stream, for A/B)
+_WG_DXD_256 = int(os.environ.get('PB_WG_DXD_256', '1'))                         # the d x d weight gradients on the 256x256 ping-pong kernel (9 tiles x split-K 21) instead of 128x128 tiles (36 x 14); same-box A/B round 5: 58.01 / 58.01 -> 57.83 / 57.62 ms (profiles/r05_dxd_wgrad_ab.txt); 0 = the round-2 choice
 _WG_TARGET = 192 if _WGRAD_STREAM & 1 else 256            # split-K work items a weight-gradient GEMM aims for (256x256 tiles)
 _NO_DEFER = False                  # settled (round 2): True reduces every bias / LayerNorm gradient right behind its producer
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
@@ -602,7 +603,7 @@ class Engine:
         """G[gname] (M,N) = dy(T,M)^T @ x(T,N)  (TN GEMM into the f32 gradient buffer)."""
         nsplit, slabs, big = 1, None, False
         if self.code == PB_BF16 and T % 64 == 0:
-            big = M >= 256 and N >= 256 and M * N > 768 * 768     # 256x256 tiles, one block per CU (768x768: 128x128 tiles measured 712 vs 636 TF)
+            big = M >= 256 and N >= 256 and (M * N > 768 * 768 or _WG_DXD_256)     # 256x256 tiles, one block per CU (768x768: 128x128 tiles measured 712 vs 636 TF)
             tl = 256 if big else 128
             tiles = ((M + tl - 1) // tl) * ((N + tl - 1) // tl)
             nsplit = max(1, min(32, T // 64, round((_WG_TARGET if big else 512) / tiles)))
@@ -1068,8 +1069,13 @@ class Engine:
         ops.ids_check(ids16, self._id_lim, self._id_flag)
 
     def check_ids(self):
-        """Synchronises. Raises IndexError if a checked batch held an id outside its embedding table."""
+        """Synchronises. Raises IndexError if a checked batch held an id outside its embedding table -- on EVERY rank of a torchrun job when any
+        rank's batch did (the flag is max-reduced first: a rank that raised alone would leave the others waiting in the next gradient exchange)."""
         self._id_verdicts = []
+        if getattr(self, '_id_flag', None) is not None and self.grad_hook is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(self._id_flag, op=dist.ReduceOp.MAX)
         if getattr(self, '_id_flag', None) is not None and int(self._id_flag.item()) != 0:
             self._id_flag.zero_()
             raise IndexError('index out of range in self: an Octuple id lies outside its embedding table (sizes %s)' % ops.SEG_SIZES)

@@ -20,8 +20,18 @@ g = torch.Generator(device=dev).manual_seed(1)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g).to(bf)
 
 
+SOAK = float(os.environ.get('SOAK', '0'))          # seconds of back-to-back launches of the same kernel before the measured ones (a cold chip boosts)
+
+
 def run(name, fn, flops, reps=5):
     fn(); torch.cuda.synchronize()
+    if SOAK > 0:
+        import time
+        t0 = time.time()
+        while time.time() - t0 < SOAK:
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
     st.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -37,11 +47,13 @@ def run(name, fn, flops, reps=5):
     per_wave_items = w[:, 6].sum() / waves
     life, life_max = w[:, 8].mean(), w[:, 8].max()
     cyc_per_us = life_max / us                                   # the longest wave spans the launch
+    real = w[:, 9]
+    mhz = (w[:, 8] / real.clip(min=1)).mean() * 100.0 if real.max() > 0 else 0.0      # s_memtime ticks per s_memrealtime tick (100 MHz): the in-kernel clock
     sec = [w[:, i].mean() for i in range(6)]                     # cycles per wave over the launch
     f = lambda c: c / cyc_per_us
     print('%-34s %7.1f us %6.0f TF | items/wg %.2f | per item: wait %5.2f  kloop %6.2f  next-issue %5.2f  epilogue %6.2f us | once: first prologue %4.1f, drain %4.1f us | '
-          'wave life %6.1f of %6.1f us (%.0f MHz)' % (name, us, flops / us / 1e6, per_wave_items, f(sec[1]) / per_wave_items, f(sec[2]) / per_wave_items,
-                                                     f(sec[3]) / per_wave_items, f(sec[4]) / per_wave_items, f(sec[0]), f(sec[5]), f(life), us, cyc_per_us))
+          'wave life %6.1f of %6.1f us (%.0f ticks/us; in-kernel clock %.0f MHz)' % (name, us, flops / us / 1e6, per_wave_items, f(sec[1]) / per_wave_items, f(sec[2]) / per_wave_items,
+                                                     f(sec[3]) / per_wave_items, f(sec[4]) / per_wave_items, f(sec[0]), f(sec[5]), f(life), us, cyc_per_us, mhz))
 
 
 d, ffn = 768, 3072

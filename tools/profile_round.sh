@@ -5,8 +5,9 @@
 #   <tag>_gemm_fc1_pmc_M<rows>.json                                     FETCH_SIZE / WRITE_SIZE passes of the dominant kernel at the step's row counts
 #   <tag>_sq_counters_attention.txt                                    SQ counters of the head_dim-64 attention kernels (4 separate --pmc passes)
 #   <tag>_decode_kernel_stats.txt                                      kernel trace of the KV-cached decode (graph replay per token)
+#   <tag>_step_byte_budget.txt                                         FETCH_SIZE x 2 + WRITE_SIZE per kernel family over one step (two --pmc passes over bench.py)
 #   <tag>_bench_default.json                                           the driver-style bench line of the same box
-TAG=${1:-r03}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; O=gpurun_out/${TAG}prof; mkdir -p $O; rm -rf $O/prof_* $O/pmc_* $O/p[1-4]
 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench_default.err; tail -c 400 $O/${TAG}_bench_default.json; echo
@@ -16,6 +17,7 @@ d=json.loads([l for l in open('$O/${TAG}_bench_default.json').read().splitlines(
 print(d['rows']['encoder_side'], d['rows']['decoder_side'])
 PY
 )
+export PB_GEMM_LDS_TAG=1          # the traced launches tell their GEMM problem through group_segment_size (tools/rocpd_stats.py splits the gemm rows by it)
 rocprofv3 --kernel-trace -d $R/$O/prof_2s -- python3 bench.py --no-cpu-baseline --no-probe --steps 4 --warmup 2 > $O/prof_2s.log 2>&1
 DB=$(ls $O/prof_2s/*/*.db | head -1)
 { echo "# rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-probe --steps 4 --warmup 2   (6 steps in the file; packed rows, shipped two-stream schedule)"; python tools/rocpd_overlap.py $DB | sed 's/^/# /'; python tools/rocpd_stats.py $DB 50; } > $O/${TAG}_bench_b32_packed_kernel_stats_two_streams.txt
@@ -23,6 +25,18 @@ PB_WGRAD_STREAM=0 rocprofv3 --kernel-trace -d $R/$O/prof_1s -- python3 bench.py 
 DB=$(ls $O/prof_1s/*/*.db | head -1)
 { echo "# PB_WGRAD_STREAM=0 rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-probe --steps 4 --warmup 2   (6 steps in the file; packed rows, one stream: undisturbed per-kernel durations)"; python tools/rocpd_overlap.py $DB | sed 's/^/# /'; python tools/rocpd_stats.py $DB 50; } > $O/${TAG}_bench_b32_packed_kernel_stats_one_stream.txt
 rm -rf $O/prof_2s $O/prof_1s
+unset PB_GEMM_LDS_TAG
+# whole-step byte budget: FETCH_SIZE and WRITE_SIZE in separate passes over the same bench command (4 steps in each trace)
+MS=$(python - <<PY
+import json
+d=json.loads([l for l in open('$O/${TAG}_bench_default.json').read().splitlines() if l.startswith('{')][-1])
+print(d['ms_per_step'])
+PY
+)
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/bud_f -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2 > $O/bud_f.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/bud_w -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2 > $O/bud_w.log 2>&1
+{ echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2; tools/pmc_step_budget.py"; python tools/pmc_step_budget.py $O/bud_f $O/bud_w 4 $MS; } > $O/${TAG}_step_byte_budget.txt 2>&1
+rm -rf $O/bud_f $O/bud_w
 for M in $ROWS; do
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_f$M -- python3 tools/pmc_gemm.py --M=$M > $O/pmc_f$M.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_w$M -- python3 tools/pmc_gemm.py --M=$M > $O/pmc_w$M.log 2>&1
