@@ -242,14 +242,26 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
         ldsND[q] = q < p.Sq ? -dsrc[q] : 0.f;
     }
     ldsVis[t] = vis_t;
+    // A masked key's score is exactly -lse (its K fragment is zero): p = exp2(-lse log2e) overflows for a row whose log-sum-exp lies below about
+    // -88, and inf x 0 in dQ^T = K^T dS^T is a NaN. Such rows are found here, once: if the sequence has one, the waves that hold a
+    // masked key run their steps through the compare path below, whose exponent is clamped at 0 (a true log-probability is <= 0).
+    bool hot = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hot |= (tl[i] != INFINITY && -tl[i] * LOG2E > 100.f);
+    for (int q = it0 * 64 + t + 4 * FT; q < p.Sq; q += FT) hot |= (-p.lse[li0 + q] * LOG2E > 100.f);
+    unsigned* ldsHot = reinterpret_cast<unsigned*>(smem + OFF_DS + 1024);   // 4 words behind ldsVis
+    const unsigned hotw = __builtin_amdgcn_ballot_w64(hot) != 0ull ? 1u : 0u;
+    if (lane == 0) ldsHot[wave] = hotw;
     PSTAMP(1);
     // this wave's 64 keys: K (prescaled: S comes out of the MFMA in log2 units) and V fragments go to AGPRs for the whole sweep. A MASKED
     // key's K fragments are zeros here and in the K^T fragments below: its scores are then -lse (p finite), its dS meets a zero K row in
     // dQ, and its own dK / dV rows are zeroed in the epilogue -- the sweep itself never looks at a key mask.
+    bool allvis = true;
     static_for<0, 4>([&](auto ktt) {
         constexpr int kt = decltype(ktt)::value;
         const int key = k0 + wave * 64 + kt * 16 + lr;
         const bool vis = key < kvis_end && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
+        allvis &= vis;
         static_for<0, 2>([&](auto kss) {
             constexpr int ks = decltype(kss)::value;
             bf16x8 kf = scale_frag(kfr[kt][ks], c);
@@ -265,6 +277,8 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     PSTAMP(3);
     __builtin_amdgcn_s_waitcnt(0xc07f);                                    // this wave's table stores
     __builtin_amdgcn_s_barrier();                                          // K images and tables are in LDS
+    const bool careful = __builtin_amdgcn_ballot_w64(!allvis) != 0ull &&
+                         __builtin_amdgcn_readfirstlane(ldsHot[0] | ldsHot[1] | ldsHot[2] | ldsHot[3]) != 0u;      // wave-uniform
     PSTAMP(4);
     // K^T fragments of this wave's share of dQ^T = K^T dS^T: query tile (wave & 1) of a 32-query step x column tiles 2 (wave >> 1), + 1
     const int qsel = wave & 1, cpair = wave >> 1;
@@ -401,8 +415,8 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
                 float pr[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pr[r] = __builtin_amdgcn_exp2f(sv[r]);
-                    pr[r] = (mykey0 + kt * 16 <= q0 + (HALF * 2 + qq) * 16 + g * 4 + r) ? pr[r] : 0.f;
+                    pr[r] = __builtin_amdgcn_exp2f(fminf(sv[r], 0.f));                    // clamped: a masked key's -lse cannot overflow (see `careful`)
+                    pr[r] = (!p.causal || mykey0 + kt * 16 <= q0 + (HALF * 2 + qq) * 16 + g * 4 + r) ? pr[r] : 0.f;
                 }
                 asm volatile("s_nop 0" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]));
 #pragma unroll
@@ -492,7 +506,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     };
     auto run = [&](int T, int slot, int pslot, int stage_tile, auto halftag, auto firsttag) {
         constexpr int HALF = decltype(halftag)::value;
-        const bool diag = p.causal && (k0 + wave * 64 + 63 > T * 64 + HALF * 32);     // wave-uniform: some key of this wave lies behind some query of the step
+        const bool diag = careful || (p.causal && (k0 + wave * 64 + 63 > T * 64 + HALF * 32));     // wave-uniform: some key of this wave lies behind some query of the step (or: clamp)
         if (diag) step(T, slot, pslot, stage_tile, halftag, firsttag, IntTag<1>{}); else step(T, slot, pslot, stage_tile, halftag, firsttag, IntTag<0>{});
     };
 

@@ -341,3 +341,21 @@ def test_g10_cfg2_shape_spot_check_bf16():
           % (rel, agree, float((arg[clear] == ref[clear]).mean()), 100 * clear.mean()))
     assert rel < 2.5e-2                                  # measured 1.4e-2 - 1.5e-2
     assert agree > 0.995 and np.array_equal(arg[clear], ref[clear])
+
+
+def test_bf16_loss_curve_follows_the_exact_f32_curve():
+    """SURVEY 7 hard part 1 / VERDICT r4 item 6: the bf16 throughput instantiation against the exact-f32 parity instantiation as TRAINING runs --
+    cfg-2 model (12L / 768d / S = 1024), same initial weights, same batches in the same order, same Philox dropout seeds, fused step + HF-AdamW
+    at lr 1e-4 (tools/loss_overlay.py; 200 steps at B = 8 are committed as profiles/r05_loss_overlay.txt: gap <= 6e-4 for the first 50 steps,
+    then the two trajectories decorrelate to 1 - 3.5 %, final losses 1.815 / 1.791). Here, reduced: B = 2, 24 steps."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import types
+    from tools import loss_overlay as LO
+    args = types.SimpleNamespace(steps=24, batch=2, nbatch=4, seq=1024, layers=12, hs=768, ffn=3072, heads=12, dropout=0.1, lr=1e-4)
+    lb, lf = LO.overlay(args)
+    gap = [abs(a - b) / b for a, b in zip(lb, lf)]
+    print('bf16 vs f32 loss, 24 steps: first %.5f / %.5f, last %.5f / %.5f, max gap %.2e' % (lb[0], lf[0], lb[-1], lf[-1], max(gap)))
+    assert gap[0] < 1e-4                                                  # the same forward at step 0 (measured 2e-6 at B = 8)
+    assert max(gap) < 3e-2 and sum(gap[-4:]) / 4 < 2e-2                   # measured at B = 2: max 1.07e-2 (the B = 8 / 200-step run peaks at 3.5e-2)
+    assert lf[-1] < 0.8 * lf[0] and lb[-1] < 0.8 * lb[0]                  # both learn

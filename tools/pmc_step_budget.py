@@ -2,7 +2,7 @@
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <fdir> -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d <wdir> -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2
-  python tools/pmc_step_budget.py <fdir> <wdir> <steps in the trace> [step_ms]
+  python tools/pmc_step_budget.py <fdir> <wdir> [step_ms]
 
 Per kernel family (GEMM / attention / row kernels / optimizer / other): bytes fetched from beyond L2 (FETCH_SIZE x 2: gfx950 tallies its
 128-byte requests at 64 bytes, MI355X_MICROARCH.md HBM) + bytes written (WRITE_SIZE), per STEP, and the rate they make at the step time
@@ -29,31 +29,36 @@ def family(name):
 
 
 def collect(d, counter):
-    """-> {family: KB}, {kernel name: KB}, number of dispatches"""
-    fam, ker, seen = {}, {}, set()
+    """-> {family: KB}, {kernel name: KB}, steps. Only the dispatches BETWEEN the first and the last gradient-norm kernel count (one per step:
+    whole steps, none of the model set-up, stream probe or read-back around them); steps = gradient-norm kernels - 1."""
+    rows = []
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get('Counter_Name') != counter:
-                continue
-            v = float(r['Counter_Value'])
-            n = r.get('Kernel_Name', '')
+            if r.get('Counter_Name') == counter:
+                rows.append((int(r['Dispatch_Id']), r.get('Kernel_Name', ''), float(r['Counter_Value'])))
+    rows.sort()
+    marks = sorted({i for i, n, _ in rows if 'sqnorm_kernel' in n})
+    if len(marks) < 2:
+        raise SystemExit('fewer than two gradient-norm kernels in %s: no whole step to count' % d)
+    fam, ker = {}, {}
+    for i, n, v in rows:
+        if marks[0] < i <= marks[-1]:
             fam[family(n)] = fam.get(family(n), 0.0) + v
             ker[n] = ker.get(n, 0.0) + v
-            seen.add(r['Dispatch_Id'])
-    return fam, ker, len(seen)
+    return fam, ker, len(marks) - 1
 
 
 def main():
-    fdir, wdir, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
-    step_ms = float(sys.argv[4]) if len(sys.argv) > 4 else None
+    fdir, wdir = sys.argv[1], sys.argv[2]
+    step_ms = float(sys.argv[3]) if len(sys.argv) > 3 else None
     ff, fk, nf = collect(fdir, 'FETCH_SIZE')
     wf, wk, nw = collect(wdir, 'WRITE_SIZE')
-    print('# dispatches with a counter record: %d (FETCH_SIZE pass), %d (WRITE_SIZE pass); %g steps in each trace (warm-up included: every step does the same work)' % (nf, nw, steps))
-    print('%-40s %12s %12s %12s' % ('family', 'fetched MB', 'written MB', 'total MB') + ('   TB/s at %.1f ms/step' % step_ms if step_ms else ''))
+    print('# whole steps counted (between the first and the last gradient-norm kernel): %d (FETCH_SIZE pass), %d (WRITE_SIZE pass)' % (nf, nw))
+    print('%-40s %12s %12s %12s' % ('family', 'fetched MB', 'written MB', 'total MB') + ('   at %.1f ms/step' % step_ms if step_ms else ''))
     tot_f = tot_w = 0.0
     for fam in [f for f, _ in FAMILY] + ['other (torch fills / copies)']:
-        fb = ff.get(fam, 0.0) * 1024 * 2 / steps / 1e6
-        wb = wf.get(fam, 0.0) * 1024 / steps / 1e6
+        fb = ff.get(fam, 0.0) * 1024 * 2 / nf / 1e6
+        wb = wf.get(fam, 0.0) * 1024 / nw / 1e6
         tot_f += fb; tot_w += wb
         print('%-40s %12.0f %12.0f %12.0f' % (fam, fb, wb, fb + wb))
     line = '%-40s %12.0f %12.0f %12.0f' % ('step', tot_f, tot_w, tot_f + tot_w)
@@ -61,9 +66,9 @@ def main():
         line += '   %.2f TB/s' % ((tot_f + tot_w) * 1e6 / (step_ms * 1e-3) / 1e12)
     print(line)
     print('# largest kernels (MB per step: fetched x2 + written)')
-    names = sorted(set(fk) | set(wk), key=lambda n: -(fk.get(n, 0.0) * 2 + wk.get(n, 0.0)))[:10]
+    names = sorted(set(fk) | set(wk), key=lambda n: -(fk.get(n, 0.0) * 2 / nf + wk.get(n, 0.0) / nw))[:10]
     for n in names:
-        print('%10.0f  %s' % ((fk.get(n, 0.0) * 2 + wk.get(n, 0.0)) * 1024 / steps / 1e6, n[:110]))
+        print('%10.0f  %s' % ((fk.get(n, 0.0) * 2 / nf + wk.get(n, 0.0) / nw) * 1024 / 1e6, n[:110]))
 
 
 if __name__ == '__main__':

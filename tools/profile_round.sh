@@ -35,7 +35,7 @@ PY
 )
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/bud_f -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2 > $O/bud_f.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/bud_w -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2 > $O/bud_w.log 2>&1
-{ echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2; tools/pmc_step_budget.py"; python tools/pmc_step_budget.py $O/bud_f $O/bud_w 4 $MS; } > $O/${TAG}_step_byte_budget.txt 2>&1
+{ echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-probe --steps 2 --warmup 2; tools/pmc_step_budget.py"; python tools/pmc_step_budget.py $O/bud_f $O/bud_w $MS; } > $O/${TAG}_step_byte_budget.txt 2>&1
 rm -rf $O/bud_f $O/bud_w
 for M in $ROWS; do
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_f$M -- python3 tools/pmc_gemm.py --M=$M > $O/pmc_f$M.log 2>&1
