@@ -356,49 +356,36 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
                                 "note": "reference corruption mix (pb_corrupt, choices 1..5 per sample, seed 1234) of the same clean sequences; 10 steps"}
     except Exception as ex:                                            # noqa: BLE001
         out["real_mix_step"] = {"error": repr(ex)[:200]}
-    # RCCL prints its version banner on file descriptor 1 when the first communicator comes up: stdout carries the ONE JSON line and nothing
-    # else, so descriptor 1 points at stderr while this leg runs
-    sys.stdout.flush()
-    fd_out = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        from pianobart_amd.parallel import GradReducer
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
-        own_pg = not dist.is_initialized()
-        if own_pg:
-            dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
-        red = GradReducer(eng, 1)
+    with stdout_to_stderr():                                         # the first communicator's banner goes to stderr
         try:
-            def dp_step():
-                eng.loss_and_grads(*step.batch, train=True, count_hook=red.reduce_counts, ids_checked=True)
-                red.all_reduce_grads()
-                eng.optimizer_step(lr=2e-5, gscale=1.0)
-            dp_step(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                dp_step()
-            torch.cuda.synchronize()
-            out["dp_mode_step"] = {"ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "world": 1, "exchange": red.mode,
-                                   "note": "GradReducer installed at world size 1: per-layer bucket exchange through RCCL on the communication "
-                                           "stream, backward GEMMs as ordinary grids; 10 steps"}
-        finally:
-            red.close() if hasattr(red, 'close') else None
-            eng.grad_hook = None
+            from pianobart_amd.parallel import GradReducer
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+            own_pg = not dist.is_initialized()
             if own_pg:
-                dist.destroy_process_group()
-    except Exception as ex:                                            # noqa: BLE001
-        eng.grad_hook = None
-        out["dp_mode_step"] = {"error": repr(ex)[:200]}
-    finally:
-        sys.stdout.flush()
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)                             # the banner sits in libc's stdout buffer (a pipe / file is fully buffered)
-        except Exception:                                              # noqa: BLE001
-            pass
-        os.dup2(fd_out, 1)
-        os.close(fd_out)
+                dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
+            red = GradReducer(eng, 1)
+            try:
+                def dp_step():
+                    eng.loss_and_grads(*step.batch, train=True, count_hook=red.reduce_counts, ids_checked=True)
+                    red.all_reduce_grads()
+                    eng.optimizer_step(lr=2e-5, gscale=1.0)
+                dp_step(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    dp_step()
+                torch.cuda.synchronize()
+                out["dp_mode_step"] = {"ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "world": 1, "exchange": red.mode,
+                                       "note": "GradReducer installed at world size 1: per-layer bucket exchange through RCCL on the communication "
+                                               "stream, backward GEMMs as ordinary grids; 10 steps"}
+            finally:
+                red.close() if hasattr(red, 'close') else None
+                eng.grad_hook = None
+                if own_pg:
+                    dist.destroy_process_group()
+        except Exception as ex:                                            # noqa: BLE001
+            eng.grad_hook = None
+            out["dp_mode_step"] = {"error": repr(ex)[:200]}
     try:
         biases = [p.detach().clone() for p in model.mask_lm.proj.parameters()]
         model.eval()
@@ -441,6 +428,29 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
     except Exception as ex:                                            # noqa: BLE001
         out["decode"] = {"error": repr(ex)[:200]}
     return out
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints its version banner on file descriptor 1 when the first communicator comes up; stdout carries the ONE JSON line and nothing
+    else, so descriptor 1 points at stderr while a communicator is being created."""
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)                             # the banner sits in libc's stdout buffer (a pipe / file is fully buffered)
+        except Exception:                                              # noqa: BLE001
+            pass
+        os.dup2(fd_out, 1)
+        os.close(fd_out)
 
 
 def _free_port():
@@ -516,7 +526,11 @@ def main():
     if world > 1 or args.force_reducer:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+            warm = torch.ones(1, device=dev)
+            dist.all_reduce(warm)                                    # the communicator (and its banner) comes up here at the latest
+            torch.cuda.synchronize()
 
     from pianobart_amd import ops
     from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
