@@ -170,7 +170,6 @@ template <int TM, int TNW = 4>
 __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[TM][TNW], int mw /*wave's first row*/, int nw /*first column*/, long coff, int lane,
                                               const float* lds_bias = nullptr /*bias[nw ..] staged in LDS by the caller*/,
                                               float* cs_row = nullptr /*this wave row's column-sum partials: N floats*/) {
-    asm volatile("" : "+v"(lane));        // opaque (see epilogue_pf): the K loop needs every register
     const int lr = lane & 15, lg = lane >> 4;
     const bool accum = p.flags & PB_GEMM_ACCUM, c32 = p.flags & PB_GEMM_C_F32;
     const bool do_gelu = p.flags & PB_GEMM_GELU, mul_gg = p.flags & PB_GEMM_MUL_GELU_GRAD;
@@ -308,7 +307,6 @@ constexpr int pf_younger(int c, int mode) {
 template <int N> __device__ __forceinline__ void pf_wait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N) : "memory"); }
 template <int MODE, bool CS>
 __device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias, float* cs_row) {
-    asm volatile("" : "+v"(lane));        // opaque: what the epilogue derives from the lane number is computed HERE, not hoisted in front of the K loop and kept in registers across it
     const int lr = lane & 15, lg = lane >> 4;
     const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
     // chunk (i, jp) of the wave's 128 x 64 tile: rows i * 16 + lr, columns jp * 32 + cb .. + 7
@@ -564,7 +562,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 a[4][2], b[2][2], bk0[2];                                  // bk0: B0's k-step-0 fragments stay in registers from phase 0 to phase 3 (half of its second read is gone; all of it would spill)
+    bf16x8 a[4][2], b[2][2];
     s16x4 ta[4][2][2], tb[2][2][2];                                   // asm destinations of the transposed reads
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     unsigned aoff[4], boff[2];
@@ -632,7 +630,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #define G3_PROLOGUE()                                                                                             \
     do {                                                                                                          \
         bslot ^= 1;                                                                                               \
-        if (p.bias && wave == 0) { int lq = lane; asm volatile("" : "+v"(lq)); glds16(reinterpret_cast<const bf16_t*>(p.bias + min(n0 + lq * 4, p.N - 4)), smem + 2 * SLOT + bslot * 1024); } \
+        if (p.bias && wave == 0) glds16(reinterpret_cast<const bf16_t*>(p.bias + min(n0 + lane * 4, p.N - 4)), smem + 2 * SLOT + bslot * 1024); \
         if (nk > 0) { G3_ISSUE_A(0, 0); G3_ISSUE_B(0, 0); G3_ISSUE_B(0, 1); G3_ISSUE_A(0, 1); }                   \
         if (nk > 1) { G3_ISSUE_A(1, 0); G3_ISSUE_B(1, 1); }                                                       \
     } while (0)
@@ -669,7 +667,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             const int sl = kt & 1;
             // phase 0: quadrant (0,0)
             G3_READ_B(sl, 0);
-            if constexpr (B_KC) { bk0[0] = b[0][0]; bk0[1] = b[1][0]; }
             __builtin_amdgcn_sched_barrier(0);
             G3_READ_A(sl, 0);
             // Where an operand needs transposed fragments (NN, TN) each phase's two DMA pieces are SPLIT: one in the load half, one
@@ -689,11 +686,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             G3_READ_A(sl, 1);
             if (kt + 2 < nk) G3_ISSUE2(G3_ISSUE_A, kt + 2, 0);
             G3_MMA(1, 1, true, false, G3_MID(G3_ISSUE_A, kt + 2 < nk, kt + 2, 0));
-            // phase 3: quadrant (1,0): B0 again. K-contiguous B: its k-step-0 fragments were kept in bk0 since phase 0, only k-step 1 is read again
-            if constexpr (!B_KC) G3_READ_B(sl, 0);
-            else {
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) { b[j][0] = bk0[j]; b[j][1] = frag<true, 128>(smem + sl * SLOT + 2 * HALF, wc * 32 + j * 16, 1, lane); }
-            }
+            // phase 3: quadrant (1,0)
+            G3_READ_B(sl, 0);
             if (kt + 2 < nk) {
                 G3_ISSUE2(G3_ISSUE_B, kt + 2, 1);
                 // in flight behind the wait: A0(t+2) (2 pieces) + B1(t+2) (both pieces, or the first one when split)
@@ -723,8 +717,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         bool epf = false, epf3 = false;                              // the item took a prefetching epilogue: 16 loads + 16 stores (+ 4 column-sum stores, or + 8 row-sum stores) per wave
         if (etail) {
             // a tail item dumps its accumulators in register order (1 KiB per wave instruction); tail_finish_kernel knows the layout
-            int lq = lane; asm volatile("" : "+v"(lq));                     // (not hoisted across the K loop: see epilogue_pf)
-            float* dst = p.tail_slabs + (long)(eL - p.n_full) * (256 * BNT) + wave * (8 * TNW * 256) + lq * 4;
+            float* dst = p.tail_slabs + (long)(eL - p.n_full) * (256 * BNT) + wave * (8 * TNW * 256) + lane * 4;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
