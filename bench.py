@@ -641,8 +641,9 @@ def main():
             E._WGRAD_STREAM = saved
     # the same kernel alone, back to back on random operands with its real epilogue, AT THE ROW COUNT THE STEP LAUNCHES IT WITH (the encoder
     # side's Te; until round 4 this probe ran the padded T = B S rows, which is most of the "0.244 alone vs 0.169 in the step" of that round's
-    # record: 32768 / 26624 rows). What is left is the isolated loop's own cost: every launch writes 2 x Te x ffn x 2 B with no neighbour
-    # kernel to absorb the store bursts.
+    # record: 32768 / 26624 rows). At equal rows the loop still runs ~20 % slower per launch than the step's launches (round 5: 0.203 against
+    # 0.168 ms on one box, host enqueue 0.009 ms per launch, so not the host): 20 launches in a row each write 2 x Te x ffn x 2 B with no lighter
+    # neighbour kernel in between.
     code = ops.dtype_code(eng.xdt)
     iso_ms, iso_host_ms, Tiso = None, None, (Te if fc1_ms else T)
     if not args.no_probe:
