@@ -170,6 +170,7 @@ template <int TM, int TNW = 4>
 __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[TM][TNW], int mw /*wave's first row*/, int nw /*first column*/, long coff, int lane,
                                               const float* lds_bias = nullptr /*bias[nw ..] staged in LDS by the caller*/,
                                               float* cs_row = nullptr /*this wave row's column-sum partials: N floats*/) {
+    asm volatile("" : "+v"(lane));        // opaque (see epilogue_pf): the K loop needs every register
     const int lr = lane & 15, lg = lane >> 4;
     const bool accum = p.flags & PB_GEMM_ACCUM, c32 = p.flags & PB_GEMM_C_F32;
     const bool do_gelu = p.flags & PB_GEMM_GELU, mul_gg = p.flags & PB_GEMM_MUL_GELU_GRAD;
@@ -307,6 +308,7 @@ constexpr int pf_younger(int c, int mode) {
 template <int N> __device__ __forceinline__ void pf_wait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N) : "memory"); }
 template <int MODE, bool CS>
 __device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias, float* cs_row) {
+    asm volatile("" : "+v"(lane));        // opaque: what the epilogue derives from the lane number is computed HERE, not hoisted in front of the K loop and kept in registers across it
     const int lr = lane & 15, lg = lane >> 4;
     const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
     // chunk (i, jp) of the wave's 128 x 64 tile: rows i * 16 + lr, columns jp * 32 + cb .. + 7
@@ -557,11 +559,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     const bf16_t* A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
 
+    // K-contiguous operands (NT): the K-tile is consumed BY K-STEP instead of by quadrant (round 5) -- see the loop
+    constexpr bool KSPLIT = A_KC && B_KC && TNW == 4;
     f32x4 acc[8][TNW];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TNW; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (KSPLIT) asm volatile("" : "+v"(acc[i][j])); }   // opaque: no peeled first K-tile with C = 0
     bf16x8 a[4][2], b[2][2];
     s16x4 ta[4][2][2], tb[2][2][2];                                   // asm destinations of the transposed reads
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -630,9 +634,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #define G3_PROLOGUE()                                                                                             \
     do {                                                                                                          \
         bslot ^= 1;                                                                                               \
-        if (p.bias && wave == 0) glds16(reinterpret_cast<const bf16_t*>(p.bias + min(n0 + lane * 4, p.N - 4)), smem + 2 * SLOT + bslot * 1024); \
+        if (p.bias && wave == 0) { int lq = lane; asm volatile("" : "+v"(lq)); glds16(reinterpret_cast<const bf16_t*>(p.bias + min(n0 + lq * 4, p.N - 4)), smem + 2 * SLOT + bslot * 1024); } \
         if (nk > 0) { G3_ISSUE_A(0, 0); G3_ISSUE_B(0, 0); G3_ISSUE_B(0, 1); G3_ISSUE_A(0, 1); }                   \
-        if (nk > 1) { G3_ISSUE_A(1, 0); G3_ISSUE_B(1, 1); }                                                       \
+        if (nk > 1) { G3_ISSUE_A(1, 0); if constexpr (!KSPLIT) G3_ISSUE_B(1, 1); }                                \
     } while (0)
     int bslot = 0;
 #ifdef PB_G3_STAMPS
@@ -647,7 +651,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         // K-tile 0 of this item must have landed. vmcnt counts loads, stores and DMA pieces in ONE in-order queue, and behind
         // K-tile 0's pieces sit the 4 pieces of K-tile 1 and the `pend` stores of the previous item's epilogue (exactly 16 / 32
         // per wave when that tile was interior and store-only; 0 = "unknown", which waits for the stores too): leave them flying.
-        if (nk > 1) {
+        if (nk > 1 && KSPLIT) {                                     // behind K-tile 0: A0 of K-tile 1 (2 pieces) and the stores
+            if (pend == 40) { asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); }
+            else if (pend == 36) { asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); }
+            else if (pend == 32) { asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); }
+            else if (pend == 16) { asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); }
+            else { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        } else if (nk > 1) {
             if (pend == 40) { asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); }
             else if (pend == 36) { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
             else if (pend == 32) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
@@ -663,6 +673,66 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
         G3_STAMP(1);                                                 // [1] wait for K-tile 0 (+ the stagger barrier)
+        if constexpr (KSPLIT) {
+            // Round 5, both operands K-contiguous. Consumed by quadrant, the four load halves of a K-tile read 12 / 4 / 8 / 4 fragments per wave, and the
+            // 12 of phase 0 -- 48 KiB through the LDS pipe for the four waves of a group -- outlast the other group's 16 MFMAs (knock-out builds,
+            // profiles/r05_gemm_kloop_knockouts.txt: without the fragment reads the K loop runs at the MFMA floor, 13.1 against 17.6 us per
+            // 12 K-tiles). Consumed by k-step the phases are (rows half 0, k-step 0) (half 0, k-step 1) (half 1, k-step 0) (half 1, k-step 1): each
+            // multiplies 4 row tiles by ALL 4 column tiles on one k-step, so a phase reads 4 A fragments, the 8 B fragments of the two k-steps are
+            // read once (phases 0 and 1) and stay in registers: 8 / 8 / 4 / 4 reads, 24 instead of 28, none above 8, same 48 fragment registers.
+            // Last reads of K-tile t: A0 and both B halves in phase 1, A1 in phase 3; a half-tile is re-staged >= 2 phases later:
+            //     phase 4t+0: B0(t+1)   4t+1: B1(t+1), vmcnt(6) -> A1(t) landed   4t+2: A1(t+1)   4t+3: A0(t+2), vmcnt(4) -> A0, B0, B1 of t+1 landed
+            // (each wait one phase ahead of the first read of what it retires, as before).
+            bf16x8 a1[4], bk[2][4];
+#define G3K_READ_A(SL, H, KS) do { _Pragma("unroll") for (int i = 0; i < 4; ++i) a1[i] = frag<true, 128>(smem + (SL) * SLOT + (H) * HALF, wr * 64 + i * 16, KS, lane); } while (0)
+#define G3K_READ_B(SL, KS) do { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) bk[KS][jj] = frag<true, 128>(smem + (SL) * SLOT + (2 + (jj >> 1)) * HALF, wc * 32 + (jj & 1) * 16, KS, lane); } while (0)
+#define G3K_MMA(MH, KS)                                                                                          \
+    do {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                       \
+                acc[(MH) * 4 + i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[KS][jj], a1[i], acc[(MH) * 4 + i][jj], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+            for (int kt = 0; kt < nk; ++kt) {
+                const int sl = kt & 1;
+                G3K_READ_B(sl, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                G3K_READ_A(sl, 0, 0);
+                if (kt + 1 < nk) G3_ISSUE_B(kt + 1, 0);
+                G3K_MMA(0, 0);
+                G3K_READ_B(sl, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                G3K_READ_A(sl, 0, 1);
+                if (kt + 1 < nk) {
+                    G3_ISSUE_B(kt + 1, 1);
+                    // A1 of THIS K-tile (issued in phase 2 of the previous one; K-tile 0's came with the prologue and was waited for above) is older
+                    // than A0(t+1), B0(t+1), B1(t+1): 6 pieces
+                    if (kt > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                } else if (kt > 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                G3K_MMA(0, 1);
+                G3K_READ_A(sl, 1, 0);
+                if (kt + 1 < nk) G3_ISSUE_A(kt + 1, 1);
+                G3K_MMA(1, 0);
+                G3K_READ_A(sl, 1, 1);
+                if (kt + 2 < nk) { G3_ISSUE_A(kt + 2, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }      // in flight: A1(t+1), A0(t+2)
+                else if (kt + 1 < nk) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }                        // in flight: A1(t+1)
+                else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                G3K_MMA(1, 1);
+            }
+#undef G3K_READ_A
+#undef G3K_READ_B
+#undef G3K_MMA
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             const int sl = kt & 1;
             // phase 0: quadrant (0,0)
@@ -717,7 +787,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         bool epf = false, epf3 = false;                              // the item took a prefetching epilogue: 16 loads + 16 stores (+ 4 column-sum stores, or + 8 row-sum stores) per wave
         if (etail) {
             // a tail item dumps its accumulators in register order (1 KiB per wave instruction); tail_finish_kernel knows the layout
-            float* dst = p.tail_slabs + (long)(eL - p.n_full) * (256 * BNT) + wave * (8 * TNW * 256) + lane * 4;
+            int lq = lane; asm volatile("" : "+v"(lq));                     // (not hoisted across the K loop: see epilogue_pf)
+            float* dst = p.tail_slabs + (long)(eL - p.n_full) * (256 * BNT) + wave * (8 * TNW * 256) + lq * 4;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -754,7 +825,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TNW; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (KSPLIT) asm volatile("" : "+v"(acc[i][j])); }   // opaque: no peeled first K-tile with C = 0
     }
 #ifdef PB_G3_STAMPS
     if (p.stamps) {
