@@ -57,6 +57,16 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same DMA with the address split into a wave-uniform 64-bit base in SGPRs and one 32-bit lane offset (global_load_lds_dwordx4 voff, s[base]): the
+// builtin above takes a 64-bit pointer per lane, which in a K loop that advances eight pieces per K-tile keeps two or three 64-bit lane terms per piece
+// in registers (the ping-pong kernel's K-contiguous loop held 72 VGPRs besides accumulators and fragments, most of them these). M0 = the LDS address of
+// the piece; it is compiler-reserved, so it is saved and restored around the instruction (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16_s(unsigned voff, const char* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // K-contiguous operand tile: rows r0..r0+RT-1 (clamped to R-1), k0..k0+63. Image [RT][128 B], chunk-swizzled.
 // RT*128 bytes = RT/8 DMA pieces of 1 KiB, dealt round-robin to the NW waves.
 template <int RT, int NW>
@@ -531,6 +541,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     constexpr int BNT = 64 * TNW, GSB = 16 * TNW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALF = 16384, SLOT = 4 * HALF;
+    // LDS map of the stage ring: [A0 slot 0 | A0 slot 1 | A1 slot 0 | A1 slot 1 | B0 s0 | B0 s1 | B1 s0 | B1 s1], 16 KiB each. The (half, slot) of an operand is
+    // then one of four offsets below 64 KiB, i.e. an IMMEDIATE of the ds_read: a fragment address needs one register per (row tile, k-step), not one more
+    // per slot (with the slots 64 KiB apart the second slot lay beyond the 16-bit offset field).
+#define G3_OFF_A(SL, H) ((H) * 2 * HALF + (SL) * HALF)
+#define G3_OFF_B(SL, H) (SLOT + (H) * 2 * HALF + (SL) * HALF)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -574,27 +589,65 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     for (int i = 0; i < 4; ++i) aoff[i] = lds0 + tr_lane_off(wr * 64 + i * 16, lane);
 #pragma unroll
     for (int j = 0; j < 2; ++j) boff[j] = lds0 + tr_lane_off(wc * 32 + j * 16, lane);
+    // K-contiguous fragment addresses of the k-step loop (frag<true, 128>'s formula). Recomputed from the (opaque) lane number in front of every item's K loop:
+    // 12 registers the epilogue in between does not have to keep
+    unsigned fa[4][2], fb[2][2];
+    auto frag_setup = [&]() {
+        if constexpr (A_KC && B_KC) {
+            int lq = lane; asm volatile("" : "+v"(lq));
+            const int lr_ = lq & 15, g_ = lq >> 4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int row = wr * 64 + i * 16 + lr_; fa[i][ks] = lds0 + (unsigned)(row * 128 + (((ks * 4 + g_) ^ kswz(row)) << 4)); asm volatile("" : "+v"(fa[i][ks])); }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { const int row = wc * 32 + j * 16 + lr_; fb[j][ks] = lds0 + (unsigned)(SLOT + row * 128 + (((ks * 4 + g_) ^ kswz(row)) << 4)); asm volatile("" : "+v"(fb[j][ks])); }
+            }
+        }
+    };
 
-#define G3_ISSUE_A(T, H) stage_half<A_KC, 64>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
-#define G3_ISSUE_B(T, H) stage_half<B_KC, 32, GSB>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
-#define G3_ISSUE_A1(T, H, PC) stage_half<A_KC, 64, 128, PC, PC + 1>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + ((T) & 1) * SLOT + (H) * HALF, H, wave, lane)
-#define G3_ISSUE_B1(T, H, PC) stage_half<B_KC, 32, GSB, PC, PC + 1>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + ((T) & 1) * SLOT + (2 + (H)) * HALF, H, wave, lane)
+#define G3_ISSUE_A(T, H) stage_half<A_KC, 64>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + G3_OFF_A((T) & 1, H), H, wave, lane)
+#define G3_ISSUE_B(T, H) stage_half<B_KC, 32, GSB>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + G3_OFF_B((T) & 1, H), H, wave, lane)
+#define G3_ISSUE_A1(T, H, PC) stage_half<A_KC, 64, 128, PC, PC + 1>(A, p.lda, m0, kbeg + (T) * BK, p.M, smem + G3_OFF_A((T) & 1, H), H, wave, lane)
+#define G3_ISSUE_B1(T, H, PC) stage_half<B_KC, 32, GSB, PC, PC + 1>(B, p.ldb, n0, kbeg + (T) * BK, p.N, smem + G3_OFF_B((T) & 1, H), H, wave, lane)
+    // K-split (NT) path: LDS-DMA addressing = SGPR base of the item's operand panel at its first k + one 32-bit lane offset per piece (row clamped once per item)
+    unsigned voA[2][2] = {{0u, 0u}, {0u, 0u}}, voB[2][2] = {{0u, 0u}, {0u, 0u}};
+    const char *sA = nullptr, *sB = nullptr;
+    auto dma_setup = [&]() {
+        if constexpr (KSPLIT) {
+            int lq = lane; asm volatile("" : "+v"(lq));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int hr = (wave * 2 + n) * 8 + (lq >> 3), chunk = (lq & 7) ^ kswz(hr);
+                    const int ra = min(m0 + (hr / 64) * 128 + h * 64 + (hr % 64), p.M - 1) - m0;
+                    const int rb = min(n0 + (hr / 32) * GSB + h * 32 + (hr % 32), p.N - 1) - n0;
+                    voA[h][n] = (unsigned)((ra * (int)p.lda + chunk * 8) * 2);
+                    voB[h][n] = (unsigned)((rb * (int)p.ldb + chunk * 8) * 2);
+                }
+            sA = sgpr_ptr(A + (long)m0 * p.lda + kbeg);
+            sB = sgpr_ptr(B + (long)n0 * p.ldb + kbeg);
+        }
+    };
+#define G3S_ISSUE_A(T, H) do { _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) glds16_s(voA[H][n_], sA + (long)(T) * (BK * 2), lds0 + (unsigned)(G3_OFF_A((T) & 1, H) + (wave * 2 + n_) * 1024)); } while (0)
+#define G3S_ISSUE_B(T, H) do { _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) glds16_s(voB[H][n_], sB + (long)(T) * (BK * 2), lds0 + (unsigned)(G3_OFF_B((T) & 1, H) + (wave * 2 + n_) * 1024)); } while (0)
 #define G3_READ_A(SL, H)                                                                                          \
     do {                                                                                                          \
         if constexpr (A_KC) {                                                                                     \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)         \
-                a[i][ks] = frag<true, 128>(smem + (SL) * SLOT + (H) * HALF, wr * 64 + i * 16, ks, lane);            \
+                a[i][ks] = frag<true, 128>(smem + G3_OFF_A(SL, H), wr * 64 + i * 16, ks, lane);            \
         } else {                                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) ds_tr_frags(ta[i], aoff[i] + (unsigned)((SL) * SLOT + (H) * HALF)); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) ds_tr_frags(ta[i], aoff[i] + (unsigned)G3_OFF_A(SL, H)); \
         }                                                                                                         \
     } while (0)
 #define G3_READ_B(SL, H)                                                                                          \
     do {                                                                                                          \
         if constexpr (B_KC) {                                                                                     \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)         \
-                b[j][ks] = frag<true, 128>(smem + (SL) * SLOT + (2 + (H)) * HALF, wc * 32 + j * 16, ks, lane);      \
+                b[j][ks] = frag<true, 128>(smem + G3_OFF_B(SL, H), wc * 32 + j * 16, ks, lane);      \
         } else {                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) ds_tr_frags(tb[j], boff[j] + (unsigned)((SL) * SLOT + (2 + (H)) * HALF)); \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) ds_tr_frags(tb[j], boff[j] + (unsigned)G3_OFF_B(SL, H)); \
         }                                                                                                         \
     } while (0)
     // RA / RB: this phase read A / B fragments (the asm destinations among them are named in the wait)
@@ -635,8 +688,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     do {                                                                                                          \
         bslot ^= 1;                                                                                               \
         if (p.bias && wave == 0) { int lq = lane; asm volatile("" : "+v"(lq)); glds16(reinterpret_cast<const bf16_t*>(p.bias + min(n0 + lq * 4, p.N - 4)), smem + 2 * SLOT + bslot * 1024); } \
-        if (nk > 0) { G3_ISSUE_A(0, 0); G3_ISSUE_B(0, 0); G3_ISSUE_B(0, 1); G3_ISSUE_A(0, 1); }                   \
-        if (nk > 1) { G3_ISSUE_A(1, 0); if constexpr (!KSPLIT) G3_ISSUE_B(1, 1); }                                \
+        if constexpr (KSPLIT) {                                                                                   \
+            dma_setup();                                                                                          \
+            if (nk > 0) { G3S_ISSUE_A(0, 0); G3S_ISSUE_B(0, 0); G3S_ISSUE_B(0, 1); G3S_ISSUE_A(0, 1); }           \
+            if (nk > 1) { G3S_ISSUE_A(1, 0); G3S_ISSUE_B(1, 0); }                                                 \
+        } else {                                                                                                  \
+            if (nk > 0) { G3_ISSUE_A(0, 0); G3_ISSUE_B(0, 0); G3_ISSUE_B(0, 1); G3_ISSUE_A(0, 1); }               \
+            if (nk > 1) { G3_ISSUE_A(1, 0); G3_ISSUE_B(1, 1); }                                                   \
+        }                                                                                                         \
     } while (0)
     int bslot = 0;
 #ifdef PB_G3_STAMPS
@@ -648,15 +707,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     int pend = 0;                                                    // store instructions this wave left in flight behind the prologue
     G3_STAMP(0);                                                     // [0] first prologue: addressing + DMA issue
     while (true) {
+        if constexpr (KSPLIT) { dma_setup(); frag_setup(); }        // (again: the copies the prologue used died with it, the epilogue in between ran without them)
         // K-tile 0 of this item must have landed. vmcnt counts loads, stores and DMA pieces in ONE in-order queue, and behind
         // K-tile 0's pieces sit the 4 pieces of K-tile 1 and the `pend` stores of the previous item's epilogue (exactly 16 / 32
         // per wave when that tile was interior and store-only; 0 = "unknown", which waits for the stores too): leave them flying.
-        if (nk > 1 && KSPLIT) {                                     // behind K-tile 0: A0 of K-tile 1 (2 pieces) and the stores
-            if (pend == 40) { asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); }
-            else if (pend == 36) { asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); }
-            else if (pend == 32) { asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); }
-            else if (pend == 16) { asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); }
-            else { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        if (false) {
         } else if (nk > 1) {
             if (pend == 40) { asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); }
             else if (pend == 36) { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
@@ -674,62 +729,74 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         if (wr == 1) __builtin_amdgcn_s_barrier();
         G3_STAMP(1);                                                 // [1] wait for K-tile 0 (+ the stagger barrier)
         if constexpr (KSPLIT) {
-            // Round 5, both operands K-contiguous. Consumed by quadrant, the four load halves of a K-tile read 12 / 4 / 8 / 4 fragments per wave, and the
-            // 12 of phase 0 -- 48 KiB through the LDS pipe for the four waves of a group -- outlast the other group's 16 MFMAs (knock-out builds,
-            // profiles/r05_gemm_kloop_knockouts.txt: without the fragment reads the K loop runs at the MFMA floor, 13.1 against 17.6 us per
-            // 12 K-tiles). Consumed by k-step the phases are (rows half 0, k-step 0) (half 0, k-step 1) (half 1, k-step 0) (half 1, k-step 1): each
-            // multiplies 4 row tiles by ALL 4 column tiles on one k-step, so a phase reads 4 A fragments, the 8 B fragments of the two k-steps are
-            // read once (phases 0 and 1) and stay in registers: 8 / 8 / 4 / 4 reads, 24 instead of 28, none above 8, same 48 fragment registers.
-            // Last reads of K-tile t: A0 and both B halves in phase 1, A1 in phase 3; a half-tile is re-staged >= 2 phases later:
-            //     phase 4t+0: B0(t+1)   4t+1: B1(t+1), vmcnt(6) -> A1(t) landed   4t+2: A1(t+1)   4t+3: A0(t+2), vmcnt(4) -> A0, B0, B1 of t+1 landed
-            // (each wait one phase ahead of the first read of what it retires, as before).
+            // Round 5, both operands K-contiguous. Knock-out builds (profiles/r05_gemm_kloop_knockouts.txt) put the quadrant loop's excess over the MFMA floor
+            // (17.6 against 13.1 us per 12 K-tiles) on the fragment reads: not their number (24 or 28 per K-tile measured equal) but their LATENCY, paid behind
+            // the barrier in front of every MFMA cluster. So a K-tile is consumed BY K-STEP -- phases (rows half 0, k-step 0) (half 0, k-step 1) (half 1, k-step 0)
+            // (half 1, k-step 1): 4 row tiles x ALL 4 column tiles on one k-step -- and the A fragments of the NEXT phase are requested INSIDE this phase's MFMA
+            // cluster, each row tile's right behind the four MFMAs that were its last readers (same registers: no second set), the B fragments of a k-step in
+            // the load half one phase ahead of their first use (they live for two phases). Behind a barrier the MFMAs start at once.
+            //     phase 4t+0: load half: B.k1(t) -> phase 1; DMA B1(t+1); vmcnt(6): A1(t) landed      MFMAs A0.k0 x B.k0, between them A0.k1(t) -> phase 1
+            //     phase 4t+1: load half: DMA A1(t+1)                                                   MFMAs A0.k1 x B.k1, between them A1.k0(t) -> phase 2
+            //     phase 4t+2: load half: DMA A0(t+2); vmcnt(4): A0, B0, B1 of t+1 landed               MFMAs A1.k0 x B.k0, between them A1.k1(t) -> phase 3
+            //     phase 4t+3: load half: B.k0(t+1) -> phase 0; DMA B0(t+2)                             MFMAs A1.k1 x B.k1, between them A0.k0(t+1) -> phase 0
+            // Every counted wait sits one phase (two barriers, the staggered group's included) ahead of the first read of what it retires; a half-tile is
+            // re-staged >= 2 barrier intervals after the last request that reads it (A0: phase 0's cluster -> phase 2; B: phase 0's load half -> phases 3 and,
+            // for the other slot, 0; A1: phase 2's cluster -> phase 1 of the next K-tile).
             bf16x8 a1[4], bk[2][4];
-#define G3K_READ_A(SL, H, KS) do { _Pragma("unroll") for (int i = 0; i < 4; ++i) a1[i] = frag<true, 128>(smem + (SL) * SLOT + (H) * HALF, wr * 64 + i * 16, KS, lane); } while (0)
-#define G3K_READ_B(SL, KS) do { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) bk[KS][jj] = frag<true, 128>(smem + (SL) * SLOT + (2 + (jj >> 1)) * HALF, wc * 32 + (jj & 1) * 16, KS, lane); } while (0)
-#define G3K_MMA(MH, KS)                                                                                          \
+            // fragment addresses: one register per (row tile, k-step) for A and per (column tile, k-step) for B, the B ones relative to the B region (its
+            // offsets would not fit the ds_read's 16-bit immediate from the ring's start, and hipcc then keeps one register per (half, slot) as well)
+#define G3K_READ_A1(I, SL, H, KS) a1[I] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(fa[I][KS] + (unsigned)G3_OFF_A(SL, H))
+#define G3K_READ_B(SL, KS) do { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) bk[KS][jj] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(fb[jj & 1][KS] + (unsigned)(G3_OFF_B(SL, jj >> 1) - SLOT)); } while (0)
+    // the cluster of a phase: for every row tile its four MFMAs, then (COND) the request of that row tile's fragment for the next phase
+#define G3K_MMA(MH, KS, COND, SL, H, NKS)                                                                         \
     do {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_barrier();                                                                             \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
             _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                       \
                 acc[(MH) * 4 + i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[KS][jj], a1[i], acc[(MH) * 4 + i][jj], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if (COND) G3K_READ_A1(i, SL, H, NKS);                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_barrier();                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
-            for (int kt = 0; kt < nk; ++kt) {
-                const int sl = kt & 1;
-                G3K_READ_B(sl, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                G3K_READ_A(sl, 0, 0);
-                if (kt + 1 < nk) G3_ISSUE_B(kt + 1, 0);
-                G3K_MMA(0, 0);
-                G3K_READ_B(sl, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                G3K_READ_A(sl, 0, 1);
-                if (kt + 1 < nk) {
-                    G3_ISSUE_B(kt + 1, 1);
-                    // A1 of THIS K-tile (issued in phase 2 of the previous one; K-tile 0's came with the prologue and was waited for above) is older
-                    // than A0(t+1), B0(t+1), B1(t+1): 6 pieces
-                    if (kt > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                } else if (kt > 0) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                G3K_MMA(0, 1);
-                G3K_READ_A(sl, 1, 0);
-                if (kt + 1 < nk) G3_ISSUE_A(kt + 1, 1);
-                G3K_MMA(1, 0);
-                G3K_READ_A(sl, 1, 1);
-                if (kt + 2 < nk) { G3_ISSUE_A(kt + 2, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }      // in flight: A1(t+1), A0(t+2)
-                else if (kt + 1 < nk) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }                        // in flight: A1(t+1)
-                else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                G3K_MMA(1, 1);
+            if (nk > 0) {                                               // phase 0 of K-tile 0: the one exposed read latency of the item
+                G3K_READ_B(0, 0);
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) G3K_READ_A1(i, 0, 0, 0);
             }
-#undef G3K_READ_A
+            // one K-tile out of LDS slot SL (a literal: the loop is written out for both slots)
+#define G3K_TILE(SL, KT)                                                                                          \
+    do {                                                                                                          \
+        G3K_READ_B(SL, 1);                                                                                        \
+        if ((KT) + 1 < nk) {                                                                                      \
+            G3S_ISSUE_B((KT) + 1, 1);                                                                              \
+            if ((KT) > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      /* A1(t) is older than A0(t+1), B0(t+1), B1(t+1) */ \
+        } else if ((KT) > 0) {                                                                                    \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        }                                                                                                         \
+        G3K_MMA(0, 0, true, SL, 0, 1);                                                                            \
+        if ((KT) + 1 < nk) G3S_ISSUE_A((KT) + 1, 1);                                                               \
+        G3K_MMA(0, 1, true, SL, 1, 0);                                                                            \
+        if ((KT) + 2 < nk) { G3S_ISSUE_A((KT) + 2, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }          /* in flight: A1(t+1), A0(t+2) */ \
+        else if ((KT) + 1 < nk) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }                              /* in flight: A1(t+1) */ \
+        G3K_MMA(1, 0, true, SL, 1, 1);                                                                            \
+        G3K_READ_B(1 - (SL), 0);                /* behind the last K-tile these read stale LDS that nobody uses: no branch inside the schedule */ \
+        if ((KT) + 2 < nk) G3S_ISSUE_B((KT) + 2, 0);                                                               \
+        G3K_MMA(1, 1, true, 1 - (SL), 0, 0);                                                                      \
+    } while (0)
+            for (int kt = 0; kt < nk; kt += 2) {
+                G3K_TILE(0, kt);
+                if (kt + 1 >= nk) break;
+                G3K_TILE(1, kt + 1);
+            }
+#undef G3K_TILE
+#undef G3K_READ_A1
 #undef G3K_READ_B
 #undef G3K_MMA
         } else
@@ -840,6 +907,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     }
 #endif
 #undef G3_PROLOGUE
+#undef G3S_ISSUE_A
+#undef G3S_ISSUE_B
+#undef G3_OFF_A
+#undef G3_OFF_B
 #undef G3_ISSUE_A
 #undef G3_ISSUE_B
 #undef G3_ISSUE_A1
