@@ -711,8 +711,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         // K-tile 0 of this item must have landed. vmcnt counts loads, stores and DMA pieces in ONE in-order queue, and behind
         // K-tile 0's pieces sit the 4 pieces of K-tile 1 and the `pend` stores of the previous item's epilogue (exactly 16 / 32
         // per wave when that tile was interior and store-only; 0 = "unknown", which waits for the stores too): leave them flying.
-        if (false) {
-        } else if (nk > 1) {
+        if (nk > 1) {
             if (pend == 40) { asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); }
             else if (pend == 36) { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
             else if (pend == 32) { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); }
