@@ -575,7 +575,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     const bf16_t* B = p.B + z1 * p.sB1 + z2 * p.sB2;
 
     // K-contiguous operands (NT): the K-tile is consumed BY K-STEP instead of by quadrant (round 5) -- see the loop
-    constexpr bool KSPLIT = A_KC && B_KC && TNW == 4;
+    constexpr bool KSPLIT = A_KC == B_KC && TNW == 4;                  // (round 5, later: the weight-gradient layout TN too -- both operands row-contiguous, transposed reads)
+    constexpr bool KS_NT = KSPLIT && A_KC, KS_TN = KSPLIT && !A_KC;
     f32x4 acc[8][TNW];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -584,15 +585,24 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     bf16x8 a[4][2], b[2][2];
     s16x4 ta[4][2][2], tb[2][2][2];                                   // asm destinations of the transposed reads
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned aoff[4], boff[2];
+    unsigned aoff[4], boff[2];                                         // transposed reads: lane offsets of the row / column tiles (boff: relative to the B region in the k-step loop)
+    if constexpr (!KS_TN) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) aoff[i] = lds0 + tr_lane_off(wr * 64 + i * 16, lane);
+        for (int i = 0; i < 4; ++i) aoff[i] = lds0 + tr_lane_off(wr * 64 + i * 16, lane);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) boff[j] = lds0 + tr_lane_off(wc * 32 + j * 16, lane);
+        for (int j = 0; j < 2; ++j) boff[j] = lds0 + tr_lane_off(wc * 32 + j * 16, lane);
+    }
     // K-contiguous fragment addresses of the k-step loop (frag<true, 128>'s formula). Recomputed from the (opaque) lane number in front of every item's K loop:
     // 12 registers the epilogue in between does not have to keep
     unsigned fa[4][2], fb[2][2];
     auto frag_setup = [&]() {
+        if constexpr (KS_TN) {
+            int lq = lane; asm volatile("" : "+v"(lq));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { aoff[i] = lds0 + tr_lane_off(wr * 64 + i * 16, lq); asm volatile("" : "+v"(aoff[i])); }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { boff[j] = lds0 + (unsigned)SLOT + tr_lane_off(wc * 32 + j * 16, lq); asm volatile("" : "+v"(boff[j])); }
+        }
         if constexpr (A_KC && B_KC) {
             int lq = lane; asm volatile("" : "+v"(lq));
             const int lr_ = lq & 15, g_ = lq >> 4;
@@ -614,7 +624,22 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
     unsigned voA[2][2] = {{0u, 0u}, {0u, 0u}}, voB[2][2] = {{0u, 0u}, {0u, 0u}};
     const char *sA = nullptr, *sB = nullptr;
     auto dma_setup = [&]() {
-        if constexpr (KSPLIT) {
+        if constexpr (KS_TN) {                                         // image [64 k][128 columns]: a piece = 4 k-rows, a lane = 8 columns (clamped once per item)
+            int lq = lane; asm volatile("" : "+v"(lq));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int krow = (wave * 2 + n) * 4 + (lq >> 4), hc = (((lq & 15) ^ rswz(krow))) * 8;
+                    const int ca = min(m0 + (hc / 64) * 128 + h * 64 + (hc % 64), p.M - 8) - m0;
+                    const int cb = min(n0 + (hc / 32) * GSB + h * 32 + (hc % 32), p.N - 8) - n0;
+                    voA[h][n] = (unsigned)((krow * (int)p.lda + ca) * 2);
+                    voB[h][n] = (unsigned)((krow * (int)p.ldb + cb) * 2);
+                }
+            sA = sgpr_ptr(A + (long)kbeg * p.lda + m0);
+            sB = sgpr_ptr(B + (long)kbeg * p.ldb + n0);
+        }
+        if constexpr (KS_NT) {
             int lq = lane; asm volatile("" : "+v"(lq));
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -630,8 +655,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             sB = sgpr_ptr(B + (long)n0 * p.ldb + kbeg);
         }
     };
-#define G3S_ISSUE_A(T, H) do { _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) glds16_s(voA[H][n_], sA + (long)(T) * (BK * 2), lds0 + (unsigned)(G3_OFF_A((T) & 1, H) + (wave * 2 + n_) * 1024)); } while (0)
-#define G3S_ISSUE_B(T, H) do { _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) glds16_s(voB[H][n_], sB + (long)(T) * (BK * 2), lds0 + (unsigned)(G3_OFF_B((T) & 1, H) + (wave * 2 + n_) * 1024)); } while (0)
+#define G3S_ISSUE_A(T, H) do { _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) glds16_s(voA[H][n_], sA + (long)(T) * (A_KC ? (long)(BK * 2) : (long)(BK * 2) * p.lda), lds0 + (unsigned)(G3_OFF_A((T) & 1, H) + (wave * 2 + n_) * 1024)); } while (0)
+#define G3S_ISSUE_B(T, H) do { _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) glds16_s(voB[H][n_], sB + (long)(T) * (B_KC ? (long)(BK * 2) : (long)(BK * 2) * p.ldb), lds0 + (unsigned)(G3_OFF_B((T) & 1, H) + (wave * 2 + n_) * 1024)); } while (0)
 #define G3_READ_A(SL, H)                                                                                          \
     do {                                                                                                          \
         if constexpr (A_KC) {                                                                                     \
@@ -744,13 +769,43 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             bf16x8 a1[4], bk[2][4];
             // fragment addresses: one register per (row tile, k-step) for A and per (column tile, k-step) for B, the B ones relative to the B region (its
             // offsets would not fit the ds_read's 16-bit immediate from the ring's start, and hipcc then keeps one register per (half, slot) as well)
-#define G3K_READ_A1(I, SL, H, KS) a1[I] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(fa[I][KS] + (unsigned)G3_OFF_A(SL, H))
-#define G3K_READ_B(SL, KS) do { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) bk[KS][jj] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(fb[jj & 1][KS] + (unsigned)(G3_OFF_B(SL, jj >> 1) - SLOT)); } while (0)
+            // The weight-gradient layout (TN: both operands row-contiguous) runs the same schedule. A fragment there = two ds_read_b64_tr_b16 (k rows +0..3 and
+            // +4..7 of each 8-row group) that must land in the two halves of ONE 128-bit operand. Written as two 64-bit values joined afterwards (asm or the
+            // compiler's builtin alike) the allocator falls apart once such a pair is in flight across phases (370 - 507 spilled registers); so each of the 12
+            // fragments is ONE asm statement with a 128-bit result PINNED to a register quad, its halves named literally (v200-v247), and the cluster's first
+            // statement is the counted wait that names what it is about to use: lgkmcnt(8) where the load half just requested the 8 B reads of the next k-step
+            // (LDS returns in order), lgkmcnt(0) elsewhere. The disassembly must show no copy of v200-v247 inside the loop (tools/check_gemm_isa.py).
+#define G3K_TRL(VAR, R0, R1, R2, R3, ADDR, OFF)                                                                   \
+    asm volatile("ds_read_b64_tr_b16 v[" #R0 ":" #R1 "], %1 offset:%2\n\tds_read_b64_tr_b16 v[" #R2 ":" #R3 "], %1 offset:%3"         \
+                 : "={v[" #R0 ":" #R3 "]}"(VAR) : "v"(ADDR), "i"(OFF), "i"((OFF) + 1024))
+#define G3K_TRA(I, OFF) do { if ((I) == 0) G3K_TRL(a1[0], 200, 201, 202, 203, aoff[0], OFF); else if ((I) == 1) G3K_TRL(a1[1], 204, 205, 206, 207, aoff[1], OFF); \
+                             else if ((I) == 2) G3K_TRL(a1[2], 208, 209, 210, 211, aoff[2], OFF); else G3K_TRL(a1[3], 212, 213, 214, 215, aoff[3], OFF); } while (0)
+#define G3K_TRB(SL, KS) do { if constexpr ((KS) == 0) {                                                          \
+            G3K_TRL(bk[0][0], 216, 217, 218, 219, boff[0], G3_OFF_B(SL, 0) - SLOT); G3K_TRL(bk[0][1], 220, 221, 222, 223, boff[1], G3_OFF_B(SL, 0) - SLOT); \
+            G3K_TRL(bk[0][2], 224, 225, 226, 227, boff[0], G3_OFF_B(SL, 1) - SLOT); G3K_TRL(bk[0][3], 228, 229, 230, 231, boff[1], G3_OFF_B(SL, 1) - SLOT); \
+        } else {                                                                                                  \
+            G3K_TRL(bk[1][0], 232, 233, 234, 235, boff[0], G3_OFF_B(SL, 0) - SLOT + 8192); G3K_TRL(bk[1][1], 236, 237, 238, 239, boff[1], G3_OFF_B(SL, 0) - SLOT + 8192); \
+            G3K_TRL(bk[1][2], 240, 241, 242, 243, boff[0], G3_OFF_B(SL, 1) - SLOT + 8192); G3K_TRL(bk[1][3], 244, 245, 246, 247, boff[1], G3_OFF_B(SL, 1) - SLOT + 8192); \
+        } } while (0)
+#define G3K_A4 "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3])
+#define G3K_B4(KS) "+v"(bk[KS][0]), "+v"(bk[KS][1]), "+v"(bk[KS][2]), "+v"(bk[KS][3])
+    // NEWB: the phase is the first reader of B k-step KS; AHEAD: the load half in front of it requested 8 reads the phase does not need
+#define G3K_TRWAIT(KS, NEWB, AHEAD) do { if constexpr (!A_KC) {                                                   \
+            if constexpr ((NEWB) && (AHEAD)) asm volatile("s_waitcnt lgkmcnt(8)" : G3K_A4, G3K_B4(KS));           \
+            else if constexpr (NEWB) asm volatile("s_waitcnt lgkmcnt(0)" : G3K_A4, G3K_B4(KS));                   \
+            else if constexpr (AHEAD) asm volatile("s_waitcnt lgkmcnt(8)" : G3K_A4);                              \
+            else asm volatile("s_waitcnt lgkmcnt(0)" : G3K_A4); } } while (0)
+#define G3K_READ_A1(I, SL, H, KS) do { if constexpr (A_KC) a1[I] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(fa[I][KS] + (unsigned)G3_OFF_A(SL, H)); \
+                                       else G3K_TRA(I, G3_OFF_A(SL, H) + (KS) * 8192); } while (0)
+#define G3K_READ_B(SL, KS) do { if constexpr (B_KC) { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                 \
+        bk[KS][jj] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(fb[jj & 1][KS] + (unsigned)(G3_OFF_B(SL, jj >> 1) - SLOT)); }     \
+        else G3K_TRB(SL, KS); } while (0)
     // the cluster of a phase: for every row tile its four MFMAs, then (COND) the request of that row tile's fragment for the next phase
-#define G3K_MMA(MH, KS, COND, SL, H, NKS)                                                                         \
+#define G3K_MMA(MH, KS, COND, SL, H, NKS, NEWB, AHEAD)                                                            \
     do {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_barrier();                                                                             \
+        G3K_TRWAIT(KS, NEWB, AHEAD);                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
@@ -779,22 +834,29 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
         } else if ((KT) > 0) {                                                                                    \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
         }                                                                                                         \
-        G3K_MMA(0, 0, true, SL, 0, 1);                                                                            \
+        G3K_MMA(0, 0, true, SL, 0, 1, true, true);                                                                            \
         if ((KT) + 1 < nk) G3S_ISSUE_A((KT) + 1, 1);                                                               \
-        G3K_MMA(0, 1, true, SL, 1, 0);                                                                            \
+        G3K_MMA(0, 1, true, SL, 1, 0, true, false);                                                                           \
         if ((KT) + 2 < nk) { G3S_ISSUE_A((KT) + 2, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }          /* in flight: A1(t+1), A0(t+2) */ \
         else if ((KT) + 1 < nk) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }                              /* in flight: A1(t+1) */ \
-        G3K_MMA(1, 0, true, SL, 1, 1);                                                                            \
+        G3K_MMA(1, 0, true, SL, 1, 1, false, false);                                                                           \
         G3K_READ_B(1 - (SL), 0);                /* behind the last K-tile these read stale LDS that nobody uses: no branch inside the schedule */ \
         if ((KT) + 2 < nk) G3S_ISSUE_B((KT) + 2, 0);                                                               \
-        G3K_MMA(1, 1, true, 1 - (SL), 0, 0);                                                                      \
+        G3K_MMA(1, 1, true, 1 - (SL), 0, 0, false, true);                                                                     \
     } while (0)
             for (int kt = 0; kt < nk; kt += 2) {
                 G3K_TILE(0, kt);
                 if (kt + 1 >= nk) break;
                 G3K_TILE(1, kt + 1);
             }
+            if constexpr (!A_KC) asm volatile("s_waitcnt lgkmcnt(0)" : G3K_A4, G3K_B4(0));    // the stale requests behind the last K-tile retire before their registers are anyone else's
 #undef G3K_TILE
+#undef G3K_TRL
+#undef G3K_TRA
+#undef G3K_TRB
+#undef G3K_A4
+#undef G3K_B4
+#undef G3K_TRWAIT
 #undef G3K_READ_A1
 #undef G3K_READ_B
 #undef G3K_MMA

@@ -28,3 +28,18 @@ for M, N, K in shapes:
         torch.cuda.synchronize()
         assert torch.isfinite(C).all()
         print(M, N, K, rep, hashlib.sha1(C.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
+# the weight-gradient layout (TN, both operands row-contiguous, split-K into f32 slabs + the reduction), launched as engine._wgrad launches it
+for M, N, T, nsplit in [(3072, 768, 26624, 7), (768, 3072, 26880, 7), (768, 768, 26624, 28), (2304, 768, 26624, 9), (768, 2304, 26880, 9), (512, 512, 8192, 8), (1280, 768, 26624, 17)]:
+    dy, x = rn(T, M), rn(T, N)
+    slabs = torch.empty(nsplit * M * N, device=dev)
+    for rep in range(REPS):
+        G = torch.zeros(M, N, device=dev)
+        if rep % 2:
+            with torch.cuda.stream(side):
+                ops.gemm(noiseA, noiseB, noiseC, M=8192, N=2048, K=1024, dtype=ops.PB_BF16)
+        ops.gemm(dy, x, G, M=M, N=N, K=T, dtype=ops.PB_BF16, a_kc=False, b_kc=False, lda=M, ldb=N, ldc=N, c_f32=True, splitk=nsplit, slabs=slabs, tile256=True,
+                 dbg=(4096 if rep % 4 == 3 else 0))
+        torch.cuda.synchronize()
+        assert torch.isfinite(G).all()
+        print('TN', M, N, T, rep, hashlib.sha1(G.cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
+
