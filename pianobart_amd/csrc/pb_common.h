@@ -97,14 +97,32 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // Fast variants for the bf16 throughput path (the exact-f32 path keeps erff): erf by Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7, far below bf16 resolution): one v_exp, one v_rcp, 6 FMAs; the derivative shares the exponential.
+// (|error| <= 1.5e-7, far below bf16 resolution): one v_exp, one v_rcp; the derivative shares the exponential. Written on
+// h(x) = 0.5 erfc(|x| / sqrt2) = 0.5 t P(t) exp(-x^2/2), t = 1 / (1 + 0.3275911 |x| / sqrt2): cdf = 0.5 + copysign(0.5 - h, x) -- a v_bfi instead of a
+// compare + select (20 cycles per wave-instruction behind the SGPR mask on gfx950: tools/probes/valu_rate.hip), the 0.5 folded into the coefficients.
+// gelu_pair2 below is the same arithmetic on two values in packed f32 instructions.
+constexpr float PB_GELU_A2 = 0.72134752044448170f;               // log2(e) / 2: exp(-x^2 / 2) = exp2(-A2 x^2)
+constexpr float PB_GELU_C1 = 0.23164188861847f;                  // 0.3275911 / sqrt(2)
+constexpr float PB_GELU_H1 = 0.127414796f, PB_GELU_H2 = -0.142248368f, PB_GELU_H3 = 0.7107068705f, PB_GELU_H4 = -0.7265760135f, PB_GELU_H5 = 0.5307027145f;
 __device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& ex) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    ex = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);                     // exp(-x^2/2)
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float erfa = 1.0f - poly * ex;                                            // erf(|x|/sqrt2)
-    cdf = 0.5f * (1.0f + (x < 0.f ? -erfa : erfa));
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), PB_GELU_C1, 1.0f));
+    ex = __builtin_amdgcn_exp2f(-((x * x) * PB_GELU_A2));                          // exp(-x^2/2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, PB_GELU_H5, PB_GELU_H4), PB_GELU_H3), PB_GELU_H2), PB_GELU_H1);
+    cdf = 0.5f + __builtin_copysignf(0.5f - poly * ex, x);
+}
+typedef __attribute__((ext_vector_type(2))) float pb_f32x2;
+__device__ __forceinline__ void gelu_pair2(pb_f32x2 x, pb_f32x2& y, pb_f32x2& dy) {
+    const pb_f32x2 q = (x * x) * PB_GELU_A2;
+    pb_f32x2 e, t;
+    e[0] = __builtin_amdgcn_exp2f(-q[0]); e[1] = __builtin_amdgcn_exp2f(-q[1]);
+    t[0] = __builtin_amdgcn_rcpf(fmaf(fabsf(x[0]), PB_GELU_C1, 1.0f)); t[1] = __builtin_amdgcn_rcpf(fmaf(fabsf(x[1]), PB_GELU_C1, 1.0f));
+    pb_f32x2 pl = t * PB_GELU_H5 + PB_GELU_H4;
+    pl = pl * t + PB_GELU_H3; pl = pl * t + PB_GELU_H2; pl = pl * t + PB_GELU_H1; pl = pl * t;
+    const pb_f32x2 r = 0.5f - pl * e;
+    pb_f32x2 rs; rs[0] = __builtin_copysignf(r[0], x[0]); rs[1] = __builtin_copysignf(r[1], x[1]);
+    const pb_f32x2 cdf = rs + 0.5f;
+    y = x * cdf;
+    dy = (x * 0.3989422804014327f) * e + cdf;
 }
 __device__ __forceinline__ float gelu_fast(float x) { float c, e; gelu_parts_fast(x, c, e); return x * c; }
 __device__ __forceinline__ void gelu_both_fast(float x, float& y, float& dy) { float c, e; gelu_parts_fast(x, c, e); y = x * c; dy = c + x * 0.3989422804014327f * e; }

@@ -400,6 +400,52 @@ __device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][
     }
 }
 
+// The forward fc1 epilogue of an interior tile: C = gelu(alpha acc + bias), aux_out = gelu'(...), both bf16. The tile's 2 x 128 KiB of stores are not what
+// it waits for: 128 values per lane x (exp + rcp + ~15 VALU operations) with two waves sharing each SIMD made 12.7 us of a 33 us item (profiles/
+// r05_gemm_item_anatomy.txt). Here the arithmetic runs two values per instruction (gelu_pair2: v_pk_mul / v_pk_fma, 5.5 cycles per wave-instruction
+// against 4.1 for the scalar ones, tools/probes/valu_rate.hip), the sign select is a v_bfi, and the addresses are an SGPR base + one lane offset per
+// operand (epilogue_regs: a 64-bit multiply-add per row and store). Exactly 32 stores per wave (the caller's `pend`).
+template <int IMM> __device__ __forceinline__ void pf_store_nt(unsigned voff, const char* sbase, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void epilogue_gelu(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias) {
+    asm volatile("" : "+v"(lane));
+    const int lr = lane & 15, lg = lane >> 4;
+    const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
+    const char* cbase = sgpr_ptr(reinterpret_cast<bf16_t*>(p.C) + coff + (long)mw * p.ldc + nw);
+    const char* abase = sgpr_ptr(p.aux_out + (long)mw * p.ldaux + nw);
+    const unsigned cvoff = (unsigned)(lr * (int)p.ldc + cb) * 2u, avoff = (unsigned)(lr * (int)p.ldaux + cb) * 2u;
+    const long cstep = 32 * p.ldc, astep = 32 * p.ldaux;                                // bytes per 16 rows
+    f32x4 bv[2][2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        bv[jp][0] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[jp][1] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    static_for<0, 16>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, i = c >> 1, jp = c & 1;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xa = acc[i][2 * jp][r], xb = acc[i][2 * jp + 1][r];
+            auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+            v0[r] = __uint_as_float(sw[0]);
+            v1[r] = __uint_as_float(sw[1]);
+        }
+        v0 = v0 * p.alpha + bv[jp][0];
+        v1 = v1 * p.alpha + bv[jp][1];
+        pb_f32x2 y[4], dy[4];
+        gelu_pair2(pb_f32x2{v0[0], v0[1]}, y[0], dy[0]);
+        gelu_pair2(pb_f32x2{v0[2], v0[3]}, y[1], dy[1]);
+        gelu_pair2(pb_f32x2{v1[0], v1[1]}, y[2], dy[2]);
+        gelu_pair2(pb_f32x2{v1[2], v1[3]}, y[3], dy[3]);
+        const bf16x8 ry = {(bf16_t)y[0][0], (bf16_t)y[0][1], (bf16_t)y[1][0], (bf16_t)y[1][1], (bf16_t)y[2][0], (bf16_t)y[2][1], (bf16_t)y[3][0], (bf16_t)y[3][1]};
+        const bf16x8 rd = {(bf16_t)dy[0][0], (bf16_t)dy[0][1], (bf16_t)dy[1][0], (bf16_t)dy[1][1], (bf16_t)dy[2][0], (bf16_t)dy[2][1], (bf16_t)dy[3][0], (bf16_t)dy[3][1]};
+        pf_store_nt<jp * 64>(avoff, abase + i * astep, __builtin_bit_cast(u32x4, rd));
+        pf_store<jp * 64>(cvoff, cbase + i * cstep, __builtin_bit_cast(u32x4, ry));
+    });
+}
+
 // One-barrier kernel. WM x WN waves, each TM x TN MFMA tiles of 16x16: block tile BM = 16*WM*TM by BN = 16*WN*TN.
 // Measured: the 128x128 main loop is bound by the L2 -> LDS load path (64 FLOP per loaded byte, ~1 PF ceiling); with two
 // workgroups per CU one's store tail overlaps the other's main loop, which is why it still serves the narrow outputs.
@@ -929,6 +975,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
                 if (inner && rmw == PB_GEMM_MUL_GELU_GRAD && cs_row) { epilogue_pf<1, true>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row); epf = true; }
                 else if (inner && rmw == PB_GEMM_MUL_GELU_GRAD) { epilogue_pf<1, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
                 else if (inner && rmw == PB_GEMM_ACCUM && !cs_row) { epilogue_pf<2, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
+                else if (inner && rmw == PB_GEMM_GELU && p.aux_out) { epilogue_gelu(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias); }   // 32 stores: `pend` below counts them
                 else if (rmw == PB_GEMM_ROWDOT) { epilogue_pf<3, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf3 = true; }   // the host admits whole tiles only
                 else epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
             } else {

@@ -32,3 +32,15 @@ def test_ops_refuse_cpu_tensors():
     x = torch.zeros(4, 4)
     with pytest.raises(_lib.PBError):
         ops.gemm(x, x, x, M=4, N=4, K=4, dtype=_lib.PB_F32)
+
+
+def test_persistent_gemm_isa_has_no_spills_and_no_copies_of_in_flight_fragments():
+    """tools/check_gemm_isa.py on the cross-compiled gfx950 code: a spilled vector register would enter the K loop's counted vmcnt queue,
+    and any instruction other than the transposed reads and the MFMAs naming v200-v247 inside the TN loop would touch data still in flight."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('check_gemm_isa', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'check_gemm_isa.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    errs, meta = mod.check(mod.disassemble())
+    assert len(meta) == 2 and not errs, errs[:5]
