@@ -408,13 +408,43 @@ __device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][
 template <int IMM> __device__ __forceinline__ void pf_store_nt(unsigned voff, const char* sbase, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
 }
-__device__ __forceinline__ void epilogue_gelu(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias) {
+// Row staging of the asm-store epilogues (round 5, late): the MFMA registers leave a lane with 8 consecutive columns of ONE row, and the four lanes that
+// complete 64 bytes of that row are 16 lane numbers apart -- the memory pipeline merges ADJACENT lanes only, so such a store instruction is 64 separate
+// 16-byte writes and a tile's 128 KiB take a CU 5.3 us whatever the rest of the chip does (tools/probes/store_tile.hip; the same bytes with 8 adjacent
+// lanes per 128-byte row: 2.3 us). Each 16-row group therefore takes a trip through a wave-private 2 KiB LDS image [16 rows][128 B] (written as the
+// registers lie, 16-byte slot XOR row & 7; read back 8 lanes per row; no barrier: a wave's LDS operations execute in order) and leaves as two stores of
+// 8 rows x 128 contiguous bytes.
+constexpr int G3_STAGE_OFF = 131072 + 2048, G3_STAGE_BYTES = 8 * 2048;
+struct RowStage {
+    unsigned wr0, wr1, rd;          // LDS byte addresses: this lane's two chunks (columns cb .. +7 and 32 + cb .. +7 of row lr); its read slot (row lane >> 3, chunk lane & 7; + 1024: row + 8)
+    int row, chunk;                 // of the read side
+};
+__device__ __forceinline__ RowStage row_stage(unsigned lds_base /* of the kernel's dynamic LDS */, int wave, int lane) {
+    const int lr = lane & 15, lg = lane >> 4, q = ((lg & 1) << 1) | (lg >> 1);            // q = cb / 8: lg 0, 2, 1, 3 -> chunk 0, 1, 2, 3 of the 32-column half
+    const unsigned base = lds_base + (unsigned)(G3_STAGE_OFF + wave * 2048);
+    RowStage r;
+    r.wr0 = base + (unsigned)(lr * 128 + ((q ^ (lr & 7)) << 4));
+    r.wr1 = base + (unsigned)(lr * 128 + (((4 + q) ^ (lr & 7)) << 4));
+    r.row = lane >> 3; r.chunk = lane & 7;
+    r.rd = base + (unsigned)(r.row * 128 + ((r.chunk ^ r.row) << 4));
+    return r;
+}
+__device__ __forceinline__ void row_stage_put(const RowStage& r, u32x4 c0, u32x4 c1) {
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(r.wr0) = c0;
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(r.wr1) = c1;
+}
+__device__ __forceinline__ void row_stage_get(const RowStage& r, u32x4& lo, u32x4& hi) {     // rows 0 .. 7 / 8 .. 15 of the group
+    lo = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(r.rd);
+    hi = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(r.rd + 1024);
+}
+__device__ __forceinline__ void epilogue_gelu(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias, unsigned lds_base, int wave) {
     asm volatile("" : "+v"(lane));
     const int lr = lane & 15, lg = lane >> 4;
     const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
+    const RowStage rs = row_stage(lds_base, wave, lane);
     const char* cbase = sgpr_ptr(reinterpret_cast<bf16_t*>(p.C) + coff + (long)mw * p.ldc + nw);
     const char* abase = sgpr_ptr(p.aux_out + (long)mw * p.ldaux + nw);
-    const unsigned cvoff = (unsigned)(lr * (int)p.ldc + cb) * 2u, avoff = (unsigned)(lr * (int)p.ldaux + cb) * 2u;
+    const unsigned cvoff = (unsigned)(rs.row * (int)p.ldc + rs.chunk * 8) * 2u, avoff = (unsigned)(rs.row * (int)p.ldaux + rs.chunk * 8) * 2u;
     const long cstep = 32 * p.ldc, astep = 32 * p.ldaux;                                // bytes per 16 rows
     f32x4 bv[2][2];
 #pragma unroll
@@ -422,27 +452,80 @@ __device__ __forceinline__ void epilogue_gelu(const Gemm2Args& p, f32x4 (&acc)[8
         bv[jp][0] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
         bv[jp][1] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    static_for<0, 16>([&](auto cc) {
-        constexpr int c = decltype(cc)::value, i = c >> 1, jp = c & 1;
-        f32x4 v0, v1;
+    static_for<0, 8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        u32x4 cy[2], cd[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float xa = acc[i][2 * jp][r], xb = acc[i][2 * jp + 1][r];
-            auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
-            v0[r] = __uint_as_float(sw[0]);
-            v1[r] = __uint_as_float(sw[1]);
+        for (int jp = 0; jp < 2; ++jp) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xa = acc[i][2 * jp][r], xb = acc[i][2 * jp + 1][r];
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+                v0[r] = __uint_as_float(sw[0]);
+                v1[r] = __uint_as_float(sw[1]);
+            }
+            v0 = v0 * p.alpha + bv[jp][0];
+            v1 = v1 * p.alpha + bv[jp][1];
+            pb_f32x2 y[4], dy[4];
+            gelu_pair2(pb_f32x2{v0[0], v0[1]}, y[0], dy[0]);
+            gelu_pair2(pb_f32x2{v0[2], v0[3]}, y[1], dy[1]);
+            gelu_pair2(pb_f32x2{v1[0], v1[1]}, y[2], dy[2]);
+            gelu_pair2(pb_f32x2{v1[2], v1[3]}, y[3], dy[3]);
+            const bf16x8 ry = {(bf16_t)y[0][0], (bf16_t)y[0][1], (bf16_t)y[1][0], (bf16_t)y[1][1], (bf16_t)y[2][0], (bf16_t)y[2][1], (bf16_t)y[3][0], (bf16_t)y[3][1]};
+            const bf16x8 rd = {(bf16_t)dy[0][0], (bf16_t)dy[0][1], (bf16_t)dy[1][0], (bf16_t)dy[1][1], (bf16_t)dy[2][0], (bf16_t)dy[2][1], (bf16_t)dy[3][0], (bf16_t)dy[3][1]};
+            cy[jp] = __builtin_bit_cast(u32x4, ry); cd[jp] = __builtin_bit_cast(u32x4, rd);
         }
-        v0 = v0 * p.alpha + bv[jp][0];
-        v1 = v1 * p.alpha + bv[jp][1];
-        pb_f32x2 y[4], dy[4];
-        gelu_pair2(pb_f32x2{v0[0], v0[1]}, y[0], dy[0]);
-        gelu_pair2(pb_f32x2{v0[2], v0[3]}, y[1], dy[1]);
-        gelu_pair2(pb_f32x2{v1[0], v1[1]}, y[2], dy[2]);
-        gelu_pair2(pb_f32x2{v1[2], v1[3]}, y[3], dy[3]);
-        const bf16x8 ry = {(bf16_t)y[0][0], (bf16_t)y[0][1], (bf16_t)y[1][0], (bf16_t)y[1][1], (bf16_t)y[2][0], (bf16_t)y[2][1], (bf16_t)y[3][0], (bf16_t)y[3][1]};
-        const bf16x8 rd = {(bf16_t)dy[0][0], (bf16_t)dy[0][1], (bf16_t)dy[1][0], (bf16_t)dy[1][1], (bf16_t)dy[2][0], (bf16_t)dy[2][1], (bf16_t)dy[3][0], (bf16_t)dy[3][1]};
-        pf_store_nt<jp * 64>(avoff, abase + i * astep, __builtin_bit_cast(u32x4, rd));
-        pf_store<jp * 64>(cvoff, cbase + i * cstep, __builtin_bit_cast(u32x4, ry));
+        u32x4 lo, hi;
+        row_stage_put(rs, cd[0], cd[1]);
+        row_stage_get(rs, lo, hi);
+        pf_store_nt<0>(avoff, abase + i * astep, lo);
+        pf_store_nt<0>(avoff, abase + i * astep + 16 * p.ldaux, hi);                    // + 8 rows
+        row_stage_put(rs, cy[0], cy[1]);
+        row_stage_get(rs, lo, hi);
+        pf_store<0>(cvoff, cbase + i * cstep, lo);
+        pf_store<0>(cvoff, cbase + i * cstep + 16 * p.ldc, hi);
+    });
+}
+
+// The store-only epilogue of an interior tile (C = alpha acc + bias, bf16) through the row staging: 16 stores of 8 rows x 128 bytes per wave.
+__device__ __forceinline__ void epilogue_plain(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias, unsigned lds_base, int wave) {
+    asm volatile("" : "+v"(lane));
+    const int lr = lane & 15, lg = lane >> 4;
+    const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
+    const RowStage rs = row_stage(lds_base, wave, lane);
+    const char* cbase = sgpr_ptr(reinterpret_cast<bf16_t*>(p.C) + coff + (long)mw * p.ldc + nw);
+    const unsigned cvoff = (unsigned)(rs.row * (int)p.ldc + rs.chunk * 8) * 2u;
+    const long cstep = 32 * p.ldc;
+    f32x4 bv[2][2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        bv[jp][0] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[jp][1] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    static_for<0, 8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        u32x4 cy[2];
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xa = acc[i][2 * jp][r], xb = acc[i][2 * jp + 1][r];
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+                v0[r] = __uint_as_float(sw[0]);
+                v1[r] = __uint_as_float(sw[1]);
+            }
+            v0 = v0 * p.alpha + bv[jp][0];
+            v1 = v1 * p.alpha + bv[jp][1];
+            const bf16x8 ry = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+            cy[jp] = __builtin_bit_cast(u32x4, ry);
+        }
+        u32x4 lo, hi;
+        row_stage_put(rs, cy[0], cy[1]);
+        row_stage_get(rs, lo, hi);
+        pf_store<0>(cvoff, cbase + i * cstep, lo);
+        pf_store<0>(cvoff, cbase + i * cstep + 16 * p.ldc, hi);
     });
 }
 
@@ -975,7 +1058,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
                 if (inner && rmw == PB_GEMM_MUL_GELU_GRAD && cs_row) { epilogue_pf<1, true>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row); epf = true; }
                 else if (inner && rmw == PB_GEMM_MUL_GELU_GRAD) { epilogue_pf<1, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
                 else if (inner && rmw == PB_GEMM_ACCUM && !cs_row) { epilogue_pf<2, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
-                else if (inner && rmw == PB_GEMM_GELU && p.aux_out) { epilogue_gelu(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias); }   // 32 stores: `pend` below counts them
+                else if (inner && rmw == 0 && !cs_row && !(p.flags & 256)) { epilogue_plain(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, lds0, wave); }   // 16 stores (bit 8: the register path, for A/B runs)
+                else if (inner && rmw == PB_GEMM_GELU && p.aux_out) { epilogue_gelu(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, lds0, wave); }   // 32 stores: `pend` below counts them
                 else if (rmw == PB_GEMM_ROWDOT) { epilogue_pf<3, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf3 = true; }   // the host admits whole tiles only
                 else epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
             } else {
@@ -1133,7 +1217,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 2048 | 4096 | 8192 | 16384 | 32768)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 256 | 2048 | 4096 | 8192 | 16384 | 32768)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue other than accumulate");
         return -2;
     }
@@ -1266,10 +1350,10 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
 #define PB_G3_LAUNCH(AK, BK_)                                                                                              \
     do {                                                                                                                 \
         auto kfn = gemm3_kernel<AK, BK_, 4>;                                                                               \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048 + 8192); \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G3_STAGE_OFF + G3_STAGE_BYTES + 8192); \
         const unsigned items = a.tail_split > 1 ? a.n_full + (grid.x - a.n_full) * a.tail_split : grid.x;                    \
         dim3 pgrid(std::min<unsigned>(items, (d->flags & 4096) ? items : (unsigned)pb_num_cus()), grid.y, 1);               \
-        hipLaunchKernelGGL(kfn, pgrid, dim3(512), 131072 + 2048 + 16 * (size_t)lds_tag, stream, a);                       \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(512), G3_STAGE_OFF + G3_STAGE_BYTES + 16 * (size_t)lds_tag, stream, a);                       \
         if (a.tail_split > 1) hipLaunchKernelGGL(tail_finish_kernel<4>, dim3((grid.x - a.n_full) * TAIL_FIN_PARTS), dim3(256), 0, stream, a); \
     } while (0)
         if (a_kc) PB_G3_LAUNCH(true, true);

@@ -42,4 +42,34 @@ for M, N, T, nsplit in [(3072, 768, 26624, 7), (768, 3072, 26880, 7), (768, 768,
         torch.cuda.synchronize()
         assert torch.isfinite(G).all()
         print('TN', M, N, T, rep, hashlib.sha1(G.cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
+# the epilogues with their own store paths: bias + GELU pair (two outputs), * gelu' (+ column sums), += and + row-dot
+for M, N, K in [(26624, 3072, 768), (26880, 3072, 768), (2048, 512, 768)]:
+    A, B = rn(M, K), rn(N, K)
+    bias = torch.randn(N, device=dev, generator=g)
+    gp = rn(M, N)
+    for rep in range(max(2, REPS // 2)):
+        C = torch.full((M, N), float('nan'), device=dev, dtype=bf); aux = torch.full((M, N), float('nan'), device=dev, dtype=bf)
+        ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, bias=bias, gelu_aux_out=aux)
+        torch.cuda.synchronize()
+        assert torch.isfinite(C).all() and torch.isfinite(aux).all()
+        print('GELU', M, N, K, rep, hashlib.sha1(C.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha1(aux.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
+        C2 = torch.full((M, N), float('nan'), device=dev, dtype=bf)
+        cs = torch.zeros(N, device=dev); csws = torch.empty(int(2 * ((M + 255) // 256) * N), device=dev)
+        ops.gemm(A, B, C2, M=M, N=N, K=K, dtype=ops.PB_BF16, gelu_grad_aux_in=gp, colsum_out=cs, colsum_ws=csws)
+        torch.cuda.synchronize()
+        print('GELUGRAD', M, N, K, rep, hashlib.sha1(C2.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha1(cs.cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
+for M, N, K in [(26624, 768, 3072), (26880, 768, 2304), (26624, 768, 768)]:
+    A, B = rn(M, K), rn(N, K)
+    C0 = rn(M, N)
+    O = rn(M, N)
+    for rep in range(max(2, REPS // 2)):
+        C = C0.clone()
+        ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, accum=True)
+        torch.cuda.synchronize()
+        print('ACCUM', M, N, K, rep, hashlib.sha1(C.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
+        if N == 768 and K == 768:
+            C = torch.full((M, N), float('nan'), device=dev, dtype=bf); rd = torch.full((N // 64, M), float('nan'), device=dev)
+            ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, rowdot=(O, rd, M))
+            torch.cuda.synchronize()
+            print('ROWDOT', M, N, K, rep, hashlib.sha1(C.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha1(rd.cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
 

@@ -10,7 +10,7 @@ import re, sqlite3, sys
 
 CLS = {0: 'other', 1: '768', 2: '1280', 3: '1536', 4: '2304', 5: '3072', 6: '18432', 7: 'rows'}
 EPI = {0: '', 1: ' +bias+gelu (2 outputs)', 2: " *gelu'", 3: ' +=', 4: ' +rowdot', 5: ' +bias'}
-BASE = {'gemm3_kernel': 131072 + 2048}                                     # dynamic LDS of an untagged launch
+BASE = {'gemm3_kernel': 131072 + 2048 + 16384}                                     # dynamic LDS of an untagged launch
 
 
 def gemm_label(name, gss):
