@@ -289,6 +289,44 @@ __device__ __forceinline__ void epilogue_regs(const Gemm2Args& p, f32x4 (&acc)[T
 //   MODE 3: C = alpha acc + bias, and rowdot[column group of 64][row] = sum over the group of bf16(C) * aux_in: the delta = rowsum(dO * O) per
 //           head of the attention backward, taken where dO is made (the out-projection's input gradient) instead of by a pass over dO and O
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// Row staging of the asm-store epilogues (round 5, late): the MFMA registers leave a lane with 8 consecutive columns of ONE row, and the four lanes that
+// complete 64 bytes of that row are 16 lane numbers apart -- the memory pipeline merges ADJACENT lanes only, so such a store instruction is 64 separate
+// 16-byte writes and a tile's 128 KiB take a CU 5.3 us whatever the rest of the chip does (tools/probes/store_tile.hip; the same bytes with 8 adjacent
+// lanes per 128-byte row: 2.3 us). Each 16-row group therefore takes a trip through a wave-private 2 KiB LDS image [16 rows][128 B] (written as the
+// registers lie, 16-byte slot XOR row & 7; read back 8 lanes per row; no barrier: a wave's LDS operations execute in order) and leaves as two stores of
+// 8 rows x 128 contiguous bytes.
+constexpr int G3_STAGE_OFF = 131072 + 2048, G3_STAGE_BYTES = 8 * 2048;
+struct RowStage {
+    unsigned wr0, wr1, rd;          // LDS byte addresses: this lane's two chunks (columns cb .. +7 and 32 + cb .. +7 of row lr); its read slot (row lane >> 3, chunk lane & 7; + 1024: row + 8)
+    int row, chunk;                 // of the read side
+};
+__device__ __forceinline__ RowStage row_stage(unsigned lds_base /* of the kernel's dynamic LDS */, int wave, int lane) {
+    const int lr = lane & 15, lg = lane >> 4, q = ((lg & 1) << 1) | (lg >> 1);            // q = cb / 8: lg 0, 2, 1, 3 -> chunk 0, 1, 2, 3 of the 32-column half
+    const unsigned base = lds_base + (unsigned)(G3_STAGE_OFF + wave * 2048);
+    RowStage r;
+    r.wr0 = base + (unsigned)(lr * 128 + ((q ^ (lr & 7)) << 4));
+    r.wr1 = base + (unsigned)(lr * 128 + (((4 + q) ^ (lr & 7)) << 4));
+    r.row = lane >> 3; r.chunk = lane & 7;
+    r.rd = base + (unsigned)(r.row * 128 + ((r.chunk ^ r.row) << 4));
+    return r;
+}
+__device__ __forceinline__ void row_stage_put(const RowStage& r, u32x4 c0, u32x4 c1) {
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(r.wr0) = c0;
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(r.wr1) = c1;
+}
+__device__ __forceinline__ void row_stage_get(const RowStage& r, u32x4& lo, u32x4& hi) {     // rows 0 .. 7 / 8 .. 15 of the group
+    lo = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(r.rd);
+    hi = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(r.rd + 1024);
+}
+// the other direction, for an operand tile that was LOADED 8 rows x 128 bytes per instruction: in as it was loaded, out as the registers want it
+__device__ __forceinline__ void row_stage_put_rows(const RowStage& r, u32x4 lo, u32x4 hi) {
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(r.rd) = lo;
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(r.rd + 1024) = hi;
+}
+__device__ __forceinline__ void row_stage_get_chunks(const RowStage& r, u32x4& c0, u32x4& c1) {
+    c0 = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(r.wr0);
+    c1 = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(r.wr1);
+}
 constexpr int PFD = 6;                            // 8 would spill 2 VGPRs next to the column-sum accumulators (a scratch access is a vmcnt operation too)
 // address = wave-uniform 64-bit base in SGPRs + one 32-bit lane offset + an immediate: no 64-bit vector arithmetic per chunk
 template <int IMM> __device__ __forceinline__ void pf_load(u32x4& d, unsigned voff, const char* sbase, bool nt) {
@@ -307,74 +345,92 @@ __device__ __forceinline__ const char* sgpr_ptr(const void* q) {
     asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
     return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
-// operations issued after load `c` when chunk c is about to consume it: the schedule is  L0 .. L(PFD-1) | { wait c; S c; L (c + PFD) } for c = 0 .. 15
-// (MODE 3 adds one more store, the row sums of a 16-row group, behind the store of every odd chunk)
-constexpr int pf_younger(int c, int mode) {
+// Since the row staging both the operand tile and the result move 8 rows x 128 contiguous bytes per instruction (adjacent lanes: see row_stage above): a 16-row
+// group = two loads (rows 0 .. 7 | 8 .. 15) that go through the wave's LDS image INTO the register layout, and two stores that go through it OUT of it.
+// Schedule: L(0) .. L(2 PFG - 1) | for every group g: { wait for its two loads; compute; S(2g), S(2g + 1) (+ the row sums of MODE 3); L(2 (g + PFG)), L(.. + 1) }.
+constexpr int PFG = PFD / 2;                      // groups of loads in flight
+constexpr int pfg_younger(int g, int mode) {      // operations issued after the second load of group g when the group is about to consume them
+    const int S = 2 + (mode == 3 ? 1 : 0);
     int n = 0;
-    if (c < PFD) { n += PFD - 1 - c; for (int k = 0; k < c; ++k) n += 1 + (k + PFD < 16 ? 1 : 0) + ((mode == 3 && (k & 1)) ? 1 : 0); }
-    else for (int k = c - PFD + 1; k < c; ++k) n += 1 + (k + PFD < 16 ? 1 : 0) + ((mode == 3 && (k & 1)) ? 1 : 0);
+    if (g < PFG) { n += 2 * (PFG - 1 - g); for (int k = 0; k < g; ++k) n += S + (k + PFG < 8 ? 2 : 0); }
+    else for (int k = g - PFG + 1; k < g; ++k) n += S + (k + PFG < 8 ? 2 : 0);
     return n;
 }
-template <int N> __device__ __forceinline__ void pf_wait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void pf_wait2(u32x4& d0, u32x4& d1) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(d0), "+v"(d1) : "n"(N) : "memory"); }
+__device__ __forceinline__ f32x4 bf_lo4(const u32x4& w) { return f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)}; }
+__device__ __forceinline__ f32x4 bf_hi4(const u32x4& w) { return f32x4{__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u), __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xffff0000u)}; }
 template <int MODE, bool CS>
-__device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias, float* cs_row) {
+__device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias, float* cs_row, unsigned lds_base, int wave) {
     asm volatile("" : "+v"(lane));        // opaque: what the epilogue derives from the lane number is computed HERE, not hoisted in front of the K loop and kept in registers across it
     const int lr = lane & 15, lg = lane >> 4;
     const int cb = (lg & 1) ? 16 + (lg - 1) * 4 : lg * 4;
-    // chunk (i, jp) of the wave's 128 x 64 tile: rows i * 16 + lr, columns jp * 32 + cb .. + 7
+    const RowStage rs = row_stage(lds_base, wave, lane);
+    // memory side: lane = (row lane >> 3 of an 8-row half group, 16-byte chunk lane & 7 of the wave's 64 columns)
     const char* cbase = sgpr_ptr(reinterpret_cast<bf16_t*>(p.C) + coff + (long)mw * p.ldc + nw);
     const char* sbase = MODE != 2 ? sgpr_ptr(p.aux_in + (long)mw * p.ldaux + nw) : cbase;
-    const unsigned cvoff = (unsigned)(lr * (int)p.ldc + cb) * 2u, svoff = MODE != 2 ? (unsigned)(lr * (int)p.ldaux + cb) * 2u : cvoff;
-    const long sstep = 32 * (MODE != 2 ? p.ldaux : p.ldc), cstep = 32 * p.ldc;          // bytes per 16 rows
+    const unsigned cvoff = (unsigned)(rs.row * (int)p.ldc + rs.chunk * 8) * 2u, svoff = MODE != 2 ? (unsigned)(rs.row * (int)p.ldaux + rs.chunk * 8) * 2u : cvoff;
+    const long sstep = 16 * (MODE != 2 ? p.ldaux : p.ldc), cstep = 16 * p.ldc;          // bytes per 8 rows
     f32x4 bv[2][2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
         bv[jp][0] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
         bv[jp][1] = p.bias ? *reinterpret_cast<const f32x4*>(lds_bias + jp * 32 + cb + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                                   // the bias reads (LDS) are the only thing hipcc may wait for in here
     u32x4 pf[PFD];
-    float rd = 0.f;
     const char* rbase = MODE == 3 ? sgpr_ptr(p.rowdot + (long)(nw >> 6) * p.ld_rowdot + mw) : nullptr;      // + 16 rows = 64 bytes per row group
     const unsigned rvoff = (unsigned)lr * 4u;
-    static_for<0, PFD>([&](auto cc) { constexpr int c = decltype(cc)::value; pf_load<(c & 1) * 64>(pf[c], svoff, sbase + (c >> 1) * sstep, MODE != 2); });
+    static_for<0, PFD>([&](auto cc) { constexpr int c = decltype(cc)::value; pf_load<0>(pf[c], svoff, sbase + c * sstep, MODE != 2); });
     f32x4 cs[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
-    static_for<0, 16>([&](auto cc) {
-        constexpr int c = decltype(cc)::value, i = c >> 1, jp = c & 1;
-        f32x4 v0, v1;
+    static_for<0, 8>([&](auto gg) {
+        constexpr int g = decltype(gg)::value, s0 = (2 * g) % PFD, s1 = (2 * g + 1) % PFD;
+        pf_wait2<pfg_younger(g, MODE)>(pf[s0], pf[s1]);
+        row_stage_put_rows(rs, pf[s0], pf[s1]);
+        u32x4 w[2];
+        row_stage_get_chunks(rs, w[0], w[1]);
+        u32x4 out[2];
+        float rd = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float xa = acc[i][2 * jp][r], xb = acc[i][2 * jp + 1][r];
-            auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
-            v0[r] = __uint_as_float(sw[0]);
-            v1[r] = __uint_as_float(sw[1]);
-        }
-        v0 = v0 * p.alpha + bv[jp][0];
-        v1 = v1 * p.alpha + bv[jp][1];
-        pf_wait<pf_younger(c, MODE)>(pf[c % PFD]);
-        const u32x4 w = pf[c % PFD];
-        const f32x4 u0 = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
-        const f32x4 u1 = {__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u), __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xffff0000u)};
-        if constexpr (MODE == 1) { v0 *= u0; v1 *= u1; } else if constexpr (MODE == 2) { v0 += u0; v1 += u1; }
-        const bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
-        pf_store<jp * 64>(cvoff, cbase + i * cstep, __builtin_bit_cast(u32x4, r));
-        if constexpr (MODE == 3) {
-            // the products use the ROUNDED values, as a pass over the stored tensor would; a row's 64 columns lie in the two chunks of 4 lanes
-            float s8 = 0.f;
+        for (int jp = 0; jp < 2; ++jp) {
+            const f32x4 u0 = bf_lo4(w[jp]), u1 = bf_hi4(w[jp]);
+            f32x4 v0, v1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s8 = fmaf((float)r[e], u0[e], s8); s8 = fmaf((float)r[4 + e], u1[e], s8); }
-            if constexpr (jp == 0) rd = s8;
-            else {
-                float s = rd + s8;
-                auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-                s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-                auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-                s = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-                asm volatile("global_store_dword %0, %1, %2" :: "v"(rvoff), "v"(s), "s"(rbase + i * 64) : "memory");    // every lane of a row holds the sum: 4 lanes write the same word
+            for (int r = 0; r < 4; ++r) {
+                const float xa = acc[g][2 * jp][r], xb = acc[g][2 * jp + 1][r];
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+                v0[r] = __uint_as_float(sw[0]);
+                v1[r] = __uint_as_float(sw[1]);
             }
+            v0 = v0 * p.alpha + bv[jp][0];
+            v1 = v1 * p.alpha + bv[jp][1];
+            if constexpr (MODE == 1) { v0 *= u0; v1 *= u1; } else if constexpr (MODE == 2) { v0 += u0; v1 += u1; }
+            const bf16x8 r = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+            out[jp] = __builtin_bit_cast(u32x4, r);
+            if constexpr (MODE == 3) {
+                // the products use the ROUNDED values, as a pass over the stored tensor would; a row's 64 columns lie in the two chunks of 4 lanes
+                float s8 = 0.f;                                                  // (per chunk from zero, then added: the association of the per-chunk form, bit for bit)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s8 = fmaf((float)r[e], u0[e], s8); s8 = fmaf((float)r[4 + e], u1[e], s8); }
+                rd = jp == 0 ? s8 : rd + s8;
+            }
+            if constexpr (CS) { cs[jp][0] += v0; cs[jp][1] += v1; }
         }
-        if constexpr (c + PFD < 16) pf_load<((c + PFD) & 1) * 64>(pf[c % PFD], svoff, sbase + ((c + PFD) >> 1) * sstep, MODE != 2);
-        if constexpr (CS) { cs[jp][0] += v0; cs[jp][1] += v1; }
+        u32x4 lo, hi;
+        row_stage_put(rs, out[0], out[1]);
+        row_stage_get(rs, lo, hi);
+        pf_store<0>(cvoff, cbase + (2 * g) * cstep, lo);
+        pf_store<0>(cvoff, cbase + (2 * g + 1) * cstep, hi);
+        if constexpr (MODE == 3) {
+            float s = rd;
+            auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+            s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+            auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+            s = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+            asm volatile("global_store_dword %0, %1, %2" :: "v"(rvoff), "v"(s), "s"(rbase + g * 64) : "memory");    // every lane of a row holds the sum: 4 lanes write the same word
+        }
+        if constexpr (g + PFG < 8) {
+            pf_load<0>(pf[s0], svoff, sbase + (2 * (g + PFG)) * sstep, MODE != 2);
+            pf_load<0>(pf[s1], svoff, sbase + (2 * (g + PFG) + 1) * sstep, MODE != 2);
+        }
     });
     if constexpr (CS) {
 #pragma unroll
@@ -407,35 +463,6 @@ __device__ __forceinline__ void epilogue_pf(const Gemm2Args& p, f32x4 (&acc)[8][
 // operand (epilogue_regs: a 64-bit multiply-add per row and store). Exactly 32 stores per wave (the caller's `pend`).
 template <int IMM> __device__ __forceinline__ void pf_store_nt(unsigned voff, const char* sbase, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
-}
-// Row staging of the asm-store epilogues (round 5, late): the MFMA registers leave a lane with 8 consecutive columns of ONE row, and the four lanes that
-// complete 64 bytes of that row are 16 lane numbers apart -- the memory pipeline merges ADJACENT lanes only, so such a store instruction is 64 separate
-// 16-byte writes and a tile's 128 KiB take a CU 5.3 us whatever the rest of the chip does (tools/probes/store_tile.hip; the same bytes with 8 adjacent
-// lanes per 128-byte row: 2.3 us). Each 16-row group therefore takes a trip through a wave-private 2 KiB LDS image [16 rows][128 B] (written as the
-// registers lie, 16-byte slot XOR row & 7; read back 8 lanes per row; no barrier: a wave's LDS operations execute in order) and leaves as two stores of
-// 8 rows x 128 contiguous bytes.
-constexpr int G3_STAGE_OFF = 131072 + 2048, G3_STAGE_BYTES = 8 * 2048;
-struct RowStage {
-    unsigned wr0, wr1, rd;          // LDS byte addresses: this lane's two chunks (columns cb .. +7 and 32 + cb .. +7 of row lr); its read slot (row lane >> 3, chunk lane & 7; + 1024: row + 8)
-    int row, chunk;                 // of the read side
-};
-__device__ __forceinline__ RowStage row_stage(unsigned lds_base /* of the kernel's dynamic LDS */, int wave, int lane) {
-    const int lr = lane & 15, lg = lane >> 4, q = ((lg & 1) << 1) | (lg >> 1);            // q = cb / 8: lg 0, 2, 1, 3 -> chunk 0, 1, 2, 3 of the 32-column half
-    const unsigned base = lds_base + (unsigned)(G3_STAGE_OFF + wave * 2048);
-    RowStage r;
-    r.wr0 = base + (unsigned)(lr * 128 + ((q ^ (lr & 7)) << 4));
-    r.wr1 = base + (unsigned)(lr * 128 + (((4 + q) ^ (lr & 7)) << 4));
-    r.row = lane >> 3; r.chunk = lane & 7;
-    r.rd = base + (unsigned)(r.row * 128 + ((r.chunk ^ r.row) << 4));
-    return r;
-}
-__device__ __forceinline__ void row_stage_put(const RowStage& r, u32x4 c0, u32x4 c1) {
-    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(r.wr0) = c0;
-    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(r.wr1) = c1;
-}
-__device__ __forceinline__ void row_stage_get(const RowStage& r, u32x4& lo, u32x4& hi) {     // rows 0 .. 7 / 8 .. 15 of the group
-    lo = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(r.rd);
-    hi = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(r.rd + 1024);
 }
 __device__ __forceinline__ void epilogue_gelu(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, const float* lds_bias, unsigned lds_base, int wave) {
     asm volatile("" : "+v"(lane));
@@ -526,6 +553,30 @@ __device__ __forceinline__ void epilogue_plain(const Gemm2Args& p, f32x4 (&acc)[
         row_stage_get(rs, lo, hi);
         pf_store<0>(cvoff, cbase + i * cstep, lo);
         pf_store<0>(cvoff, cbase + i * cstep + 16 * p.ldc, hi);
+    });
+}
+
+// The same for an f32 C without bias or accumulation (the split-K slabs of the weight gradients): a row of the wave's 64 columns is 256 bytes, so a 16-row
+// group goes through the 2 KiB image one 32-column half at a time (a lane's f32x4 of column tile 2 jh is chunk lg, of tile 2 jh + 1 chunk 4 + lg) and
+// leaves as 8 rows x 128 contiguous bytes per store: 32 stores per wave, as before.
+__device__ __forceinline__ void epilogue_f32_plain(const Gemm2Args& p, f32x4 (&acc)[8][4], int mw, int nw, long coff, int lane, unsigned lds_base, int wave) {
+    asm volatile("" : "+v"(lane));
+    const int lr = lane & 15, lg = lane >> 4;
+    RowStage rs = row_stage(lds_base, wave, lane);
+    const unsigned base = lds_base + (unsigned)(G3_STAGE_OFF + wave * 2048);
+    rs.wr0 = base + (unsigned)(lr * 128 + ((lg ^ (lr & 7)) << 4));
+    rs.wr1 = base + (unsigned)(lr * 128 + (((4 + lg) ^ (lr & 7)) << 4));
+    const char* cbase = sgpr_ptr(reinterpret_cast<float*>(p.C) + coff + (long)mw * p.ldc + nw);
+    const unsigned cvoff = (unsigned)(rs.row * (int)p.ldc + rs.chunk * 4) * 4u;
+    const long cstep = 64 * p.ldc;                                                       // bytes per 16 rows
+    static_for<0, 16>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, i = c >> 1, jh = c & 1;
+        const f32x4 a0 = acc[i][2 * jh] * p.alpha, a1 = acc[i][2 * jh + 1] * p.alpha;
+        u32x4 lo, hi;
+        row_stage_put(rs, __builtin_bit_cast(u32x4, a0), __builtin_bit_cast(u32x4, a1));
+        row_stage_get(rs, lo, hi);
+        pf_store<jh * 128>(cvoff, cbase + i * cstep, lo);
+        pf_store<jh * 128>(cvoff, cbase + i * cstep + 32 * p.ldc, hi);                   // + 8 rows
     });
 }
 
@@ -1055,15 +1106,19 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
             if constexpr (A_KC && B_KC && TNW == 4) {
                 const int rmw = p.flags & (PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | PB_GEMM_ROWDOT);
                 const bool inner = em0 + 256 <= p.M && en0 + BNT <= p.N;
-                if (inner && rmw == PB_GEMM_MUL_GELU_GRAD && cs_row) { epilogue_pf<1, true>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row); epf = true; }
-                else if (inner && rmw == PB_GEMM_MUL_GELU_GRAD) { epilogue_pf<1, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
-                else if (inner && rmw == PB_GEMM_ACCUM && !cs_row) { epilogue_pf<2, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf = true; }
+                if (inner && rmw == PB_GEMM_MUL_GELU_GRAD && cs_row) { epilogue_pf<1, true>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row, lds0, wave); epf = true; }
+                else if (inner && rmw == PB_GEMM_MUL_GELU_GRAD) { epilogue_pf<1, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr, lds0, wave); epf = true; }
+                else if (inner && rmw == PB_GEMM_ACCUM && !cs_row) { epilogue_pf<2, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr, lds0, wave); epf = true; }
                 else if (inner && rmw == 0 && !cs_row && !(p.flags & 256)) { epilogue_plain(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, lds0, wave); }   // 16 stores (bit 8: the register path, for A/B runs)
                 else if (inner && rmw == PB_GEMM_GELU && p.aux_out) { epilogue_gelu(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, lds0, wave); }   // 32 stores: `pend` below counts them
-                else if (rmw == PB_GEMM_ROWDOT) { epilogue_pf<3, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr); epf3 = true; }   // the host admits whole tiles only
+                else if (rmw == PB_GEMM_ROWDOT) { epilogue_pf<3, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr, lds0, wave); epf3 = true; }   // the host admits whole tiles only
                 else epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
             } else {
-                epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
+                const bool inner = em0 + 256 <= p.M && en0 + BNT <= p.N;
+                if (TNW == 4 && inner && (p.flags & (PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | PB_GEMM_ROWDOT | 256)) == PB_GEMM_C_F32 && !p.bias && !cs_row)
+                    epilogue_f32_plain(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, lds0, wave);        // split-K slabs: 32 stores (`pend`)
+                else
+                    epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
             }
         }
         G3_STAMP(4);                                                 // [4] epilogue: arithmetic + store (and load) issue
