@@ -117,13 +117,14 @@ int opt_grid(long n4) { return (int)std::max(1L, std::min((long)OPT_BLOCKS, (n4 
 // Batched bf16 transpose inside one flat buffer: table entry e = {element offset, R, C, first tile}; matrix e (R x C, row-major at
 // src + offset) is written C x R at dst + offset. One workgroup per 64 x 64 tile, through LDS. Dimensions multiples of 8.
 __global__ __launch_bounds__(256) void transpose_batch_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int4* __restrict__ table, int n) {
-    __shared__ short tile[64][66];
+    __shared__ __attribute__((aligned(16))) short tile[64][72];        // 144-byte rows: 16-byte aligned pieces, and a column walk (stride 36 words) spreads over the banks
     __shared__ int4 ent;
     const int t = threadIdx.x, b = blockIdx.x;
-    if (t == 0) {
-        int e = 0;
-        while (e + 1 < n && table[e + 1].w <= b) ++e;
-        ent = table[e];
+    // which matrix owns tile b: every thread tests one table entry (a walk of the table by one thread was ~85 dependent loads per workgroup: 16 us of the
+    // workgroup's life, the whole kernel's 200 us)
+    for (int e = t; e < n; e += 256) {
+        const int4 cur = table[e];
+        if (cur.w <= b && (e + 1 == n || table[e + 1].w > b)) ent = cur;
     }
     __syncthreads();
     const long off = ent.x;
@@ -131,33 +132,30 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const bf16_t* __re
     const int r0 = (lt / tc) * 64, c0 = (lt % tc) * 64;
     const short* S = reinterpret_cast<const short*>(src) + off;
     short* D = reinterpret_cast<short*>(dst) + off;
+    // a row of the tile is 128 bytes = the 16-byte pieces of 8 ADJACENT lanes (the memory pipeline merges adjacent lanes only: 16-byte pieces 32 bytes
+    // apart, as in the first form of this kernel, are separate requests), 32 rows per instruction, two instructions per side
     {
-        const int r = t >> 2, c = (t & 3) * 16;
-        if (r0 + r < R) {
+        const int r = t >> 3, c = (t & 7) * 8;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (c0 + c + 8 * h < C) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(S + (long)(r0 + r) * C + c0 + c + 8 * h);
-                    const short* e = reinterpret_cast<const short*>(&v);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) tile[r][c + 8 * h + j] = e[j];
-                }
+        for (int h = 0; h < 2; ++h) {
+            const int rr = r + 32 * h;
+            if (r0 + rr < R && c0 + c < C) {
+                *reinterpret_cast<uint4*>(&tile[rr][c]) = *reinterpret_cast<const uint4*>(S + (long)(r0 + rr) * C + c0 + c);
             }
         }
     }
     __syncthreads();
     {
-        const int orow = t >> 2, oc = (t & 3) * 16;              // output row = source column
-        if (c0 + orow < C) {
+        const int orow = t >> 3, oc = (t & 7) * 8;               // output row = source column
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (r0 + oc + 8 * h < R) {
-                    uint4 v;
-                    short* e = reinterpret_cast<short*>(&v);
+        for (int h = 0; h < 2; ++h) {
+            const int oo = orow + 32 * h;
+            if (c0 + oo < C && r0 + oc < R) {
+                uint4 v;
+                short* e = reinterpret_cast<short*>(&v);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) e[j] = tile[oc + 8 * h + j][orow];
-                    *reinterpret_cast<uint4*>(D + (long)(c0 + orow) * R + r0 + oc + 8 * h) = v;
-                }
+                for (int j = 0; j < 8; ++j) e[j] = tile[oc + j][oo];
+                *reinterpret_cast<uint4*>(D + (long)(c0 + oo) * R + r0 + oc) = v;
             }
         }
     }
