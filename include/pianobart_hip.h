@@ -37,6 +37,8 @@ const char* pb_last_error(void);
 #define PB_GEMM_TILE128 32       /* bf16 fast path: force the 128x128 tile             */
 #define PB_GEMM_TILE256 64       /* bf16 fast path: prefer the 256x256 tile (default when M >= 2048, N >= 512, no split-K) */
 #define PB_GEMM_NO_EPILOGUE 128  /* profiling: main loop only, nothing is stored                                    */
+#define PB_GEMM_REG_EPILOGUE 256 /* A/B runs: interior tiles of the 256x256 kernel store straight from the MFMA register layout (64-byte row pieces on
+                                    lanes 16 apart) instead of through the row staging (8 rows x 128 contiguous bytes per instruction)            */
 #define PB_GEMM_ONE_BARRIER 2048 /* A/B runs: 256x256 tile with the one-barrier kernel instead of the ping-pong one   */
 #define PB_GEMM_PLAIN_GRID 4096  /* 256x256 ping-pong kernel as an ordinary grid (one workgroup per work item) instead of the
                                     persistent one-per-CU grid: what to ask for when other kernels (RCCL) hold CUs        */

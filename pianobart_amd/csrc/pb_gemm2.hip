@@ -1109,13 +1109,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
                 if (inner && rmw == PB_GEMM_MUL_GELU_GRAD && cs_row) { epilogue_pf<1, true>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row, lds0, wave); epf = true; }
                 else if (inner && rmw == PB_GEMM_MUL_GELU_GRAD) { epilogue_pf<1, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr, lds0, wave); epf = true; }
                 else if (inner && rmw == PB_GEMM_ACCUM && !cs_row) { epilogue_pf<2, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr, lds0, wave); epf = true; }
-                else if (inner && rmw == 0 && !cs_row && !(p.flags & 256)) { epilogue_plain(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, lds0, wave); }   // 16 stores (bit 8: the register path, for A/B runs)
+                else if (inner && rmw == 0 && !cs_row && !(p.flags & PB_GEMM_REG_EPILOGUE)) { epilogue_plain(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, lds0, wave); }   // 16 stores (PB_GEMM_REG_EPILOGUE: the register path, for A/B runs)
                 else if (inner && rmw == PB_GEMM_GELU && p.aux_out) { epilogue_gelu(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, lds0, wave); }   // 32 stores: `pend` below counts them
                 else if (rmw == PB_GEMM_ROWDOT) { epilogue_pf<3, false>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, nullptr, lds0, wave); epf3 = true; }   // the host admits whole tiles only
                 else epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
             } else {
                 const bool inner = em0 + 256 <= p.M && en0 + BNT <= p.N;
-                if (TNW == 4 && inner && (p.flags & (PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | PB_GEMM_ROWDOT | 256)) == PB_GEMM_C_F32 && !p.bias && !cs_row)
+                if (TNW == 4 && inner && (p.flags & (PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD | PB_GEMM_ROWDOT | PB_GEMM_REG_EPILOGUE)) == PB_GEMM_C_F32 && !p.bias && !cs_row)
                     epilogue_f32_plain(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, lds0, wave);        // split-K slabs: 32 stores (`pend`)
                 else
                     epilogue_regs<8, TNW>(p, acc, em0 + wr * 128, en0 + wc * GSB, ecoff, lane, ebias, cs_row);
@@ -1272,7 +1272,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | 256 | 2048 | 4096 | 8192 | 16384 | 32768)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | PB_GEMM_REG_EPILOGUE | 2048 | 4096 | 8192 | 16384 | 32768)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue other than accumulate");
         return -2;
     }
