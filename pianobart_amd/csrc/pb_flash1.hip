@@ -208,7 +208,30 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(DO), 0, (int)(((long)(p.Sq - 1) * p.o_ss + HDT) * 2), 0x00020000);
     // the slab rows of this (sequence, head): rows beyond the sequence fall outside the descriptor and are dropped by the hardware
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(((long)(p.Sq - 1) * d_model + HDT) * 2), 0x00020000);
-    const unsigned slab_vo = (unsigned)((((wave & 1) * 16 + lr) * d_model + (wave >> 1) * 32 + g * 4) * 2);
+    // dQ slab stores (round 5, late): a wave's dQ^T piece of a step is 16 query rows x 32 columns, and the MFMA layout leaves a row's 8-byte pieces on lanes 16
+    // apart -- two store instructions of 64 separate 8-byte writes each (the memory pipeline merges adjacent lanes only; without the stores the whole backward
+    // measured 7 % shorter). The piece goes through a 1 KiB LDS image of the wave (in the K images, dead since the K^T fragments were read: [16 rows][64 B],
+    // 16-byte slot XOR (row >> 1) & 3) and leaves as ONE store of 16 bytes per lane, 4 adjacent lanes per 64-byte row; the read-back is waited for by the
+    // lgkmcnt(0) every step ends with (sync), and the store is issued behind it.
+    const unsigned stg = lds_u32(smem) + OFF_K + (unsigned)(wave * 1024);
+    const unsigned stg_wa = stg + (unsigned)(lr * 64 + ((((g >> 1) ^ ((lr >> 1) & 3)) << 4) | ((g & 1) << 3)));            // columns 4 g .. of tile A; tile B: 16-byte slots 2, 3
+    const unsigned stg_wb = stg + (unsigned)(lr * 64 + (((2 + (g >> 1)) ^ ((lr >> 1) & 3)) << 4 | ((g & 1) << 3)));
+    const int srow = lane >> 2, schunk = lane & 3;
+    const unsigned stg_rd = stg + (unsigned)(srow * 64 + ((schunk ^ ((srow >> 1) & 3)) << 4));
+    const unsigned slab_vo = (unsigned)((((wave & 1) * 16 + srow) * d_model + (wave >> 1) * 32 + schunk * 8) * 2);
+    u32x4 slab_v = {0u, 0u, 0u, 0u};
+    int slab_qs = 0;
+    bool slab_pending = false;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    auto slab_put = [&](const f32x4& a, const f32x4& b_, int qs) {          // the two pieces in, the row-major 16 bytes requested
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2_t*>(stg_wa) = __builtin_bit_cast(u32x2_t, to_bf4(a));
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2_t*>(stg_wb) = __builtin_bit_cast(u32x2_t, to_bf4(b_));
+        ds_rd128<0>(slab_v, stg_rd);
+        slab_qs = qs; slab_pending = true;
+    };
+    auto slab_flush = [&]() {                                               // behind a wait that names slab_v
+        if (slab_pending) { __builtin_amdgcn_raw_buffer_store_b128(slab_v, rsS, slab_vo, slab_qs, 0); slab_pending = false; }
+    };
     const unsigned voQ0 = so_q.off[0] * 2, voQ1 = so_q.off[1] * 2, voO0 = so_o.off[0] * 2, voO1 = so_o.off[1] * 2;
     typedef __attribute__((address_space(3))) void* lds_t;
 #pragma unroll
@@ -489,8 +512,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
             asm volatile("s_nop 15" : "+v"(dqa0), "+v"(dqb0), "+v"(dqa1), "+v"(dqb1));
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             const int qs = (HALF ? T * 64 : T * 64 - 32) * d_model * 2;    // first row of the previous step, in bytes
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, to_bf4((dqa0 + dqa1) * p.scale)), rsS, slab_vo, qs, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, to_bf4((dqb0 + dqb1) * p.scale)), rsS, slab_vo + 32, qs, 0);
+            slab_put((dqa0 + dqa1) * p.scale, (dqb0 + dqb1) * p.scale, qs);
         }
         STAMP(7);                                                          // hand-over, dQ stores
 #ifdef PB_FA1_STAMPS
@@ -499,7 +521,8 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     };
     auto sync = [&]() {
         // this wave's dS stores and the transposed reads for the next step have landed; behind the barrier every wave's have
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(to[0][0]), "+v"(to[0][1]), "+v"(to[1][0]), "+v"(to[1][1]), "+v"(tq[0][0]), "+v"(tq[0][1]), "+v"(tq[1][0]), "+v"(tq[1][1]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(to[0][0]), "+v"(to[0][1]), "+v"(to[1][0]), "+v"(to[1][1]), "+v"(tq[0][0]), "+v"(tq[0][1]), "+v"(tq[1][0]), "+v"(tq[1][1]), "+v"(slab_v) :: "memory");
+        slab_flush();
         STAMP(8);                                                          // DMA wait + LDS wait in front of the barrier
         __builtin_amdgcn_s_barrier();
         STAMP(9);                                                          // barrier
@@ -576,8 +599,9 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
         asm volatile("s_nop 15" : "+v"(dqa), "+v"(dqb));
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
         const int qs = (T * 64 + 32) * d_model * 2;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, to_bf4(dqa * p.scale)), rsS, slab_vo, qs, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, to_bf4(dqb * p.scale)), rsS, slab_vo + 32, qs, 0);
+        slab_put(dqa * p.scale, dqb * p.scale, qs);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slab_v) :: "memory");
+        slab_flush();
     }
 
     // ---- epilogue: dK (x scale), dV rows of this block; masked keys receive zeros; column sums = k / v bias-gradient partials
