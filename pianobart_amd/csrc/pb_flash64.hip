@@ -216,6 +216,36 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args pin) {
         __builtin_amdgcn_s_barrier();
         sidx = sidx == C::NS - 1 ? 0 : sidx + 1;
     }
+    if constexpr (HD == 64) {
+        // O leaves through LDS (round 5, late): the accumulator layout gives a lane 4 columns (8 bytes) of one row with the row's pieces on lanes 16 apart --
+        // 8 store instructions of 64 separate 8-byte writes per wave, 5 - 7 % of the kernel (a build without them: 166 -> 156 us dense; the memory pipeline
+        // merges adjacent lanes only). The wave's 32 x 64 tile goes into a 4 KiB image of the stage ring (free behind the loop's last barrier; 16-byte slot
+        // XOR row & 7) and out as 4 stores of 8 rows x 128 contiguous bytes, 8 adjacent lanes per row.
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const unsigned obase = lds_u32(smem) + (unsigned)(wave * 4096);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float lq = lacc[qt][0];
+            const float inv = lq > 0.f ? 1.0f / lq : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x4 r = {(bf16_t)(oacc[qt][dt][0] * inv), (bf16_t)(oacc[qt][dt][1] * inv), (bf16_t)(oacc[qt][dt][2] * inv), (bf16_t)(oacc[qt][dt][3] * inv)};
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(obase + (unsigned)(qt * 2048 + lr * 128 + ((((dt * 2 + (g >> 1)) ^ (lr & 7)) << 4) | ((g & 1) << 3)))) =
+                    __builtin_bit_cast(u32x2, r);
+            }
+            if (myq[qt] < p.Sq && g == 0) p.lse[((long)b * p.H + h) * lse_ld + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;   // m = the reference l was summed against
+        }
+        const int orow = lane >> 3, ochunk = lane & 7;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int r = hh * 8 + orow, q = q0 + wave * 32 + qt * 16 + r;
+                const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(obase + (unsigned)(qt * 2048 + r * 128 + ((ochunk ^ (r & 7)) << 4)));
+                if (q < p.Sq) *reinterpret_cast<u32x4*>(p.out + b * p.o_sb + (long)q * p.o_ss + h * HDT + ochunk * 8) = v;
+            }
+    } else {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         if (myq[qt] < p.Sq) {
@@ -229,6 +259,7 @@ __global__ __launch_bounds__(FT) void fa64_fwd_kernel(const Fa64Args pin) {
             }
             if (g == 0) p.lse[((long)b * p.H + h) * lse_ld + myq[qt]] = lq > 0.f ? (m[qt] + log2f(lq)) / LOG2E : INFINITY;   // m = the reference l was summed against
         }
+    }
     }
 }
 
