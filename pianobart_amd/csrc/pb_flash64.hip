@@ -448,6 +448,43 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args pin) {
     f32x4 csk[DT], csv[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { csk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; csv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if constexpr (HD == 64) {
+        // dK / dV rows leave through LDS images like the forward's O (8 rows x 128 contiguous bytes per store instead of 8-byte pieces on lanes 16 apart);
+        // the images lie behind the 4 KiB the column-sum reduction below uses
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const unsigned obase = lds_u32(smem) + 4096u + (unsigned)(wave * (KT * 4096));
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int key = k0 + wave * (16 * KT) + kt * 16 + lr;
+            const bool kvis = pin.vl_q_off ? key < (p.kmax ? p.kmax[b] : p.Sk)
+                                           : (!p.key_mask || p.key_mask[(long)b * p.Sk + (key < p.Sk ? key : 0)] != 0.f);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x4 vk = dk[kt][dt] * p.scale, vv = dv[kt][dt];
+                if (!kvis) { vk = f32x4{0.f, 0.f, 0.f, 0.f}; vv = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                const bf16x4 rk = {(bf16_t)vk[0], (bf16_t)vk[1], (bf16_t)vk[2], (bf16_t)vk[3]}, rv = {(bf16_t)vv[0], (bf16_t)vv[1], (bf16_t)vv[2], (bf16_t)vv[3]};
+                const unsigned slot = (unsigned)(lr * 128 + ((((dt * 2 + (g >> 1)) ^ (lr & 7)) << 4) | ((g & 1) << 3)));
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(obase + (unsigned)(kt * 4096) + slot) = __builtin_bit_cast(u32x2, rk);
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(obase + (unsigned)(kt * 4096 + 2048) + slot) = __builtin_bit_cast(u32x2, rv);
+                if (key < p.Sk) { csk[dt] += vk; csv[dt] += vv; }
+            }
+        }
+        const int orow = lane >> 3, ochunk = lane & 7;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int r = hh * 8 + orow, key = k0 + wave * (16 * KT) + kt * 16 + r;
+                const unsigned slot = (unsigned)(r * 128 + ((ochunk ^ (r & 7)) << 4));
+                const u32x4 vk = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(obase + (unsigned)(kt * 4096) + slot);
+                const u32x4 vv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(obase + (unsigned)(kt * 4096 + 2048) + slot);
+                if (key < p.Sk) {
+                    *reinterpret_cast<u32x4*>(p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HDT + ochunk * 8) = vk;
+                    *reinterpret_cast<u32x4*>(p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HDT + ochunk * 8) = vv;
+                }
+            }
+    } else {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
         const int key = k0 + wave * (16 * KT) + kt * 16 + lr;
@@ -466,6 +503,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dkv_kernel(const Fa64Args pin) {
                 csk[dt] += vk; csv[dt] += vv;
             }
         }
+    }
     }
     if (p.cs_kv) {      // bias gradients: column sums of the block's dK / dV rows -> partial row (b, key block), head h's columns
         const int nkb = (pin.Sk + BK_ - 1) / BK_, d_model = p.H * HDT;
@@ -653,6 +691,31 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args pin) {
     f32x4 csq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) csq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (HD == 64) {
+        // dQ rows through LDS images, as the forward's O
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const unsigned obase = lds_u32(smem) + 4096u + (unsigned)(wave * 4096);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const f32x4 v = dq[qt][dt] * p.scale;
+                const bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(obase + (unsigned)(qt * 2048 + lr * 128 + ((((dt * 2 + (g >> 1)) ^ (lr & 7)) << 4) | ((g & 1) << 3)))) =
+                    __builtin_bit_cast(u32x2, r);
+                if (myq[qt] < p.Sq) csq[dt] += v;
+            }
+        const int orow = lane >> 3, ochunk = lane & 7;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int r = hh * 8 + orow, q = q0 + wave * 32 + qt * 16 + r;
+                const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(obase + (unsigned)(qt * 2048 + r * 128 + ((ochunk ^ (r & 7)) << 4)));
+                if (q < p.Sq) *reinterpret_cast<u32x4*>(p.dq + b * p.dq_sb + (long)q * p.dq_ss + h * HDT + ochunk * 8) = v;
+            }
+    } else {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
         if (myq[qt] < p.Sq) {
@@ -665,6 +728,7 @@ __global__ __launch_bounds__(FT) void fa64_bwd_dq_kernel(const Fa64Args pin) {
                 csq[dt] += v;
             }
         }
+    }
     if (p.cs_q) {       // bias gradient of the q projection: the 16 lanes of a DPP row hold 16 queries of the same 4 columns
         const int nqb = (pin.Sq + 127) / 128, d_model = p.H * HDT;
         float* red = reinterpret_cast<float*>(smem);                      // [4 waves][HDT]
