@@ -761,7 +761,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < TNW; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (KSPLIT) asm volatile("" : "+v"(acc[i][j])); }   // opaque: no peeled first K-tile with C = 0
+        for (int j = 0; j < TNW; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (KS_TN) asm volatile("" : "+v"(acc[i][j])); }   // TN: opaque (no second copy of the pinned-register loop); NT: the first K-tile's MFMAs take C = 0 and the 128 v_mov go away
     bf16x8 a[4][2], b[2][2];
     s16x4 ta[4][2][2], tb[2][2][2];                                   // asm destinations of the transposed reads
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const Gemm2Args p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < TNW; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (KSPLIT) asm volatile("" : "+v"(acc[i][j])); }   // opaque: no peeled first K-tile with C = 0
+            for (int j = 0; j < TNW; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (KS_TN) asm volatile("" : "+v"(acc[i][j])); }   // TN: opaque (no second copy of the pinned-register loop); NT: the first K-tile's MFMAs take C = 0 and the 128 v_mov go away
     }
 #ifdef PB_G3_STAMPS
     if (p.stamps) {
