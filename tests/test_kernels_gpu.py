@@ -605,6 +605,39 @@ def test_gemm_rowdot_epilogue(ops, M, N, K, bias):
         ops.gemm(A[:M - 8], B, C[:M - 8], M=M - 8, N=N, K=K, dtype=ops.PB_BF16, rowdot=(aux, out, ld))
 
 
+@pytest.mark.parametrize('M,N,K', [(1024, 768, 256), (2048 + 136, 512 + 64, 192), (4096, 3072, 768)])
+def test_gemm_row_staged_epilogues_store_the_register_path_bits(ops, M, N, K):
+    """The 256 x 256 kernel's interior tiles store through the row staging (8 rows x 128 contiguous bytes per instruction, through a wave-private
+    LDS image); PB_GEMM_REG_EPILOGUE (256) is the path straight from the MFMA register layout. Same bits, for the store-only epilogue, the f32
+    split-K slabs of the weight-gradient layout and -- against edge tiles, which always take the register path -- a ragged problem; the GELU pair,
+    the read-modify-write epilogues and the row sums (no register twin left) are pinned by their own tests above and by tools/gemm_race_screen.py."""
+    g = torch.Generator(device='cuda').manual_seed(M * 7 + N)
+    rn = lambda *s_: torch.randn(*s_, device='cuda', generator=g).to(torch.bfloat16)
+    A, B = rn(M, K), rn(N, K)
+    bias = torch.randn(N, device='cuda', generator=g)
+    out = []
+    for dbg in (0, 256):
+        C = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+        ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, bias=bias, tile256=True, dbg=dbg)
+        assert torch.isfinite(C).all()
+        out.append(C)
+    assert torch.equal(out[0], out[1])
+    ref = A.double() @ B.double().t() + bias.double()
+    assert float((out[0].double() - ref).abs().max() / ref.abs().max()) < 6e-3
+    # weight-gradient layout: G (Mw x Nw) = dY^T X over T rows, split-K into f32 slabs
+    T, Mw, Nw, ns = 4096, 768, 512, 4
+    dy, x = rn(T, Mw), rn(T, Nw)
+    slabs = torch.empty(ns * Mw * Nw, device='cuda')
+    res = []
+    for dbg in (0, 256):
+        G = torch.zeros(Mw, Nw, device='cuda')
+        ops.gemm(dy, x, G, M=Mw, N=Nw, K=T, dtype=ops.PB_BF16, a_kc=False, b_kc=False, lda=Mw, ldb=Nw, ldc=Nw, c_f32=True, splitk=ns, slabs=slabs, tile256=True, dbg=dbg)
+        res.append(G)
+    assert torch.equal(res[0], res[1])
+    refg = dy.double().t() @ x.double()
+    assert float((res[0].double() - refg).abs().max() / refg.abs().max()) < 2e-3
+
+
 def test_one_pass_backward_takes_delta_rows(ops):
     """pb_flash_bwd1 with delta_rows = [H][B * S] row sums made elsewhere (the GEMM epilogue) gives the gradients of the call that computes
     delta itself, bit for bit when the table holds the same numbers."""
