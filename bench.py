@@ -460,15 +460,34 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _kfd_gpu_count():
+    """GPUs of this node without a HIP call: KFD topology nodes with SIMDs (CPU nodes have simd_count 0), cut down to the
+    ROCR_ / HIP_VISIBLE_DEVICES list when one is set; torch's count if the topology cannot be read."""
+    try:
+        base, n = '/sys/class/kfd/kfd/topology/nodes', 0
+        for node in os.listdir(base):
+            props = dict(l.split(None, 1) for l in open(os.path.join(base, node, 'properties')).read().splitlines() if ' ' in l)
+            n += int(props.get('simd_count', '0')) > 0
+        for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+            if os.environ.get(var, '').strip():
+                n = min(n, len([v for v in os.environ[var].split(',') if v.strip()]))
+        return n
+    except (OSError, ValueError):
+        return torch.cuda.device_count()
+
+
 def launch_ranks(n, argv, device_count=None, run=None, out=None):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: this process becomes a LAUNCHER. It never imports
-    pianobart_amd and never initialises the GPU (torch.cuda.device_count() only counts); it starts
+    pianobart_amd; it counts the devices from /sys/class/kfd (no HIP call -- torch.cuda.device_count() may bring the HIP runtime up when
+    amdsmi is unavailable, ADVICE r5, so it is only the fallback) and in any case STARTS A CHILD and never replaces itself: do not turn
+    the child start into an os.exec* on the strength of "the launcher has not touched the GPU". It starts
         python -m torch.distributed.run --nnodes 1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>
     as a CHILD process (one rank per GPU over RCCL, the reference's nn.DataParallel replaced: pretrain.py:63-65), relays rank 0's ONE
-    JSON line to stdout and returns the child's exit code. A box with fewer than N GPUs is refused loudly: the line must never
-    say n_gpus 1 for a --gpus N request. `device_count`, `run` and `out` are injection points for the CPU test of this logic."""
+    JSON line to stdout and returns the child's exit code -- the line is NOT relayed when the child failed (a consumer that reads stdout
+    without looking at the exit code must not see a line from a failed job). A box with fewer than N GPUs is refused loudly: the line
+    must never say n_gpus 1 for a --gpus N request. `device_count`, `run` and `out` are injection points for the CPU test of this logic."""
     import subprocess
-    have = torch.cuda.device_count() if device_count is None else device_count
+    have = (_kfd_gpu_count() if device_count is None else device_count)
     if have < n:
         sys.stderr.write('bench.py: --gpus %d requested but this node shows %d GPU(s): refusing to run (no silent fallback to fewer ranks)\n' % (n, have))
         return 2
@@ -486,6 +505,9 @@ def launch_ranks(n, argv, device_count=None, run=None, out=None):
         if rec is not None and r.returncode == 0 and rec.get('n_gpus') != n:
             sys.stderr.write('bench.py: the ranks reported n_gpus %r for --gpus %d\n' % (rec.get('n_gpus'), n))
             return 3
+        if r.returncode != 0:
+            sys.stderr.write('bench.py: the ranks exited %d: their JSON line is withheld\n' % r.returncode)
+            return r.returncode
         out.write(lines[-1] + '\n'); out.flush()
     elif r.returncode == 0:
         sys.stderr.write('bench.py: the %d ranks exited 0 without a JSON line\n' % n)

@@ -324,6 +324,13 @@ extern "C" int pb_gemm(const pb_gemm_desc* d, void* stream_) {
         if (r2 == 0) return 0;
         if (r2 == 2) return colsum_of_c(d, stream_);
     }
+    // The generic kernel below has no row-dot epilogue: a caller that asked for one must not get a C without it (its rowdot_out would
+    // stay uninitialised and feed the attention backward). Refused here for EVERY way of reaching this point: PB_GEMM_FORCE_V1, f32
+    // operands, K no multiple of 64, a misaligned operand (pb_gemm2_try declines those before it looks at the flag).
+    if (d->flags & PB_GEMM_ROWDOT) {
+        pb_set_error("pb_gemm: PB_GEMM_ROWDOT is only served by the bf16 NT 256x256 kernel (not with PB_GEMM_FORCE_V1, f32, K %% 64 != 0 or operands off 16 bytes)");
+        return -2;
+    }
     const int esz = d->dtype == PB_BF16 ? 2 : 4, epv = 16 / esz;
     GemmArgs a;
     a.A = d->A; a.B = d->B; a.C = d->C; a.bias = d->bias; a.aux_in = d->aux_in; a.aux_out = d->aux_out;

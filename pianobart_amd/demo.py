@@ -11,7 +11,7 @@ import os
 import torch
 
 from ._lib import PBError
-from .model import BartConfig, PianoBart, PianoBartLM
+from .model import BartConfig, PianoBart, PianoBartLM, checkpoint_state_dict
 from .octuple_midi import Midi2Octuple, Octuple2Midi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -66,7 +66,8 @@ def demo(args=None):
     model = PianoBartLM(pianobart)
     if not args.nopretrain:
         print("   Loading pre-trained model from", args.ckpt.split('/')[-1])
-        model.load_state_dict(torch.load(args.ckpt, map_location='cpu', weights_only=False)['state_dict'], strict=False)
+        sd = torch.load(args.ckpt, map_location='cpu', weights_only=False)['state_dict']
+        model.load_state_dict(checkpoint_state_dict(sd, model), strict=False)       # 'module.'-prefixed multi-GPU files load too
     octuple = Midi2Octuple(args.input, window=args.max_seq_len)
     device_num = args.cuda_devices[0] if args.cuda_devices else 0
     device = torch.device('cuda', device_num)

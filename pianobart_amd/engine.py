@@ -1058,21 +1058,29 @@ class Engine:
         f = lambda m: None if m is None else m.to(dtype=torch.float32).contiguous()
         return enc16, dec16, f(emask), f(dmask)
 
-    def note_ids(self, ids16):
+    def note_ids(self, ids16, owned=True):
         """Enqueue the range check of (..., 8) Octuple ids (PianoBart.py:15-16: nn.Embedding raises IndexError on an id outside its
-        table); the verdict is read by check_ids() at a point where the host waits for the device anyway. NOTE: the kernel rewrites an
-        offending id to 0 IN PLACE (int16 inputs are not copied), so that the gathers queued behind it stay inside their tables; a batch
-        that trips the check is followed by IndexError, so the rewritten tensor is never a silently different input."""
+        table); the verdict is read by check_ids() at a point where the host waits for the device anyway. The kernel rewrites an
+        offending id to 0 so that the gathers queued behind it stay inside their tables -- in a tensor the ENGINE owns: `owned=False`
+        (a caller's int16 tensor) is checked on a private copy, which is returned and must be the one the step reads; the caller's
+        tensor is never written."""
+        if not owned:
+            ids16 = ids16.clone()
         if getattr(self, '_id_flag', None) is None or self._id_flag.device != ids16.device:
             self._id_flag = torch.zeros(1, dtype=torch.int32, device=ids16.device)
             self._id_lim = torch.tensor(ops.SEG_SIZES, dtype=torch.int32, device=ids16.device)
         ops.ids_check(ids16, self._id_lim, self._id_flag)
+        return ids16
 
-    def check_ids(self):
-        """Synchronises. Raises IndexError if a checked batch held an id outside its embedding table -- on EVERY rank of a torchrun job when any
-        rank's batch did (the flag is max-reduced first: a rank that raised alone would leave the others waiting in the next gradient exchange)."""
+    def check_ids(self, collective=True):
+        """Synchronises. Raises IndexError if a checked batch held an id outside its embedding table. collective=True (the module route's
+        TRAINING forward, which every rank of a torchrun job runs in step): the flag is max-reduced first, so the error is raised on EVERY rank
+        when any rank's batch tripped it (a rank that raised alone would leave the others waiting in the next gradient exchange).
+        collective=False (`generate` and the eval forwards: calls that a rank may make by itself -- rank-0 validation, a demo): local verdict
+        only, no exchange that the other ranks would have to join. The fused step does not come through here: its verdict is
+        local (`_raise_if_bad_ids`) and the trainers validate the loader's host batch on every rank before the copy."""
         self._id_verdicts = []
-        if getattr(self, '_id_flag', None) is not None and self.grad_hook is not None:
+        if collective and getattr(self, '_id_flag', None) is not None and self.grad_hook is not None:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 dist.all_reduce(self._id_flag, op=dist.ReduceOp.MAX)
@@ -1121,7 +1129,7 @@ class Engine:
         self.bind(enc_ids.device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
         out = _LMFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, *self.params)
-        self.check_ids()                                                 # nn.Embedding's IndexError (the module route hands tensors to host code next anyway)
+        self.check_ids(collective=bool(training))                        # nn.Embedding's IndexError (the module route hands tensors to host code next anyway)
         return out
 
     def module_forward_hidden(self, enc_ids, dec_ids, emask, dmask, training, dec_embeds=None):
@@ -1131,7 +1139,7 @@ class Engine:
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
         n_backbone = len(self.params) - (16 if self.mlm is not None else 0)
         out = _HiddenFn.apply(self, enc_ids, dec_ids, emask, dmask, training, need_grad, dec_embeds, *self.params[:n_backbone])
-        self.check_ids()
+        self.check_ids(collective=bool(training))
         return out
 
     # ------------------------------------------------------------------ fused pre-train step (bench / Pretrainer)
@@ -1147,8 +1155,8 @@ class Engine:
         T = B * S
         self._raise_if_bad_ids()
         if not ids_checked:
-            self.note_ids(enc16)
-            self.note_ids(dec16)
+            enc16 = self.note_ids(enc16, owned=False)
+            dec16 = self.note_ids(dec16, owned=False)
             self._queue_id_verdict()
         seed = self._next_seed()
         self._select_grads(False)
@@ -1273,7 +1281,7 @@ class Engine:
         result = pad.repeat(1, S, 1)
         em = emask.to(torch.float32).contiguous() if emask is not None else None
         enc16 = ops.ids_to_i16(enc_ids)
-        self.note_ids(enc16); self.check_ids()
+        self.note_ids(enc16); self.check_ids(collective=False)
         e = lambda *shape, dt=X: torch.empty(*shape, dtype=dt, device=dev)
         with torch.no_grad():
             _, enc_out = self.forward_hidden(enc16, None, em, None, False, 0)
@@ -1374,7 +1382,7 @@ class Engine:
         result = pad.repeat(1, S, 1)
         em = emask.to(torch.float32).contiguous() if emask is not None else None
         enc16 = ops.ids_to_i16(enc_ids)
-        self.note_ids(enc16); self.check_ids()
+        self.note_ids(enc16); self.check_ids(collective=False)
         e = lambda *shape, dt=X: torch.empty(*shape, dtype=dt, device=dev)
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         with torch.no_grad():
@@ -1436,7 +1444,7 @@ class Engine:
         pad_cpu = torch.from_numpy(pb.pad_word_np)
         em = emask.to(torch.float32).contiguous() if emask is not None else None
         enc16 = ops.ids_to_i16(enc_ids)
-        self.note_ids(enc16); self.check_ids()
+        self.note_ids(enc16); self.check_ids(collective=False)
         with torch.no_grad():
             for i in range(S):
                 dec16 = ops.ids_to_i16(dec)

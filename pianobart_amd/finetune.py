@@ -17,7 +17,7 @@ from torch.utils.data import Dataset
 
 from . import heads, ops
 from ._lib import LIB, PBError
-from .model import SequenceClassification, TokenClassification
+from .model import SequenceClassification, TokenClassification, checkpoint_state_dict
 
 
 def get_args_finetune(argv=None):
@@ -352,7 +352,7 @@ def finetune(argv=None):
     best_mdl = '' if args.nopretrain else args.ckpt
     if best_mdl:
         print('   Loading pre-trained model from', best_mdl.split('/')[-1])
-        pianobart.load_state_dict(torch.load(best_mdl, map_location='cpu', weights_only=False)['state_dict'])
+        pianobart.load_state_dict(checkpoint_state_dict(torch.load(best_mdl, map_location='cpu', weights_only=False)['state_dict']))
     print('\nCreating Finetune Trainer')
     trainer = FinetuneTrainer(pianobart, train_loader, valid_loader, test_loader, args.lr, args.class_num, args.hs, test_shape, args.cpu,
                               args.cuda_devices[:1], None, args.task in ('composer', 'emotion'), args.error_correction, args.weight)

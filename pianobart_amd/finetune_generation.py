@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from ._lib import PBError
-from .model import PianoBartLM
+from .model import PianoBartLM, checkpoint_state_dict
 
 HEAD_WEIGHT = [1.0, 1.0, 0.3, 1.5, 1.0, 1.0, 0.3, 0.3]          # finetune_generation.py:241-248 (index = head i)
 
@@ -190,7 +190,7 @@ def finetune_generation(argv=None):
     if args.eval or not args.nopretrain:
         best_mdl = args.ckpt
         print("   Loading pre-trained model from", best_mdl.split('/')[-1])
-        sd = torch.load(best_mdl, map_location='cpu', weights_only=False)['state_dict']
+        sd = checkpoint_state_dict(torch.load(best_mdl, map_location='cpu', weights_only=False)['state_dict'])
         if args.eval:                                                          # a whole fine-tuned PianoBartLM
             model = PianoBartLM(pianobart)
             model.load_state_dict(sd)

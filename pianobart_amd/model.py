@@ -20,6 +20,25 @@ from ._lib import LIB, PBError
 CLASSES = ['Bar', 'Position', 'Instrument', 'Pitch', 'Duration', 'Velocity', 'TimeSig', 'Tempo']
 
 
+def checkpoint_state_dict(sd, module=None):
+    """The `state_dict` of a reference checkpoint, ready for `load_state_dict`.
+
+    Under `nn.DataParallel` the reference saves `self.model.state_dict()` of the WRAPPER (finetune_generation.py:276-285,
+    finetune.py save_checkpoint), so every key carries a leading `module.`; its own `demo.py:128-129` then loads that file with
+    `strict=False` and silently keeps the random initialisation. Here the prefix is stripped (with a message), and -- when `module`
+    is given -- a file none of whose keys name a parameter of `module` is reported instead of being "loaded"."""
+    if sd and all(k.startswith('module.') for k in sd):
+        print("   [pianobart_amd] checkpoint was saved from an nn.DataParallel wrapper: stripping the 'module.' prefix of its %d keys" % len(sd))
+        sd = type(sd)((k[len('module.'):], v) for k, v in sd.items())
+    if module is not None:
+        own = set(module.state_dict().keys())
+        hit = sum(k in own for k in sd)
+        if hit == 0:
+            print("   [pianobart_amd] WARNING: none of the checkpoint's %d keys names a parameter of %s (first key: %r): nothing will be "
+                  "loaded under strict=False" % (len(sd), type(module).__name__, next(iter(sd), None)))
+    return sd
+
+
 class BartConfig:
     """Stand-in for transformers.BartConfig with the attributes the reference reads (main.py:39-47 sets the
     first eight; the rest are BartConfig defaults). Any object with these attribute names is accepted."""

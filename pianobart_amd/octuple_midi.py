@@ -244,7 +244,10 @@ def write_midi(song, path):
 
 
 def read_midi(path):
-    """Notes (note-on/off pairs per channel and pitch, running status), program changes, tempo and time-signature metas."""
+    """Notes (note-on/off per track, channel and pitch; running status; note-on with velocity 0 = note-off), program changes, tempo
+    and time-signature metas; every other event is stepped over. Pinned by tests/golden/g13_song.mid, a byte fixture built from the
+    SMF specification without this module (tests/golden/make_smf_fixture.py): reading it gives the G13 song and, through
+    `midi_to_encoding`, the reference's own 400 rows."""
     raw = open(path, 'rb').read()
     if raw[:4] != b'MThd':
         raise ValueError('%s is not a Standard MIDI File' % path)
@@ -302,10 +305,14 @@ def read_midi(path):
                     if hi == 0x90 and d2 > 0:
                         open_notes.setdefault((ch, d1), []).append((t, d2))
                     elif hi == 0x80 or (hi == 0x90 and d2 == 0):
-                        pend = open_notes.get((ch, d1))
-                        if pend:
-                            start, vel = pend.pop(0)
-                            song.notes.append((start, t, d1, vel, 0 if ch == 9 else program.get(ch, 0), ch == 9))
+                        # miditoolkit's rule (its parser is what demo.py:61-68 reads files with; restated from the published
+                        # package, source absent here): ONE note-off ends EVERY sounding note of that track / channel / pitch
+                        # that began at an earlier tick; a note begun at this very tick stays open.
+                        pend = open_notes.get((ch, d1), [])
+                        for start, vel in pend:
+                            if start != t:
+                                song.notes.append((start, t, d1, vel, 0 if ch == 9 else program.get(ch, 0), ch == 9))
+                        open_notes[(ch, d1)] = [n for n in pend if n[0] == t]
     song.notes.sort()
     return song
 

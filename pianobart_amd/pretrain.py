@@ -58,6 +58,7 @@ def get_args_pretrain(argv=None):
     parser.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'fp32'])
     parser.add_argument('--data_root', type=str, default='Data/output_pretrain')
     parser.add_argument('--quiet', action='store_true', help='do not print the two per-step Loss/Acc lines')
+    parser.add_argument('--resume', type=str, default='', help='continue from a checkpoint THIS driver wrote: weights, LM heads, AdamW moments and step, epoch, best_acc')
     return parser.parse_args(argv)
 
 
@@ -208,12 +209,35 @@ class Pretrainer:
         """pretrain.py:96-110: same dict keys; 'state_dict' holds PianoBart only; optimizer = HF-AdamW state, moments keyed by parameter name."""
         eng = self.engine
         opt = dict(eng.optimizer_state(self.model), lr=self.lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01)   # waits for a pipelined update
+        # The moments are keyed by PianoBartLM's parameter names ('pianobart.*', 'mask_lm.*') because the optimizer owns the LM heads too,
+        # while 'state_dict' below is PianoBart's alone (the reference's file format, pretrain.py:98-106, which drops the heads). So that the
+        # moments of the heads have their weights beside them -- and `--resume` continues the SAME trajectory -- the heads travel inside
+        # this dict (the top-level keys stay the reference's).
+        opt['mask_lm'] = {k: v.detach().cpu() for k, v in self.model.mask_lm.state_dict().items()}
         state = {'epoch': epoch + 1, 'state_dict': {k: v.detach().cpu() for k, v in self.pianobart.state_dict().items()},
                  'best_acc': best_acc, 'valid_acc': valid_acc, 'valid_loss': valid_loss, 'train_loss': train_loss, 'optimizer': opt}
         torch.save(state, filename)
         best_mdl = filename.split('.')[0] + '_best.ckpt'
         if is_best:
             shutil.copyfile(filename, best_mdl)
+
+    def resume(self, filename):
+        """Continue from a checkpoint `save_checkpoint` wrote: PianoBart weights ('state_dict'), the LM heads and the AdamW moments / step count
+        ('optimizer'). Returns (epoch, best_acc). A reference-written file (torch's optimizer.state_dict(): 'state' / 'param_groups') carries
+        neither heads nor named moments and is refused -- load its 'state_dict' as a pre-trained model instead."""
+        from .model import checkpoint_state_dict
+        ck = torch.load(filename, map_location='cpu', weights_only=False)
+        opt = ck.get('optimizer') or {}
+        if 'mask_lm' not in opt or not isinstance(opt.get('exp_avg'), (dict, type(None))):
+            raise PBError('%s has no resumable optimizer state (written by the reference or before round 6): load its state_dict as a pre-trained model' % filename)
+        self.engine.finish_updates()
+        self.pianobart.load_state_dict(checkpoint_state_dict(ck['state_dict']), strict=True)
+        self.model.mask_lm.load_state_dict(opt['mask_lm'], strict=True)
+        self.engine.bind(self.device)
+        self.engine.refresh_shadow(force=True)
+        self.engine.load_optimizer_state(self.model, opt)
+        self._epoch = int(ck.get('epoch', 0))
+        return int(ck.get('epoch', 0)), ck.get('best_acc', 0)
 
     def gen_mask(self, input_ids, choice=None):
         """pretrain.py:211-546 for ONE sequence (S,8): returns (masked (S,8) long, mask (S,) long) on the input's device."""
@@ -252,7 +276,7 @@ class Pretrainer:
         ori = ori_seq_batch.to(self.device, non_blocking=True)
         tgt16 = ori.contiguous() if ori.dtype == torch.int16 else ops.ids_to_i16(ori.long() if ori.dtype != torch.int64 else ori)
         if ori_seq_batch.device.type != 'cpu':                             # a batch that is already on the device: checked there, the verdict is read
-            self.engine.note_ids(tgt16)                                    # without draining the stream (Engine._raise_if_bad_ids); the corrupted and the
+            tgt16 = self.engine.note_ids(tgt16, owned=tgt16.data_ptr() != ori_seq_batch.data_ptr())   # (a caller's int16 tensor is checked on a copy) without draining the stream (Engine._raise_if_bad_ids); the corrupted and the
             self.engine._queue_id_verdict()                                # shifted ids derive from these and from in-range specials / random tokens
         B, S = tgt16.shape[:2]
         enc16, loss_mask, _ = self._corrupt(tgt16)
@@ -399,9 +423,12 @@ def pretrain(argv=None):
     print("\nTraining Start")
     run = _RunLog(args.name, rank == 0)
     print("   save model at {}".format(run.filename))
-    best_acc, stale = 0, 0
+    best_acc, stale, first_epoch = 0, 0, 0
+    if args.resume:
+        first_epoch, best_acc = trainer.resume(args.resume)
+        print("   resumed from {} at epoch {} (best_acc {})".format(args.resume, first_epoch, best_acc))
     start_t = time.time()
-    for epoch in range(args.epochs):
+    for epoch in range(first_epoch, args.epochs):
         if stale >= 30:
             print('valid acc not improving for 30 epochs')
             break

@@ -58,6 +58,11 @@ def test_launcher_refuses_more_ranks_than_gpus_and_a_line_for_another_n():
     def failing(cmd, **kw):
         return types.SimpleNamespace(returncode=7, stdout='')
     assert bench.launch_ranks(2, ['--gpus', '2'], device_count=2, run=failing, out=out) == 7
+
+    def failing_after_the_line(cmd, **kw):                                             # rank 0 printed, then a rank died: the line is withheld
+        return types.SimpleNamespace(returncode=9, stdout=json.dumps({"n_gpus": 2, "value": 1.0}) + '\n')
+    assert bench.launch_ranks(2, ['--gpus', '2'], device_count=2, run=failing_after_the_line, out=out) == 9 and out.getvalue() == ''
+    assert isinstance(bench._kfd_gpu_count(), int) and bench._kfd_gpu_count() >= 0      # counted without a HIP call (0 on this GPU-less box)
     assert bench.launch_ranks(2, ['--gpus', '2'], device_count=2, run=lambda cmd, **kw: types.SimpleNamespace(returncode=0, stdout='no json\n'), out=out) != 0
 
 

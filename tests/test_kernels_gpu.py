@@ -603,6 +603,19 @@ def test_gemm_rowdot_epilogue(ops, M, N, K, bias):
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max()) + 1e-4
     with pytest.raises(PBError):                                          # a ragged row count is not the whole-tile form
         ops.gemm(A[:M - 8], B, C[:M - 8], M=M - 8, N=N, K=K, dtype=ops.PB_BF16, rowdot=(aux, out, ld))
+    # ... and every route to the generic kernel (which has no such epilogue) refuses instead of leaving `out` unwritten:
+    out.fill_(float('nan'))
+    with pytest.raises(PBError):                                          # PB_GEMM_FORCE_V1 (also reachable through PB_GEMM_FLAGS=16)
+        ops.gemm(A, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, rowdot=(aux, out, ld), force_v1=True)
+    with pytest.raises(PBError):                                          # an operand off 16 bytes: the tiled kernels decline it
+        Am = torch.empty(M * K + 8, device='cuda', dtype=torch.bfloat16)[1:M * K + 1].view(M, K)
+        ops.gemm(Am, B, C, M=M, N=N, K=K, dtype=ops.PB_BF16, rowdot=(aux, out, ld))
+    with pytest.raises(PBError):                                          # K no multiple of 64
+        ops.gemm(A[:, :K - 32].contiguous(), B[:, :K - 32].contiguous(), C, M=M, N=N, K=K - 32, dtype=ops.PB_BF16, rowdot=(aux, out, ld))
+    with pytest.raises(PBError):                                          # f32 operands
+        ops.gemm(A.float(), B.float(), C.float(), M=M, N=N, K=K, dtype=ops.PB_F32, rowdot=(aux.float(), out, ld))
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()                                         # none of them launched anything that touched it
 
 
 @pytest.mark.parametrize('M,N,K', [(1024, 768, 256), (2048 + 136, 512 + 64, 192), (4096, 3072, 768)])

@@ -124,3 +124,24 @@ def test_fast_host_sampler_reproduces_sampling_draw_for_draw():
         assert st_ref[2] == st_got[2] and np.array_equal(st_ref[1], st_got[1])
         n_multi += int(ref[3] != int(np.argmax(row[ops.SEG_OFF[3]:ops.SEG_OFF[4]])))
     assert n_multi > 20          # the p = 0.9 heads really sampled (not just argmax) in a good share of the trials
+
+
+def test_module_prefixed_checkpoint_loads(capsys):
+    """Fine-tune checkpoints saved under nn.DataParallel carry `module.` keys (finetune_generation.py:276-285); the reference's demo.py:128-129
+    loads them with strict=False, i.e. loads NOTHING. The drop-in strips the prefix, and says so; a file with no matching key is reported."""
+    from pianobart_amd.model import PianoBart, PianoBartLM, checkpoint_state_dict
+    c, oc = _cfgs(32, 64, 1, 64, 4)
+    o = O.PianoBartLM(O.PianoBart(oc, E2W, W2E))
+    randomize_params(o, 11)
+    wrapped = torch.nn.DataParallel(o).state_dict()                              # what the reference writes from a multi-GPU fine-tune
+    assert all(k.startswith('module.') for k in wrapped)
+    m = PianoBartLM(PianoBart(c, E2W, W2E))
+    res = m.load_state_dict(checkpoint_state_dict(wrapped, m), strict=False)
+    assert not res.missing_keys and not res.unexpected_keys
+    for (k1, v1), (k2, v2) in zip(o.state_dict().items(), m.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert "stripping the 'module.' prefix" in capsys.readouterr().out
+    plain = o.state_dict()
+    assert checkpoint_state_dict(plain, m) is plain and capsys.readouterr().out == ''
+    checkpoint_state_dict(o.pianobart.state_dict(), m)                           # a pre-train file (PianoBart only) into PianoBartLM: the reference's silent no-op
+    assert 'WARNING: none of the checkpoint' in capsys.readouterr().out

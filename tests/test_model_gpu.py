@@ -611,6 +611,13 @@ def test_fused_step_checks_caller_supplied_ids():
             eng.loss_and_grads(*args(e, dec), train=True)
             torch.cuda.synchronize()
             eng._raise_if_bad_ids()                                      # (a step that did not wait for anything learns it here at the latest)
+        if bad > 0:                                                       # the caller's own int16 tensor is checked on a copy: never rewritten
+            mine = ops.ids_to_i16(e); keep = mine.clone()
+            with pytest.raises(IndexError):
+                eng.loss_and_grads(mine, *args(e, dec)[1:], train=True)
+                torch.cuda.synchronize()
+                eng._raise_if_bad_ids()
+            assert torch.equal(mine, keep) and int(mine[1, 7, col]) == bad
         d = dec.clone(); d[2, 5, col] = bad
         with pytest.raises(IndexError):
             eng.loss_and_grads(*args(enc, d), train=True)

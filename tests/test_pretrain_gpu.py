@@ -64,6 +64,56 @@ def test_main_pretrain_cfg1_end_to_end(tmp_path, capsys):
     assert losses[-1] < losses[0]                                                       # it learns
 
 
+def test_pretrain_resume_continues_the_run(tmp_path, capsys):
+    """--resume (the checkpoint's moments had no loader and the heads' moments no weights beside them): the file holds PianoBart's
+    state_dict (reference format), and inside 'optimizer' the LM heads + named AdamW moments + step; a resumed run continues epoch numbering,
+    step count and log, and a fresh Pretrainer that resumes holds bit for bit what was saved. A reference-written optimizer state is refused."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from pianobart_amd._lib import PBError
+    from pianobart_amd.model import BartConfig, PianoBart
+    from pianobart_amd.pretrain import Pretrainer, pretrain
+    data_root = str(tmp_path / 'Data' / 'output_pretrain')
+    _write_dataset(data_root)
+    common = ['--dict_file', VOCAB_JSON, '--name', 'r', '--datasets', 'syn', '--num_workers', '0', '--batch_size', '2', '--max_seq_len', '128',
+              '--hs', '64', '--layers', '1', '--ffn_dims', '128', '--heads', '4', '--lr', '1e-3', '--cuda_devices', '0', '--data_root', data_root, '--quiet']
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        pretrain(common + ['--epochs', '1'])
+        ck1 = torch.load('result/pretrain/r/model.ckpt', weights_only=False)
+        os.replace('result/pretrain/r/model.ckpt', 'first.ckpt')
+        capsys.readouterr()
+        pretrain(common + ['--epochs', '3', '--resume', 'first.ckpt'])
+        out = capsys.readouterr().out
+        ck3 = torch.load('result/pretrain/r/model.ckpt', weights_only=False)
+        log = open('result/pretrain/r/log').read().splitlines()
+        kw = dict(max_position_embeddings=128, d_model=64, encoder_layers=1, decoder_layers=1, encoder_ffn_dim=128, decoder_ffn_dim=128,
+                  encoder_attention_heads=4, decoder_attention_heads=4)
+        tr = Pretrainer(PianoBart(BartConfig(**kw), E2W, W2E), None, None, 1e-3, 2, 128, 0.15, False, [0])
+        assert tr.resume('first.ckpt') == (1, ck1['best_acc'])
+        st = tr.engine.optimizer_state(tr.model)
+        ref_style = dict(ck1, optimizer={'state': {}, 'param_groups': [{'lr': 1e-3}]})
+        torch.save(ref_style, 'ref_style.ckpt')
+        with pytest.raises(PBError):
+            tr.resume('ref_style.ckpt')
+    finally:
+        os.chdir(cwd)
+    assert set(ck1.keys()) == {'epoch', 'state_dict', 'best_acc', 'valid_acc', 'valid_loss', 'train_loss', 'optimizer'}      # still the reference's keys
+    nb = ck1['optimizer']['step']
+    assert ck1['epoch'] == 1 and nb >= 3 and ck3['epoch'] == 3 and ck3['optimizer']['step'] == 3 * nb
+    assert 'resumed from first.ckpt at epoch 1' in out and 'epoch: 2/3' in out and 'epoch: 3/3' in out and 'epoch: 1/3' not in out
+    assert [l.split(':')[0] for l in log if l.startswith('Epoch')] == ['Epoch 1', 'Epoch 2', 'Epoch 3']
+    assert st['step'] == nb and set(st['exp_avg']) == set(ck1['optimizer']['exp_avg'])
+    for k, v in ck1['optimizer']['exp_avg_sq'].items():
+        assert torch.equal(st['exp_avg_sq'][k], v) and torch.equal(st['exp_avg'][k], ck1['optimizer']['exp_avg'][k]), k
+    for k, v in ck1['optimizer']['mask_lm'].items():
+        assert torch.equal(tr.model.mask_lm.state_dict()[k].cpu(), v), k
+    for k, v in ck1['state_dict'].items():
+        assert torch.equal(tr.pianobart.state_dict()[k].cpu(), v), k
+    assert any(not torch.equal(ck3['state_dict'][k], ck1['state_dict'][k]) for k in ck1['state_dict'] if 'fc1.weight' in k)     # and it kept training
+
+
 def test_pretrainer_step_matches_oracle_on_its_own_batch():
     """One Pretrainer batch (device corruption + shift-right + masks) -> fused loss == oracle loss on the same tensors."""
     if not torch.cuda.is_available():
