@@ -356,6 +356,32 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
                                 "note": "reference corruption mix (pb_corrupt, choices 1..5 per sample, seed 1234) of the same clean sequences; 10 steps"}
     except Exception as ex:                                            # noqa: BLE001
         out["real_mix_step"] = {"error": repr(ex)[:200]}
+    # (a'') what the step EXCLUDES and SURVEY 8(d) wants reported beside it: building the batch on the device -- the reference's gen_mask over
+    # the B sequences (pretrain.py:131-144: serial Python, 20-80 ms per SAMPLE), here ONE pb_corrupt launch + shift-right + the two masks.
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = 20
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(nrep):
+            ops.corrupt(tgt16, enc_r, lm_r, ch, None, 0.15, 0x1234ABCD, pb.pad_word_np, pb.mask_word_np, pb.n_tokens)
+            ops.shift_right(tgt16, eng.sos16, dec_r, B, S)
+            em_r, dm_r = (enc_r[:, :, 0] != pad).float(), (dec_r[:, :, 0] != pad).float()
+        e1.record()
+        torch.cuda.synchronize()
+        e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e2.record()
+        for _ in range(nrep):
+            ops.corrupt(tgt16, enc_r, lm_r, ch, None, 0.15, 0x1234ABCD, pb.pad_word_np, pb.mask_word_np, pb.n_tokens)
+        e3.record()
+        torch.cuda.synchronize()
+        out["corruption_ms"] = {"ms_per_batch": e0.elapsed_time(e1) / nrep, "pb_corrupt_kernel_ms": e2.elapsed_time(e3) / nrep, "batch": B, "seq_len": S,
+                                "bytes_per_batch": B * S * 8 * (2 + 2 + 4), "launches": 4,
+                                "note": "excluded from `value` (SURVEY 8d): pb_corrupt (reference 5-way mix, one workgroup per sequence) + pb_shift_right + "
+                                        "2 mask compares for the B = %d batch, HIP events over %d repetitions; the reference does this as serial Python "
+                                        "per sample on the host (pretrain.py:131-144)" % (B, nrep)}
+    except Exception as ex:                                            # noqa: BLE001
+        out["corruption_ms"] = {"error": repr(ex)[:200]}
     with stdout_to_stderr():                                         # the first communicator's banner goes to stderr
         try:
             from pianobart_amd.parallel import GradReducer
@@ -427,6 +453,71 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
         model.train()
     except Exception as ex:                                            # noqa: BLE001
         out["decode"] = {"error": repr(ex)[:200]}
+    return out
+
+
+def side_model_step(cfgkw, precision, B, S, dev, nsteps, seed=1234):
+    """One more model in the same process (its own parameters, engine and synthetic SURVEY 8(d) batch), `nsteps` timed steps after 2
+    warm-up steps; returns (ms per step, executed FLOPs per step, kept rows). Used for the legs whose shape or precision differs from the
+    headline's: the exact-f32 parity instantiation and BASELINE configs[4]'s model on one GPU. Freed before returning."""
+    from pianobart_amd import ops
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab, synth_octuple_batch
+    e2w, w2e = load_vocab()
+    torch.manual_seed(1)
+    model = PianoBartLM(PianoBart(BartConfig(**cfgkw), e2w, w2e, precision=precision)).train().to(dev)
+    eng = model._get_engine()
+    eng.bind(dev)
+    eng.pipeline_updates = True
+    enc, dec, loss_mask, emask, dmask, target = [x.to(dev) for x in synth_octuple_batch(B, S, seed)]
+    b = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
+
+    def one():
+        eng.loss_and_grads(*b, train=True, ids_checked=True)
+        eng.optimizer_step(lr=2e-5, gscale=1.0)
+    one(); one(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / nsteps * 1e3
+    Te, Td, _, Ts = eng.last_rows
+    d, L, f = cfgkw['d_model'], cfgkw['encoder_layers'], cfgkw['encoder_ffn_dim']
+    fl = train_flops_live_rows(Te, Td, eng.last_pairs, d, L, f, Ts=Ts)
+    rows = {"encoder_side": Te, "decoder_side": Td, "last_layer_query_side": Ts, "of": B * S}
+    eng.finish_updates()
+    del eng, model, b
+    torch.cuda.empty_cache()
+    return ms, fl, rows
+
+
+def other_instantiations(args, cfgkw, dev):
+    """SURVEY 8(d) legs the headline does not cover, each driver-timed in the default run:
+    fp32_parity_step -- the SAME model shape in the exact-f32 instantiation (`precision="fp32"`: f32 storage, f32-input MFMA = an fmaf chain,
+    unfused attention), i.e. the instantiation that is gated at the north-star tolerance (logits 1e-4 against the CPU oracle), at B = 4;
+    cfg5_step -- BASELINE configs[4]'s model (24L / 1024d / ffn 4096 / 16 heads, S = 2048) on ONE GPU at B = 8, bf16."""
+    out = {}
+    try:
+        B4 = 4
+        ms, fl, rows = side_model_step(cfgkw, 'fp32', B4, args.seq, dev, 3)
+        out["fp32_parity_step"] = {"ms_per_step": ms, "batch": B4, "tokens_per_s": B4 * args.seq / (ms * 1e-3), "rows": rows,
+                                   "step_tflops": fl / (ms * 1e-3) / 1e12, "peak_tflops_f32_mfma": 157.3, "frac_of_f32_mfma_peak": fl / (ms * 1e-3) / 1e12 / 157.3,
+                                   "note": "precision='fp32' (exact f32 arithmetic, the parity-gated instantiation: tests/test_model_gpu.py at 1e-4), same "
+                                           "model shape as the headline, B = 4, padded rows (the packed step is bf16-only), 3 steps"}
+    except Exception as ex:                                            # noqa: BLE001
+        out["fp32_parity_step"] = {"error": repr(ex)[:200]}
+    if args.precision == 'bf16' and (args.layers, args.hs, args.seq) == (12, 768, 1024):
+        try:
+            kw5 = dict(max_position_embeddings=2048, d_model=1024, encoder_layers=24, decoder_layers=24, encoder_ffn_dim=4096, decoder_ffn_dim=4096,
+                       encoder_attention_heads=16, decoder_attention_heads=16, dropout=cfgkw['dropout'])
+            B5, S5 = 8, 2048
+            ms, fl, rows = side_model_step(kw5, 'bf16', B5, S5, dev, 5)
+            out["cfg5_step"] = {"ms_per_step": ms, "batch": B5, "seq_len": S5, "tokens_per_s": B5 * S5 / (ms * 1e-3), "rows": rows,
+                                "step_tflops": fl / (ms * 1e-3) / 1e12, "step_mfma_frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                                "flops_per_token_train": train_flops_per_token(S5, 1024, 24, 4096),
+                                "note": "BASELINE configs[4]'s model (24L / 1024d / ffn 4096 / 16 heads, S = 2048) on one GPU, B = 8, bf16, dropout on, packed rows, 5 steps"}
+        except Exception as ex:                                        # noqa: BLE001
+            out["cfg5_step"] = {"error": repr(ex)[:200]}
     return out
 
 
@@ -677,6 +768,18 @@ def main():
     extras = {}
     if world == 1 and not args.no_probe:
         extras = extra_measurements(args, model, eng, ops, step, peak, dev)
+        extras.update(other_instantiations(args, cfgkw, dev))
+    # the largest single row of the committed kernel trace is not the GEMM but the one-pass attention backward: a second roofline entry
+    # for it, from the same in-step HIP events (the interval of a flash_bwd1_packed call = fa1_bwd + its fa1_reduce launch)
+    roofline2 = None
+    if table is not None:
+        fa = [(k, v) for k, v in shapes.items() if k.startswith(('flash_bwd1_packed', 'flash_bwd1 '))]
+        if fa:
+            ms_ = sum(v[0] for _, v in fa); fl_ = sum(v[1] for _, v in fa); n_ = sum(v[2] for _, v in fa)
+            roofline2 = {"bound": "mfma", "achieved": fl_ / (ms_ * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl_ / (ms_ * 1e-3) / 1e12 / peak,
+                         "traffic": None, "kernel": "fa1_bwd_kernel (one-pass attention backward, head_dim 64) + fa1_reduce, encoder self- and cross-attention calls",
+                         "avg_launch_ms": ms_ / n_, "calls_per_step": n_ / nprobe,
+                         "how": "HIP events around the %d calls of the probe steps; FLOPs = 2.5 x 4 x H x hd x (query, key) pairs covered" % n_}
 
     if rank == 0:
         traffic, traffic_src = pmc_traffic(sorted({Te, Td}), args.ffn, args.hs)
@@ -714,6 +817,8 @@ def main():
                          "isolated_back_to_back_ms": iso_ms, "isolated_rows": Tiso, "isolated_host_enqueue_ms_per_launch": iso_host_ms,
                          "families_in_step": families, "top_ops_in_step": table},
         }
+        if roofline2 is not None:
+            rec["roofline_secondary"] = roofline2
         rec.update(extras)
         rec["rows"]["loss_rows_fraction"] = Ts / float(Td)
         if world == 1 and not args.no_cpu_baseline:

@@ -832,11 +832,163 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int16_t* __restric
     if (t == 0) *pos = i;                                        // every thread has read *pos (two barriers ago); later launches see i
 }
 
+// ---------------------------------------------------------------- device-side nucleus sampling (round 6)
+// model.py:68-107 for the 8 heads of ONE position, on the device: logits row -> y = logit / T[h] -> softmax -> nucleus(p[h]) with
+// the uniform draw u[pos][h] the host drew AHEAD for this position (the draws do not depend on the logits, model.py:97 /
+// np.random.choice) -> the 8 ids of the next decoder input, written to tok_dev for the next step's embedding kernel, and -- with the
+// raw logits row -- to pinned host logs indexed by position. The arithmetic follows pb_nucleus_rows above statement for statement
+// (numpy's order: sequential f32 sums, probs /= (sum + 1e-5), descending order with ties by index, candidates up to the first
+// cumsum > p, q = cand / sum(cand), f64 cdf / cdf[-1] > u); what it cannot reproduce bit for bit is the CPU softmax the host path
+// uses (torch's vectorised exp and its summation order: 1 ulp apart), so the HOST remains the authority: it replays every position
+// from the logged logits row with the reference code path and rolls the decoder back on the (rare) position where the device chose
+// differently (Engine.generate). The device result is a PREDICTION that lets the next token start without a host round trip.
+// One workgroup of 512 threads: wave h = head h for the softmax and the scans; the rank counting of the heads with p < 1 uses one
+// thread per (head, class). fault_period > 0 (tests only) corrupts head 0's id at every fault_period-th position.
+struct SampleArgs {
+    const float* logits;                  // (vocab) f32 row of the position just decoded
+    const double* u;                      // (S, 8) uniform draws, device
+    const int* pos;                       // device: the position the row belongs to
+    int16_t* tok_dev;                     // (8) next decoder input
+    float* log_logits;                    // pinned host (S, vocab)
+    int16_t* log_tok;                     // pinned host (S, 8)
+    int vocab, fault_period;
+    int off[8], n[8];
+    float temp[8], p[8];
+};
+constexpr int SMP_W = 272;                // >= the largest head (262), multiple of 16
+__global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
+    __shared__ float pn[8][SMP_W];        // normalised probabilities, class order
+    __shared__ float sp[8][SMP_W];        // ... in descending order (heads with p < 1)
+    __shared__ int si[8][SMP_W];          // class of each sorted entry
+    __shared__ double cdf[8][SMP_W];      // running f64 sum of the candidates' renormalised probabilities
+    __shared__ float hsum[8];
+    __shared__ int hk[8], htok[8];
+    const int t = threadIdx.x, lane = t & 63, h = t >> 6;
+    const int pos = *a.pos;
+    const int n = a.n[h], off = a.off[h];
+    const float T = a.temp[h];
+    // softmax(logit / T) of head h (torch.softmax(logit / t, dim=-1), model.py:103-104)
+    float y[5], e[5];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        const bool in = c < n;
+        const float lg = in ? a.logits[off + c] : 0.f;
+        if (in) a.log_logits[(size_t)pos * a.vocab + off + c] = lg;
+        y[k] = in ? lg / T : -INFINITY;
+        mx = fmaxf(mx, y[k]);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { e[k] = (lane + 64 * k < n) ? expf(y[k] - mx) : 0.f; s += e[k]; }
+    s = wave_sum(s);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) if (lane + 64 * k < n) pn[h][lane + 64 * k] = e[k] / s;
+    __syncthreads();
+    if (lane == 0) {                                           // np.cumsum(probs)[-1]: left to right in f32
+        float c = pn[h][0];
+        for (int i = 1; i < n; ++i) c = c + pn[h][i];
+        hsum[h] = c + 1e-5f;
+    }
+    __syncthreads();
+    {
+        const float c = hsum[h];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (lane + 64 * k < n) pn[h][lane + 64 * k] = pn[h][lane + 64 * k] / c;      // probs /= (sum + 1e-5)
+    }
+    __syncthreads();
+    // descending order of the heads with p < 1 by rank counting, one thread per (head, class): ties by class index
+    {
+        int hh = -1, c = t;
+        for (int q = 0; q < 8; ++q) {
+            if (a.p[q] < 1.0f) {
+                if (hh < 0 && c < a.n[q]) hh = q;
+                if (hh < 0) c -= a.n[q];
+            }
+        }
+        if (hh >= 0) {
+            const float v = pn[hh][c];
+            const int nn = a.n[hh];
+            int rank = 0;
+            for (int j = 0; j < nn; ++j) {
+                const float w = pn[hh][j];
+                rank += (w > v || (w == v && j < c)) ? 1 : 0;
+            }
+            sp[hh][rank] = v; si[hh][rank] = c;
+        }
+    }
+    __syncthreads();
+    const float ph = a.p[h];
+    if (ph < 1.0f) {
+        if (lane == 0) {                                       // candidates: up to and including the first cumsum > p; none -> top 1
+            float cs = sp[h][0];
+            int first = cs > ph ? 0 : -1;
+            for (int i = 1; i < n && first < 0; ++i) { cs = cs + sp[h][i]; if (cs > ph) first = i; }
+            const int k = first < 0 ? 1 : first + 1;
+            float qs = sp[h][0];
+            for (int i = 1; i < k; ++i) qs = qs + sp[h][i];    // np.cumsum(q)[-1]
+            hk[h] = k; hsum[h] = qs;
+        }
+        __syncthreads();
+        const int k = hk[h];
+        const float qs = hsum[h];
+        for (int i = lane; i < k; i += 64) pn[h][i] = sp[h][i] / qs;                // q (pn is free now)
+        __syncthreads();
+        if (lane == 0) {
+            double cum = 0.0;
+            for (int i = 0; i < k; ++i) { cum += (double)pn[h][i]; cdf[h][i] = cum; }
+        }
+        __syncthreads();
+        const double last = cdf[h][k - 1], u = a.u[(size_t)pos * 8 + h];
+        int best = k - 1;                                      // first index with cdf / cdf[-1] > u
+        for (int i = lane; i < k; i += 64) if (cdf[h][i] / last > u) { best = i; break; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+        if (lane == 0) htok[h] = si[h][best];
+    } else {                                                   // p = 1: the cumsum never exceeds it -> the largest probability (lowest class among equals)
+        float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            if (c < n) { const float v = pn[h][c]; if (v > bv) { bv = v; bi = c; } }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads(); __syncthreads(); __syncthreads();     // the barriers of the other branch (whole waves take one branch or the other)
+        if (lane == 0) htok[h] = bi;
+    }
+    __syncthreads();
+    if (t < 8) {
+        int id = htok[t];
+        if (a.fault_period > 0 && t == 0 && (pos % a.fault_period) == a.fault_period - 1) id = (id + 1) % a.n[0];
+        a.tok_dev[t] = (int16_t)id;
+        a.log_tok[(size_t)pos * 8 + t] = (int16_t)id;
+    }
+}
+
+constexpr int SPEC_K = 8;                  // tokens per graph replay of the device-sampled decode
+constexpr int SPEC_EVENTS = 8;
+
 struct Decoder {
     pb_decode_plan plan;
     hipStream_t stream = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // device-sampled ("speculative") decode, pb_decoder_sampler_init .. pb_decoder_seek
+    bool sampler = false;
+    SampleArgs sa{};
+    double* u_dev = nullptr;
+    float* log_logits = nullptr;           // pinned (S, vocab)
+    int16_t* log_tok = nullptr;            // pinned (S, 8)
+    hipGraph_t graph1 = nullptr, graphK = nullptr;
+    hipGraphExec_t exec1 = nullptr, execK = nullptr;
+    hipEvent_t evs[SPEC_EVENTS] = {};
+    int next_ev = 0;
     int* pos = nullptr;                    // device: position of the token being decoded
     int16_t* tok_dev = nullptr;            // device copy of the current token (8 ids)
     int16_t* tok_host = nullptr;           // pinned
@@ -948,6 +1100,14 @@ extern "C" int pb_decoder_destroy(void* dec) {
     if (D->stream) (void)hipStreamSynchronize(D->stream);
     if (D->exec) (void)hipGraphExecDestroy(D->exec);
     if (D->graph) (void)hipGraphDestroy(D->graph);
+    if (D->exec1) (void)hipGraphExecDestroy(D->exec1);
+    if (D->graph1) (void)hipGraphDestroy(D->graph1);
+    if (D->execK) (void)hipGraphExecDestroy(D->execK);
+    if (D->graphK) (void)hipGraphDestroy(D->graphK);
+    for (int i = 0; i < SPEC_EVENTS; ++i) if (D->evs[i]) (void)hipEventDestroy(D->evs[i]);
+    if (D->u_dev) (void)hipFree(D->u_dev);
+    if (D->log_logits) (void)hipHostFree(D->log_logits);
+    if (D->log_tok) (void)hipHostFree(D->log_tok);
     if (D->ev) (void)hipEventDestroy(D->ev);
     if (D->pos) (void)hipFree(D->pos);
     if (D->tok_dev) (void)hipFree(D->tok_dev);
@@ -1012,6 +1172,118 @@ extern "C" int pb_decoder_step(void* dec, const int16_t* tok8, float* logits_out
     }
     PB_CHECK_HIP(hipStreamSynchronize(D->stream));
     for (int k = 0; k < D->plan.vocab; ++k) logits_out[k] = D->logits_host[k];
+    return 0;
+}
+
+// ---- device-sampled decode: the sampler's constants and the uniform draws of the whole prompt go up once; tokens are then enqueued in
+// runs (pb_decoder_launch: SPEC_K tokens = one graph replay) without waiting for the host; the host follows behind through the pinned
+// logs (pb_decoder_wait + pb_decoder_logs), and pb_decoder_seek rewinds after a position where it disagrees with the device's choice.
+extern "C" int pb_decoder_sampler_init(void* dec, const float* temps8, const float* p8, const int32_t* n8, const int32_t* off8,
+                                       const double* u, int64_t n_u, int32_t fault_period) {
+    Decoder* D = (Decoder*)dec;
+    PB_REQUIRE(D && temps8 && p8 && n8 && off8 && u, "pb_decoder_sampler_init: null argument");
+    PB_REQUIRE(n_u >= (int64_t)D->plan.S * 8, "pb_decoder_sampler_init: %lld draws for %d positions x 8 heads", (long long)n_u, D->plan.S);
+    for (int h = 0; h < 8; ++h) {
+        PB_REQUIRE(n8[h] > 0 && n8[h] <= SMP_W && n8[h] <= 320 && off8[h] >= 0 && off8[h] + n8[h] <= D->plan.vocab && temps8[h] > 0.f,
+                   "pb_decoder_sampler_init: head %d (n %d, offset %d, temperature %g)", h, n8[h], off8[h], (double)temps8[h]);
+        D->sa.n[h] = n8[h]; D->sa.off[h] = off8[h]; D->sa.temp[h] = temps8[h]; D->sa.p[h] = p8[h];
+    }
+    int sorted = 0;
+    for (int h = 0; h < 8; ++h) if (p8[h] < 1.0f) sorted += n8[h];
+    PB_REQUIRE(sorted <= 512, "pb_decoder_sampler_init: %d classes under heads with p < 1 (one thread each, 512 threads)", sorted);
+    const size_t S = (size_t)D->plan.S;
+    if (!D->u_dev) {
+        if (hipMalloc(&D->u_dev, sizeof(double) * S * 8) != hipSuccess ||
+            hipHostMalloc(&D->log_logits, sizeof(float) * S * (size_t)D->plan.vocab, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&D->log_tok, sizeof(int16_t) * S * 8, hipHostMallocDefault) != hipSuccess) {
+            pb_set_error("pb_decoder_sampler_init: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+            return -1;
+        }
+        for (int i = 0; i < SPEC_EVENTS; ++i) PB_CHECK_HIP(hipEventCreateWithFlags(&D->evs[i], hipEventDisableTiming));
+    }
+    PB_CHECK_HIP(hipMemcpyAsync(D->u_dev, u, sizeof(double) * S * 8, hipMemcpyHostToDevice, D->stream));
+    PB_CHECK_HIP(hipStreamSynchronize(D->stream));                     // `u` may be pageable: the copy is done when we return
+    D->sa.logits = D->plan.logits; D->sa.u = D->u_dev; D->sa.pos = D->pos; D->sa.tok_dev = D->tok_dev;
+    D->sa.log_logits = D->log_logits; D->sa.log_tok = D->log_tok; D->sa.vocab = D->plan.vocab; D->sa.fault_period = fault_period;
+    D->sampler = true;
+    return 0;
+}
+
+static int spec_issue(Decoder* D, hipStream_t st, int ntok, int* count) {
+    int n = 0;
+    for (int k = 0; k < ntok; ++k) {
+        if (decoder_issue(D, st, &n)) return -1;
+        hipLaunchKernelGGL(dec_sample_kernel, dim3(1), dim3(512), 0, st, D->sa);
+        PB_LAUNCH_CHECK();
+    }
+    *count = n + 1;
+    return 0;
+}
+
+static bool spec_capture(Decoder* D, int ntok, hipGraph_t* g, hipGraphExec_t* x) {
+    int n = 0;
+    if (hipStreamBeginCapture(D->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const int rc = spec_issue(D, D->stream, ntok, &n);
+    const hipError_t e = hipStreamEndCapture(D->stream, g);
+    if (rc || e != hipSuccess || !*g || hipGraphInstantiate(x, *g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (*g) { (void)hipGraphDestroy(*g); *g = nullptr; }
+        *x = nullptr;
+        return false;
+    }
+    D->launches = n;
+    return true;
+}
+
+// Enqueue the next `ntok` tokens (decoder input of the first = tok_dev as the previous step's sampler, pb_decoder_seek or `first_tok8`
+// left it). Returns a ticket >= 0 for pb_decoder_wait, < 0 on error. first_tok8 (8 ids, may be NULL) is copied up in front of the run.
+extern "C" int pb_decoder_launch(void* dec, int32_t ntok, const int16_t* first_tok8) {
+    Decoder* D = (Decoder*)dec;
+    PB_REQUIRE(D && D->sampler, "pb_decoder_launch: pb_decoder_sampler_init first");
+    PB_REQUIRE(ntok > 0 && D->steps + ntok <= D->plan.S, "pb_decoder_launch: %d tokens from position %d leave the K/V caches (S = %d)", ntok, D->steps, D->plan.S);
+    if (first_tok8) {
+        PB_CHECK_HIP(hipStreamSynchronize(D->stream));                 // tok_host is about to be rewritten: no copy of it may be in flight
+        for (int k = 0; k < 8; ++k) D->tok_host[k] = first_tok8[k];
+        PB_CHECK_HIP(hipMemcpyAsync(D->tok_dev, D->tok_host, 16, hipMemcpyHostToDevice, D->stream));
+    }
+    if (D->use_graph && !D->exec1) {
+        PB_CHECK_HIP(hipStreamSynchronize(D->stream));
+        if (!spec_capture(D, 1, &D->graph1, &D->exec1) || !spec_capture(D, SPEC_K, &D->graphK, &D->execK)) D->use_graph = 0;
+    }
+    int left = ntok;
+    while (left > 0) {
+        if (D->use_graph && left >= SPEC_K) { PB_CHECK_HIP(hipGraphLaunch(D->execK, D->stream)); left -= SPEC_K; }
+        else if (D->use_graph) { PB_CHECK_HIP(hipGraphLaunch(D->exec1, D->stream)); left -= 1; }
+        else { int n = 0; if (spec_issue(D, D->stream, 1, &n)) return -1; D->launches = n; left -= 1; }
+    }
+    D->steps += ntok;
+    const int tk = D->next_ev;
+    D->next_ev = (D->next_ev + 1) % SPEC_EVENTS;
+    PB_CHECK_HIP(hipEventRecord(D->evs[tk], D->stream));
+    return tk;
+}
+extern "C" int pb_decoder_wait(void* dec, int32_t ticket) {
+    Decoder* D = (Decoder*)dec;
+    PB_REQUIRE(D && D->sampler && ticket >= 0 && ticket < SPEC_EVENTS, "pb_decoder_wait: bad ticket %d", ticket);
+    PB_CHECK_HIP(hipEventSynchronize(D->evs[ticket]));
+    return 0;
+}
+extern "C" int pb_decoder_logs(void* dec, float** logits_rows, int16_t** tok_rows) {
+    Decoder* D = (Decoder*)dec;
+    PB_REQUIRE(D && D->sampler && logits_rows && tok_rows, "pb_decoder_logs: no sampler");
+    *logits_rows = D->log_logits; *tok_rows = D->log_tok;
+    return 0;
+}
+// Rewind: drain what is enqueued, make `pos` the last decoded position and tok8 the decoder input of position pos + 1.
+extern "C" int pb_decoder_seek(void* dec, int32_t pos, const int16_t* tok8) {
+    Decoder* D = (Decoder*)dec;
+    PB_REQUIRE(D && tok8 && pos >= -1 && pos < D->plan.S, "pb_decoder_seek: position %d", pos);
+    PB_CHECK_HIP(hipStreamSynchronize(D->stream));
+    for (int k = 0; k < 8; ++k) D->tok_host[k] = tok8[k];
+    PB_CHECK_HIP(hipMemcpyAsync(D->tok_dev, D->tok_host, 16, hipMemcpyHostToDevice, D->stream));
+    PB_CHECK_HIP(hipMemcpyAsync(D->pos, &pos, 4, hipMemcpyHostToDevice, D->stream));
+    PB_CHECK_HIP(hipStreamSynchronize(D->stream));
+    D->steps = pos + 1;
     return 0;
 }
 
