@@ -266,19 +266,13 @@ def decode_bench(args, model, eng, dev, rank):
     enc = synth_octuple_batch(1, S, seed=7, min_len=S // 2)[5].to(dev)
     emask = (enc[:, :, 0] != 256).float()
     nsteps = min(args.steps, S)
-    count = {'n': 0}
-
-    def sample_row(row):
-        count['n'] += 1
-        if count['n'] > nsteps:
-            return torch.tensor([256, 128, 129, 256, 128, 32, 254, 49])          # PAD row: stops the loop
-        return model.sample_row(row)
-
+    sampler = dict(T=model.SAMPLE_T, P=model.SAMPLE_P)
     np.random.seed(0)
     eng.generate(enc[:, :64].contiguous(), emask[:, :64].contiguous(), lambda r: torch.tensor([256, 128, 129, 256, 128, 32, 254, 49]))  # warm-up
+    eng.generate(enc, emask, model.sample_row, max_new=16, sampler=sampler)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = eng.generate(enc, emask, sample_row)
+    out = eng.generate(enc, emask, model.sample_row, max_new=nsteps, sampler=sampler)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
@@ -422,16 +416,13 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
         enc = synth_octuple_batch(1, S, seed=7, min_len=S // 2)[5].to(dev)
         emask = (enc[:, :, 0] != 256).float()
         ntok = min(200, S)
-        cnt = {'n': 0}
-
-        def sample_row(row):
-            cnt['n'] += 1
-            return torch.tensor([256, 128, 129, 256, 128, 32, 254, 49]) if cnt['n'] > ntok else model.sample_row(row)
-
+        sampler = dict(T=model.SAMPLE_T, P=model.SAMPLE_P)           # model.sample_row IS model.py:68-107 with these constants: the device may sample ahead
         np.random.seed(0)
         eng.generate(enc[:, :64].contiguous(), emask[:, :64].contiguous(), lambda r: torch.tensor([256, 128, 129, 256, 128, 32, 254, 49]))
+        eng.generate(enc, emask, model.sample_row, max_new=16, sampler=sampler)      # warm-up of the device-sampled path (graph capture)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        eng.generate(enc, emask, sample_row)
+        eng.generate(enc, emask, model.sample_row, max_new=ntok, sampler=sampler)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) * 1e3
         info = eng.last_decode or {}
@@ -444,8 +435,12 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
         out["decode"] = {"ms_per_token": ms_tok, "tokens": n, "launches_per_token": info.get('launches_per_token'), "graph": info.get('graph'),
                          "prompt_ms_encoder_and_cross_kv": wall - info.get('loop_ms', wall), "bytes_per_token": wbytes + kvbytes,
                          "hbm_gbps": (wbytes + kvbytes) / (ms_tok * 1e-3) / 1e9, "hbm_frac": (wbytes + kvbytes) / (ms_tok * 1e-3) / 8e12,
-                         "note": "BASELINE configs[3] shape (B = 1, S = %d, %d visible encoder rows): per-token wall time of the decode loop incl. "
-                                 "the host-side nucleus sampling (same RNG stream as the reference); one hipGraph replay per token" % (S, s_enc)}
+                         "device_sampler": info.get('device_sampler', False), "rewinds": info.get('rewinds'),
+                         "tokens_per_graph_replay": info.get('tokens_per_graph_replay', 1),
+                         "note": "BASELINE configs[3] shape (B = 1, S = %d, %d visible encoder rows): per-token wall time of the decode loop. The "
+                                 "device samples each position itself from uniform draws made ahead (8 tokens per hipGraph replay); the host "
+                                 "replays every position from the logged logits row with the reference's sampler and RNG stream and rewinds the "
+                                 "decoder where it disagrees (`rewinds`), so the tokens are the host loop's" % (S, s_enc)}
         with torch.no_grad():
             for p_, b_ in zip(model.mask_lm.proj.parameters(), biases):
                 p_.copy_(b_)

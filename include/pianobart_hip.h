@@ -20,7 +20,7 @@ extern "C" {
 #define PB_F32 0
 #define PB_BF16 1
 
-#define PB_ABI_VERSION 7   /* 7 (round 5): + PB_GEMM_ROWDOT / rowdot_out in pb_gemm_desc, delta_rows in pb_flash_bwd1*; 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
+#define PB_ABI_VERSION 8   /* 8 (round 6): + pb_decoder_sampler_init / launch / wait / logs / seek (device-sampled decode); 7 (round 5): + PB_GEMM_ROWDOT / rowdot_out in pb_gemm_desc, delta_rows in pb_flash_bwd1*; 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
 int pb_abi_version(void);
 const char* pb_last_error(void);
 
@@ -396,6 +396,28 @@ int pb_decoder_reset(void* dec, void* caller_stream, int32_t use_graph);
 int pb_decoder_step(void* dec, const int16_t* tok8, float* logits_out);
 int pb_decoder_launches(void* dec);
 int pb_decoder_graph(void* dec);
+/* Device-sampled decode (round 6; ABI 8): the per-token host round trip of model.py:42-65 (logits row down, sampling(), token up) leaves
+ * the critical path. np.random.choice's uniform draws do not depend on the logits (model.py:97), so the host draws the (S, 8) of a whole
+ * prompt ahead and uploads them once; a one-workgroup kernel behind the LM-head GEMV then does model.py:68-107 for the 8 heads (y = logit
+ * / T, softmax, nucleus with the threshold p and the draw of that position: pb_nucleus_rows' arithmetic order) and writes the next decoder
+ * input on the device, so tokens are enqueued back to back, 8 per hipGraph replay. The kernel also writes the raw logits row and its 8 ids
+ * to pinned host logs indexed by position: the HOST stays the authority -- it replays each position from the logged row through the
+ * reference code path (CPU softmax + nucleus, consuming the global RNG stream exactly as before) and, on the rare position where the
+ * device's softmax rounding made another choice, rewinds the decoder (pb_decoder_seek) and continues from its own token. Results are
+ * therefore bit-identical to the per-token loop (tests/test_model_gpu.py) whatever the device sampled.
+ *   pb_decoder_sampler_init  temperatures, thresholds, class counts and logits offsets of the 8 heads, u = (S, 8) f64 draws (host; copied),
+ *                            fault_period > 0 corrupts head 0's id at every fault_period-th position (tests of the rewind path only).
+ *   pb_decoder_launch        enqueue the next ntok tokens (first_tok8, 8 host ids or NULL, is copied up as the first decoder input);
+ *                            returns a ticket >= 0 for pb_decoder_wait, or < 0.
+ *   pb_decoder_wait          block until that run's tokens are decoded and logged.
+ *   pb_decoder_logs          the pinned logs: (S, vocab) f32 logits rows, (S, 8) int16 device-sampled ids.
+ *   pb_decoder_seek          drain, then: last decoded position = pos, decoder input of position pos + 1 = tok8. */
+int pb_decoder_sampler_init(void* dec, const float* temps8, const float* p8, const int32_t* n8, const int32_t* off8, const double* u,
+                            int64_t n_u, int32_t fault_period);
+int pb_decoder_launch(void* dec, int32_t ntok, const int16_t* first_tok8);
+int pb_decoder_wait(void* dec, int32_t ticket);
+int pb_decoder_logs(void* dec, float** logits_rows, int16_t** tok_rows);
+int pb_decoder_seek(void* dec, int32_t pos, const int16_t* tok8);
 
 /* ---- K15: deferred parameter-gradient reductions -----------------------------------------------------------------------
  * The bias / LayerNorm-parameter gradients of one backward pass (the `db = grad.sum(0)` of every nn.Linear and nn.LayerNorm autograd

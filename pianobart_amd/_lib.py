@@ -92,8 +92,8 @@ class _Lib:
                 fn.restype = restype
                 fn.argtypes = argtypes
             ver = dll.pb_abi_version()
-            if ver != 7:
-                raise PBError('ABI version mismatch: library %d, binding 7' % ver)
+            if ver != 8:
+                raise PBError('ABI version mismatch: library %d, binding 8' % ver)
             self._dll = dll
         return self._dll
 

@@ -921,26 +921,31 @@ __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
     }
     __syncthreads();
     const float ph = a.p[h];
-    if (ph < 1.0f) {
-        if (lane == 0) {                                       // candidates: up to and including the first cumsum > p; none -> top 1
-            float cs = sp[h][0];
-            int first = cs > ph ? 0 : -1;
-            for (int i = 1; i < n && first < 0; ++i) { cs = cs + sp[h][i]; if (cs > ph) first = i; }
-            const int k = first < 0 ? 1 : first + 1;
-            float qs = sp[h][0];
-            for (int i = 1; i < k; ++i) qs = qs + sp[h][i];    // np.cumsum(q)[-1]
-            hk[h] = k; hsum[h] = qs;
-        }
-        __syncthreads();
+    const bool sorted = ph < 1.0f;                             // wave-uniform; every barrier below is reached by all 8 waves
+    if (sorted && lane == 0) {                                 // candidates: up to and including the first cumsum > p; none -> top 1
+        float cs = sp[h][0];
+        int first = cs > ph ? 0 : -1;
+        for (int i = 1; i < n && first < 0; ++i) { cs = cs + sp[h][i]; if (cs > ph) first = i; }
+        const int k = first < 0 ? 1 : first + 1;
+        float qs = sp[h][0];
+        for (int i = 1; i < k; ++i) qs = qs + sp[h][i];        // np.cumsum(q)[-1]
+        hk[h] = k; hsum[h] = qs;
+    }
+    __syncthreads();
+    if (sorted) {
         const int k = hk[h];
         const float qs = hsum[h];
         for (int i = lane; i < k; i += 64) pn[h][i] = sp[h][i] / qs;                // q (pn is free now)
-        __syncthreads();
-        if (lane == 0) {
-            double cum = 0.0;
-            for (int i = 0; i < k; ++i) { cum += (double)pn[h][i]; cdf[h][i] = cum; }
-        }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (sorted && lane == 0) {
+        const int k = hk[h];
+        double cum = 0.0;
+        for (int i = 0; i < k; ++i) { cum += (double)pn[h][i]; cdf[h][i] = cum; }
+    }
+    __syncthreads();
+    if (sorted) {
+        const int k = hk[h];
         const double last = cdf[h][k - 1], u = a.u[(size_t)pos * 8 + h];
         int best = k - 1;                                      // first index with cdf / cdf[-1] > u
         for (int i = lane; i < k; i += 64) if (cdf[h][i] / last > u) { best = i; break; }
@@ -959,7 +964,6 @@ __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
             const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        __syncthreads(); __syncthreads(); __syncthreads();     // the barriers of the other branch (whole waves take one branch or the other)
         if (lane == 0) htok[h] = bi;
     }
     __syncthreads();

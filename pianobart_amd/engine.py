@@ -28,7 +28,8 @@ _WG_TARGET = 192 if _WGRAD_STREAM & 1 else 256            # split-K work items a
 _NO_DEFER = False                  # settled (round 2): True reduces every bias / LayerNorm gradient right behind its producer
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
 _ROWDOT = int(os.environ.get('PB_ROWDOT', '1'))                                  # 1 = delta of the one-pass attention backward from the out-projection dgrad's epilogue (0: a separate pass)
-_DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop (the persistent-kernel forms of round 4, measured slower, left the library in round 5: tools/decode1/, profiles/r04_decode_persistent.txt)
+_DECODE_SPEC = int(os.environ.get('PB_DECODE_SPEC', '1'))                       # 1 = device-side sampling ahead of the host where the caller names the sampler (Engine._generate_device_sampled), 0 = one host round trip per token
+_DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop (the persistent-kernel forms of round 4, measured slower, left the library in round 5: profiles/r04_decode_persistent.txt)
 _NO_FUSED_BIAS = False             # settled (round 2): True takes the bias gradients out of the GEMM / attention epilogues
 
 LN_EPS = 1e-5
@@ -1260,12 +1261,15 @@ class Engine:
         self._await_updates(2)
 
     # ------------------------------------------------------------------ generate (model.py:28-66)
-    def generate(self, enc_ids, emask, sample_row, use_cache=True):
+    def generate(self, enc_ids, emask, sample_row, use_cache=True, max_new=None, sampler=None):
         """Autoregressive decode with the reference's control flow (SOS start, host-side nucleus sampling, early stop on
         any special token). The reference re-runs encoder AND decoder over all S positions for every generated position
         (model.py:42-45); here the encoder runs once, the cross-attention K/V of every decoder layer are projected once,
         and each step feeds ONE decoder token through the layers against a self-attention K/V cache. Position-i logits
-        only depend on decoder inputs <= i (causal), so the tokens are identical (tests/test_model_gpu.py)."""
+        only depend on decoder inputs <= i (causal), so the tokens are identical (tests/test_model_gpu.py).
+        max_new: stop after that many positions (None = the window). sampler = dict(T=[8 temperatures], P=[8 thresholds]): the caller
+        states that `sample_row` IS model.py:68-107 with these constants, drawing np.random.random_sample(8) per position; the decoder may
+        then sample on the device ahead of the host (`_generate_device_sampled`) -- `sample_row` still decides every token."""
         self._await_updates(2)
         if not use_cache:
             return self._generate_nocache(enc_ids, emask, sample_row)
@@ -1335,6 +1339,14 @@ class Engine:
             rc_dec = int(LIB.query('pb_decoder_create', pref, ctypes.byref(dec))) if (_DECODE_GRAPH >= 0 and _DECODE_SPLIT) else 1
             if rc_dec < 0:                                              # 1 = the fused kernels do not cover this shape (the loop below does); < 0 is an error
                 raise PBError('pb_decoder_create failed (%d): %s' % (rc_dec, LIB.load().pb_last_error().decode()))
+            if rc_dec == 0 and sampler is not None and _DECODE_SPEC:
+                try:
+                    LIB.call('pb_decoder_reset', dec, stream, _DECODE_GRAPH)
+                    torch.cuda.current_stream().synchronize()
+                    self._generate_device_sampled(dec, sample_row, sampler, S, s_enc, res_cpu, pad_cpu, max_new)
+                finally:
+                    LIB.call('pb_decoder_destroy', dec)
+                return res_cpu.to(dev).unsqueeze(0)
             if rc_dec == 0:
                 try:
                     LIB.call('pb_decoder_reset', dec, stream, _DECODE_GRAPH)
@@ -1344,7 +1356,7 @@ class Engine:
                     n = 0
                     torch.cuda.current_stream().synchronize()           # the prompt's encoder pass: not part of the per-token time below
                     t_loop = time.perf_counter()
-                    for i in range(S):
+                    for i in range(S if max_new is None else min(S, max_new)):
                         LIB.call('pb_decoder_step', dec, tok_p, log_p)
                         n += 1
                         tok = sample_row(logit_cpu)
@@ -1370,6 +1382,70 @@ class Engine:
                 tok16.copy_(tok_pin, non_blocking=True)                     # stream-ordered before the next step's kernels
             result = res_cpu.to(dev).unsqueeze(0)
         return result
+
+    def _generate_device_sampled(self, dec, sample_row, sampler, S, s_enc, res_cpu, pad_cpu, max_new):
+        """The decode loop without a host round trip per token (round 6). The 8 uniform draws of a position do not depend on its logits
+        (np.random.choice inside nucleus(), model.py:97), so all S x 8 are drawn AHEAD from a copy of the global RNG state and uploaded;
+        the device then samples each position itself (pb_decoder_sampler_init: model.py:68-107 in pb_nucleus_rows' arithmetic order) and
+        runs on, 8 tokens per hipGraph replay, two runs in flight. The host follows one run behind: for every position it calls
+        `sample_row` on the logged logits row -- the reference code path, consuming the GLOBAL RNG exactly as the per-token loop did, so
+        np.random.get_state() ends where the reference's does -- and compares with the ids the device chose. They differ only where the
+        device's softmax rounding (1 ulp against torch's CPU softmax) crosses a threshold or a tie; then the decoder is rewound to that
+        position with the host's token and everything decoded behind it is discarded. The result is the host's, token for token."""
+        import ctypes
+        from collections import deque
+        K, vocab = 8, ops.VOCAB
+        limit = S if max_new is None else max(0, min(S, int(max_new)))
+        state = np.random.get_state()
+        ahead = np.random.RandomState()
+        ahead.set_state(state)
+        U = np.ascontiguousarray(ahead.random_sample(S * 8))
+        n8 = np.asarray([ops.SEG_OFF[j + 1] - ops.SEG_OFF[j] for j in range(8)], dtype=np.int32)
+        off8 = np.asarray(ops.SEG_OFF[:8], dtype=np.int32)
+        t8, p8 = np.asarray(sampler['T'], dtype=np.float32), np.asarray(sampler['P'], dtype=np.float32)
+        fault = int(getattr(self, 'decode_fault_period', 0) or 0)                # tests: the device's choice is corrupted at every fault-th position
+        LIB.call('pb_decoder_sampler_init', dec, t8.ctypes.data, p8.ctypes.data, n8.ctypes.data, off8.ctypes.data, U.ctypes.data, S * 8, fault)
+        lp, tp = ctypes.c_void_p(), ctypes.c_void_p()
+        LIB.call('pb_decoder_logs', dec, ctypes.byref(lp), ctypes.byref(tp))
+        log_logits = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * (S * vocab)).from_address(lp.value)).reshape(S, vocab))
+        log_tok = np.ctypeslib.as_array((ctypes.c_int16 * (S * 8)).from_address(tp.value)).reshape(S, 8)
+        first = np.asarray(self.pb.sos_word_np, dtype=np.int16).copy()
+        runs, enq, n, rewinds, stop = deque(), 0, 0, 0, False
+
+        def launch(tok=None):
+            nonlocal enq
+            cnt = min(K, limit - enq)
+            tk = int(LIB.query('pb_decoder_launch', dec, cnt, None if tok is None else tok.ctypes.data))
+            if tk < 0:
+                raise PBError('pb_decoder_launch failed (%d): %s' % (tk, LIB.load().pb_last_error().decode()))
+            runs.append((tk, enq, cnt))
+            enq += cnt
+
+        t_loop = time.perf_counter()
+        if limit > 0:
+            launch(first)
+        while not stop and (runs or enq < limit):
+            while len(runs) < 2 and enq < limit:
+                launch()
+            tk, start, cnt = runs.popleft()
+            LIB.call('pb_decoder_wait', dec, tk)
+            for i in range(start, start + cnt):
+                tok = sample_row(log_logits[i])
+                n += 1
+                if (tok >= pad_cpu).any():
+                    stop = True
+                    break
+                res_cpu[i] = tok
+                t16 = tok.numpy().astype(np.int16)
+                if not np.array_equal(t16, log_tok[i]):                  # the device chose another id here: its later positions are void
+                    rewinds += 1
+                    LIB.call('pb_decoder_seek', dec, i, t16.ctypes.data)
+                    runs.clear()
+                    enq = i + 1
+                    break
+        self.last_decode = dict(launches_per_token=int(LIB.query('pb_decoder_launches', dec)), graph=bool(LIB.query('pb_decoder_graph', dec)),
+                                tokens=n, loop_ms=(time.perf_counter() - t_loop) * 1e3, s_enc=s_enc, device_sampler=True, rewinds=rewinds,
+                                tokens_per_graph_replay=K)
 
     def _generate_pyloop(self, enc_ids, emask, sample_row):
         """KV-cached decode sequenced from Python with the training kernels (M = 1 GEMMs, flash attention with one query):

@@ -348,7 +348,7 @@ class PianoBartLM(nn.Module):
         if input_ids_encoder.shape[0] != 1:
             print("ERROR")
             exit(-1)
-        out = eng.generate(input_ids_encoder, encoder_attention_mask, self.sample_row)
+        out = eng.generate(input_ids_encoder, encoder_attention_mask, self.sample_row, sampler=dict(T=self.SAMPLE_T, P=self.SAMPLE_P))
         # model.py:33-36: the result lives on `cuda:device_num`, or on the CPU for device_num == -1
         return out.cpu() if device_num == -1 else out.to(torch.device('cuda', device_num))
 

@@ -427,6 +427,9 @@ def pretrain(argv=None):
     if args.resume:
         first_epoch, best_acc = trainer.resume(args.resume)
         print("   resumed from {} at epoch {} (best_acc {})".format(args.resume, first_epoch, best_acc))
+        log_path = os.path.join(run.dir, 'log')
+        if os.path.exists(log_path) and not open(log_path).read().endswith('\n'):
+            run.write('\n')                                    # the closing line of the earlier run has no newline (main.py:97-99)
     start_t = time.time()
     for epoch in range(first_epoch, args.epochs):
         if stale >= 30:

@@ -17,7 +17,7 @@ def test_header_parses_and_library_exports_all():
     dll = ctypes.CDLL(_lib.LIB_PATH)
     for name in decls:
         assert hasattr(dll, name), 'library does not export %s' % name
-    assert _lib.LIB.query('pb_abi_version') == 7
+    assert _lib.LIB.query('pb_abi_version') == 8
     assert _lib.LIB.query('pb_ln_partials_floats', 768) == 512 * 3 * 768
 
 

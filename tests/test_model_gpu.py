@@ -784,3 +784,52 @@ def test_graph_decode_equals_the_per_launch_decode(monkeypatch, d, heads, S):
     # a second prompt through a fresh decoder of the same engine: nothing is left over from the first
     g2, _ = run(1)
     assert all(torch.equal(a, b) for a, b in zip(g, g2))
+
+
+@pytest.mark.parametrize('d,heads,S,sharp', [(256, 4, 200, 1.0), (768, 12, 130, 1.0), (512, 8, 72, 40.0), (1024, 8, 40, 8.0)])
+def test_device_sampled_decode_emits_the_host_loops_tokens(monkeypatch, d, heads, S, sharp):
+    """Round 6: model.py:68-107 sampled on the device ahead of the host (8 tokens per graph replay, uniform draws of the whole prompt uploaded
+    once), the host following behind through the logged logits rows with the reference code path. Against the per-token host loop
+    (PB_DECODE_SPEC=0) on the same prompt and RNG seed: the same tokens, the same early stop, the same np.random state afterwards -- with flat
+    distributions (random weights: ~230 candidates under the p = 0.9 heads) and peaked ones (LM head scaled up), with `max_new`, and with
+    the device's choice corrupted at every 7th position (decode_fault_period: the rewind path must restore the host's sequence)."""
+    _need_gpu()
+    from pianobart_amd import engine as E
+    m = _lm(S, d, 2, 512, heads, 31, 'bf16').eval()
+    with torch.no_grad():
+        for i, p0 in enumerate([256, 128, 129, 256, 128, 32, 254, 49]):
+            m.mask_lm.proj[i].weight.mul_(sharp)
+            m.mask_lm.proj[i].bias[p0 + 3:] = -30.0                # EOS stays reachable: some runs stop early by themselves
+            m.mask_lm.proj[i].bias[p0:p0 + 3] = -30.0
+    m = m.cuda()
+    enc = synth_octuple_batch(1, S, seed=8, min_len=S - 9)[5].cuda()
+    emask = (enc[:, :, 0] != 256).float()
+    eng = m._get_engine()
+    sampler = dict(T=m.SAMPLE_T, P=m.SAMPLE_P)
+
+    def run(spec, fault=0, max_new=None, seed=5):
+        monkeypatch.setattr(E, '_DECODE_SPEC', spec)
+        eng.decode_fault_period = fault
+        np.random.seed(seed)
+        out = eng.generate(enc, emask, m.sample_row, max_new=max_new, sampler=sampler)
+        return out.cpu(), np.random.get_state()[1].copy(), dict(eng.last_decode)
+
+    want, st_w, info_w = run(0)
+    got, st_g, info_g = run(1)
+    assert not info_w.get('device_sampler') and info_g['device_sampler'] and info_g['graph']
+    assert info_g['launches_per_token'] == 6 * 2 + 3 and info_g['tokens'] == info_w['tokens']
+    assert torch.equal(got, want) and np.array_equal(st_g, st_w)
+    assert info_g['rewinds'] <= 2, info_g                              # the device's own choice is (almost) always the host's
+    got_f, st_f, info_f = run(1, fault=7)
+    assert torch.equal(got_f, want) and np.array_equal(st_f, st_w)
+    assert info_f['rewinds'] >= min(info_w['tokens'], S) // 7 - 1 and info_f['rewinds'] > 0, info_f
+    for cut in (1, 8, 13):
+        a, sa, ia = run(0, max_new=cut, seed=9)
+        b, sb, ib = run(1, max_new=cut, seed=9)
+        assert torch.equal(a, b) and np.array_equal(sa, sb) and ia['tokens'] == ib['tokens'] <= cut
+    eng.decode_fault_period = 0
+    # through the module surface (PianoBartLM.forward(generate=True)): the sampler is named there, so this is the default path
+    monkeypatch.setattr(E, '_DECODE_SPEC', 1)
+    np.random.seed(5)
+    y = m(enc, None, emask, None, generate=True, device_num=-1)
+    assert torch.equal(y, want) and eng.last_decode['device_sampler']
