@@ -501,6 +501,19 @@ def other_instantiations(args, cfgkw, dev):
                                            "model shape as the headline, B = 4, padded rows (the packed step is bf16-only), 3 steps"}
     except Exception as ex:                                            # noqa: BLE001
         out["fp32_parity_step"] = {"error": repr(ex)[:200]}
+    try:
+        for B3 in (4, 16):
+            ms, fl, rows = side_model_step(cfgkw, 'bf16x3', B3, args.seq, dev, 3)
+            key = "bf16x3_parity_step" if B3 == 4 else "bf16x3_parity_step_b%d" % B3
+            out[key] = {"ms_per_step": ms, "batch": B3, "tokens_per_s": B3 * args.seq / (ms * 1e-3), "rows": rows,
+                        "step_tflops_algorithmic": fl / (ms * 1e-3) / 1e12, "frac_of_bf16_mfma_peak_algorithmic": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                        "note": "precision='bf16x3': f32 storage and row kernels, every GEMM as split-bf16 triples (a_hi b_hi + a_hi b_lo + a_lo b_hi, f32 "
+                                "accumulate) on the bf16 MFMA -- 3x the matrix work per algorithmic FLOP; logits within 1e-3 of the CPU reference "
+                                "(tests/test_model_gpu.py: G1, G4, G10); same model shape, padded rows, unfused attention, 3 steps"}
+        if "ms_per_step" in out.get("fp32_parity_step", {}):
+            out["bf16x3_parity_step"]["speedup_over_fp32_parity_step"] = out["fp32_parity_step"]["ms_per_step"] / out["bf16x3_parity_step"]["ms_per_step"]
+    except Exception as ex:                                            # noqa: BLE001
+        out.setdefault("bf16x3_parity_step", {"error": repr(ex)[:200]})
     if args.precision == 'bf16' and (args.layers, args.hs, args.seq) == (12, 768, 1024):
         try:
             kw5 = dict(max_position_embeddings=2048, d_model=1024, encoder_layers=24, decoder_layers=24, encoder_ffn_dim=4096, decoder_ffn_dim=4096,
@@ -614,7 +627,7 @@ def main():
     ap.add_argument('--hs', type=int, default=768)
     ap.add_argument('--ffn', type=int, default=3072)
     ap.add_argument('--heads', type=int, default=12)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dropout', action='store_true')
     ap.add_argument('--no-probe', action='store_true', help='skip the per-family in-step timing that follows the timed region')

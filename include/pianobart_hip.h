@@ -19,8 +19,11 @@ extern "C" {
 
 #define PB_F32 0
 #define PB_BF16 1
+#define PB_F32X3 2   /* pb_gemm only (ABI 8): f32 operands, f32 C and aux, the products as split-bf16 triples a_hi b_hi + a_hi b_lo + a_lo b_hi on the
+                        bf16 matrix cores with f32 accumulation (~2^-16 relative per product): the parity-grade instantiation that is not bound by
+                        the f32-input MFMA rate (precision="bf16x3"); every other op of that instantiation runs its PB_F32 form */
 
-#define PB_ABI_VERSION 8   /* 8 (round 6): + pb_decoder_sampler_init / launch / wait / logs / seek (device-sampled decode); 7 (round 5): + PB_GEMM_ROWDOT / rowdot_out in pb_gemm_desc, delta_rows in pb_flash_bwd1*; 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
+#define PB_ABI_VERSION 8   /* 8 (round 6): + pb_decoder_sampler_init / launch / wait / logs / seek (device-sampled decode), dtype PB_F32X3 in pb_gemm; 7 (round 5): + PB_GEMM_ROWDOT / rowdot_out in pb_gemm_desc, delta_rows in pb_flash_bwd1*; 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
 int pb_abi_version(void);
 const char* pb_last_error(void);
 

@@ -13,7 +13,7 @@ HEADER = os.path.join(os.path.dirname(HERE), 'include', 'pianobart_hip.h')
 # PB_LIB_PATH: developer aid for same-box A/B runs of two builds of the library (box-to-box spread on the pool is +-3 %)
 LIB_PATH = os.environ.get('PB_LIB_PATH') or os.path.join(HERE, 'libpianobart_hip.so')
 
-PB_F32, PB_BF16 = 0, 1
+PB_F32, PB_BF16, PB_F32X3 = 0, 1, 2
 GEMM_ACCUM, GEMM_C_F32, GEMM_GELU, GEMM_MUL_GELU_GRAD = 1, 2, 4, 8
 GEMM_ROWDOT = 131072
 

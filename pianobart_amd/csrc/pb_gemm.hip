@@ -310,7 +310,7 @@ static int colsum_of_c(const pb_gemm_desc* d, void* stream_) {
 extern "C" int pb_gemm(const pb_gemm_desc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PB_REQUIRE(d != nullptr, "pb_gemm: null descriptor");
-    PB_REQUIRE(d->dtype == PB_F32 || d->dtype == PB_BF16, "pb_gemm: bad dtype %d", d->dtype);
+    PB_REQUIRE(d->dtype == PB_F32 || d->dtype == PB_BF16 || d->dtype == PB_F32X3, "pb_gemm: bad dtype %d", d->dtype);
     PB_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "pb_gemm: negative size");
     if (d->M == 0 || d->N == 0) return 0;
     PB_REQUIRE(d->A && d->B && d->C, "pb_gemm: null operand");
@@ -318,6 +318,7 @@ extern "C" int pb_gemm(const pb_gemm_desc* d, void* stream_) {
     PB_REQUIRE(!(d->flags & PB_GEMM_MUL_GELU_GRAD) || d->aux_in, "pb_gemm: gelu-grad epilogue needs aux_in");
     const int nbt = (d->nb1 > 0 ? d->nb1 : 1) * (d->nb2 > 0 ? d->nb2 : 1);
     PB_REQUIRE(!d->colsum_out || (d->colsum_ws && nbt == 1 && d->ldc == d->N), "pb_gemm: colsum_out needs colsum_ws, one batch and a dense C");
+    if (d->dtype == PB_F32X3) return pb_gemm_x3(d, stream_);        // f32 operands as bf16 triples on the bf16 kernels (pb_gemm_x3.hip)
     if (!(d->flags & PB_GEMM_FORCE_V1)) {
         const int r2 = pb_gemm2_try(d, stream_);     // 0: done (column sums included), 2: done but the column sums are still owed, 1: declined
         if (r2 < 0) return r2;

@@ -44,7 +44,7 @@ def get_args(argv=None):
     ap.add_argument('--nopretrain', action='store_true', default=False)
     ap.add_argument('--cpu', action='store_true')
     ap.add_argument('--cuda_devices', type=int, nargs='+', default=[0], help='HIP device ids (one: generate is batch-1 sequential)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
     return ap.parse_args(argv)
 
 

@@ -20,7 +20,7 @@ import torch
 
 from . import ops, rowpack
 
-from ._lib import LIB, PB_BF16, PB_F32, PBError
+from ._lib import LIB, PB_BF16, PB_F32, PB_F32X3, PBError
 
 _WGRAD_STREAM = int(os.environ.get('PB_WGRAD_STREAM', '7'))            # second HIP stream, bits: 1 = weight-gradient GEMMs, 2 = cross-attention K/V projections, 4 = backward GEMMs as ordinary grids (0: everything on one stream, for A/B)
 _WG_DXD_256 = int(os.environ.get('PB_WG_DXD_256', '1'))                         # the d x d weight gradients on the 256x256 ping-pong kernel (9 tiles x split-K 21) instead of 128x128 tiles (36 x 14); same-box A/B round 5: 58.01 / 58.01 -> 57.83 / 57.62 ms (profiles/r05_dxd_wgrad_ab.txt); 0 = the round-2 choice
@@ -86,8 +86,8 @@ class _Slot:
 
 class Engine:
     def __init__(self, pianobart, mask_lm, precision='bf16'):
-        if precision not in ('bf16', 'fp32'):
-            raise PBError('precision must be "bf16" or "fp32"')
+        if precision not in ('bf16', 'fp32', 'bf16x3'):
+            raise PBError('precision must be "bf16", "fp32" or "bf16x3"')
         self.pb, self.mlm = pianobart, mask_lm
         for mod in (pianobart, mask_lm):
             if mod is not None and hasattr(mod, 'register_state_dict_pre_hook'):         # a checkpoint must not read parameters a pipelined update is still writing
@@ -95,6 +95,12 @@ class Engine:
         self.precision = precision
         self.code = PB_BF16 if precision == 'bf16' else PB_F32
         self.xdt = torch.bfloat16 if precision == 'bf16' else torch.float32
+        # "bf16x3" (round 6): the exact-f32 instantiation -- f32 storage, f32 LayerNorm / softmax / loss / dropout kernels, unfused attention --
+        # with every GEMM handed to pb_gemm as PB_F32X3: f32 operands cut into bf16 (hi, lo) pairs, a_hi b_hi + a_hi b_lo + a_lo b_hi on
+        # the bf16 matrix cores with f32 accumulation (pb_gemm_x3.hip). ~2^-16 per product instead of bf16's 2^-8: the parity-grade
+        # instantiation (logits <= 1e-3 of the CPU reference, north_star) that does not run at the f32-input MFMA rate.
+        self.x3 = precision == 'bf16x3'
+        self.gcode = PB_F32X3 if self.x3 else self.code
         cfg = pianobart.bartConfig
         self.cfg = cfg
         self.d = cfg.d_model
@@ -386,7 +392,7 @@ class Engine:
     # ------------------------------------------------------------------ building blocks
     def _linear(self, x, wname, bname, out, M, N, K, **kw):
         # forward GEMMs run alone on their stream (nothing fills a partly filled last round of the persistent grid): allow the tail split
-        ops.gemm(x, self.w[wname], out, M=M, N=N, K=K, dtype=self.code, bias=self.wf[bname] if bname else None, dbg=_FWD_GEMM_FLAGS, **kw)
+        ops.gemm(x, self.w[wname], out, M=M, N=N, K=K, dtype=self.gcode, bias=self.wf[bname] if bname else None, dbg=_FWD_GEMM_FLAGS, **kw)
 
     def _attn_fwd(self, q, k, v, out, key_mask, causal, B, Sq, Sk, save, rows=None):
         """q,k,v,out: (tensor, elem offset, row stride). Unfused form: QK^T -> masked softmax -> PV. rows: packed-row descriptors."""
@@ -402,10 +408,10 @@ class Engine:
             return
         scores, P = ws['scores'], save['P']
         (qt, qo, ql), (kt, ko, kl), (vt, vo, vl), (ot, oo, ol) = q, k, v, out
-        ops.gemm(qt, kt, scores, M=Sq, N=Sk, K=hd, dtype=self.code, lda=ql, ldb=kl, ldc=Sk, c_f32=True, nb1=B, nb2=H,
+        ops.gemm(qt, kt, scores, M=Sq, N=Sk, K=hd, dtype=self.gcode, lda=ql, ldb=kl, ldc=Sk, c_f32=True, nb1=B, nb2=H,
                  sA=(Sq * ql, hd), sB=(Sk * kl, hd), sC=(H * Sq * Sk, Sq * Sk), a_off=qo, b_off=ko)
         ops.softmax_fwd(scores, key_mask, P, B, H, Sq, Sk, hd ** -0.5, causal)
-        ops.gemm(P, vt, ot, M=Sq, N=hd, K=Sk, dtype=self.code, b_kc=False, lda=Sk, ldb=vl, ldc=ol, nb1=B, nb2=H,
+        ops.gemm(P, vt, ot, M=Sq, N=hd, K=Sk, dtype=self.gcode, b_kc=False, lda=Sk, ldb=vl, ldc=ol, nb1=B, nb2=H,
                  sA=(H * Sq * Sk, Sq * Sk), sB=(Sk * vl, hd), sC=(Sq * ol, hd), b_off=vo, c_off=oo)
 
     def _one_pass_bwd(self, causal, rows, B, Sq, Sk, q_rows):
@@ -451,14 +457,14 @@ class Engine:
         (dot, doo, dol) = dout
         (dqt, dqo, dql), (dkt, dko, dkl), (dvt, dvo, dvl) = dq, dk, dv
         bs = (H * Sq * Sk, Sq * Sk)
-        ops.gemm(dot, vt, dP, M=Sq, N=Sk, K=hd, dtype=self.code, lda=dol, ldb=vl, ldc=Sk, c_f32=True, nb1=B, nb2=H,
+        ops.gemm(dot, vt, dP, M=Sq, N=Sk, K=hd, dtype=self.gcode, lda=dol, ldb=vl, ldc=Sk, c_f32=True, nb1=B, nb2=H,
                  sA=(Sq * dol, hd), sB=(Sk * vl, hd), sC=bs, a_off=doo, b_off=vo)
         ops.softmax_bwd(dP, P, dS, B * H * Sq, Sk, hd ** -0.5)
-        ops.gemm(dS, kt, dqt, M=Sq, N=hd, K=Sk, dtype=self.code, b_kc=False, lda=Sk, ldb=kl, ldc=dql, nb1=B, nb2=H,
+        ops.gemm(dS, kt, dqt, M=Sq, N=hd, K=Sk, dtype=self.gcode, b_kc=False, lda=Sk, ldb=kl, ldc=dql, nb1=B, nb2=H,
                  sA=bs, sB=(Sk * kl, hd), sC=(Sq * dql, hd), b_off=ko, c_off=dqo)
-        ops.gemm(dS, qt, dkt, M=Sk, N=hd, K=Sq, dtype=self.code, a_kc=False, b_kc=False, lda=Sk, ldb=ql, ldc=dkl, nb1=B, nb2=H,
+        ops.gemm(dS, qt, dkt, M=Sk, N=hd, K=Sq, dtype=self.gcode, a_kc=False, b_kc=False, lda=Sk, ldb=ql, ldc=dkl, nb1=B, nb2=H,
                  sA=bs, sB=(Sq * ql, hd), sC=(Sk * dkl, hd), b_off=qo, c_off=dko)
-        ops.gemm(P, dot, dvt, M=Sk, N=hd, K=Sq, dtype=self.code, a_kc=False, b_kc=False, lda=Sk, ldb=dol, ldc=dvl, nb1=B, nb2=H,
+        ops.gemm(P, dot, dvt, M=Sk, N=hd, K=Sq, dtype=self.gcode, a_kc=False, b_kc=False, lda=Sk, ldb=dol, ldc=dvl, nb1=B, nb2=H,
                  sA=bs, sB=(Sq * dol, hd), sC=(Sk * dvl, hd), b_off=doo, c_off=dvo)
         return False
 
@@ -544,7 +550,7 @@ class Engine:
         kv_cut = min(_KV_CUT, self.ND)
 
         def kv_project(l0, l1):
-            ops.gemm(enc_out, self.w['dec.wkv_all'], ws['kvc_all'], M=Te, N=(l1 - l0) * 2 * d, K=d, dtype=self.code, bias=self.wf['dec.bkv_all'][l0 * 2 * d:],
+            ops.gemm(enc_out, self.w['dec.wkv_all'], ws['kvc_all'], M=Te, N=(l1 - l0) * 2 * d, K=d, dtype=self.gcode, bias=self.wf['dec.bkv_all'][l0 * 2 * d:],
                      ldc=kvld, b_off=l0 * 2 * d * d, c_off=l0 * 2 * d, dbg=_FWD_GEMM_FLAGS)
         kv_ready = None
         if (_WGRAD_STREAM & 2) and self._side_stream() is not None and self.ND:
@@ -596,14 +602,14 @@ class Engine:
         ws = self._cur_ws
         T = dec_hidden.shape[0]
         logits = ws['logits'][:T]
-        ops.gemm(dec_hidden, self.w['head.w'], logits, M=T, N=ops.VOCAB, K=self.d, dtype=self.code, bias=self.wf['head.b'], c_f32=True)
+        ops.gemm(dec_hidden, self.w['head.w'], logits, M=T, N=ops.VOCAB, K=self.d, dtype=self.gcode, bias=self.wf['head.b'], c_f32=True)
         return logits
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dy, x, gname, M, N, T, ldy=None, ldx=None, dy_off=0, x_off=0, g_off=0):
         """G[gname] (M,N) = dy(T,M)^T @ x(T,N)  (TN GEMM into the f32 gradient buffer)."""
         nsplit, slabs, big = 1, None, False
-        if self.code == PB_BF16 and T % 64 == 0:
+        if (self.code == PB_BF16 or self.x3) and T % 64 == 0:
             big = M >= 256 and N >= 256 and (M * N > 768 * 768 or _WG_DXD_256)     # 256x256 tiles, one block per CU (768x768: 128x128 tiles measured 712 vs 636 TF)
             tl = 256 if big else 128
             tiles = ((M + tl - 1) // tl) * ((N + tl - 1) // tl)
@@ -614,7 +620,7 @@ class Engine:
                     self._join_side()
                     self._slabs = torch.empty(need, dtype=torch.float32, device=self.device)
                 slabs = self._slabs
-        launch = lambda dbg: ops.gemm(dy, x, self.g[gname], M=M, N=N, K=T, dtype=self.code, a_kc=False, b_kc=False, lda=ldy or M, ldb=ldx or N, ldc=N,
+        launch = lambda dbg: ops.gemm(dy, x, self.g[gname], M=M, N=N, K=T, dtype=self.gcode, a_kc=False, b_kc=False, lda=ldy or M, ldb=ldx or N, ldc=N,
                                       c_f32=True, a_off=dy_off, b_off=x_off, c_off=g_off, splitk=nsplit, slabs=slabs, tile256=big, dbg=dbg)
         if not (_WGRAD_STREAM & 1) or self._side_stream() is None:
             return launch(self._bwd_dbg())
@@ -710,9 +716,9 @@ class Engine:
         self._before_write(out)
         wT = self.wT.get(wname)
         if wT is not None:                                        # W^T (N,K): both operands K-contiguous
-            ops.gemm(dy, wT, out, M=T, N=N, K=K, dtype=self.code, lda=ldy or K, ldb=K, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
+            ops.gemm(dy, wT, out, M=T, N=N, K=K, dtype=self.gcode, lda=ldy or K, ldb=K, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
             return
-        ops.gemm(dy, self.w[wname], out, M=T, N=N, K=K, dtype=self.code, b_kc=False, lda=ldy or K, ldb=N, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
+        ops.gemm(dy, self.w[wname], out, M=T, N=N, K=K, dtype=self.gcode, b_kc=False, lda=ldy or K, ldb=N, ldc=N, accum=accum, dbg=self._bwd_dbg(), **kw)
 
     def _cs_ws(self, M, N):
         need = int(LIB.query('pb_gemm_colsum_ws_floats', M, N))
@@ -1482,8 +1488,8 @@ class Engine:
                 for l in range(self.ND):
                     pf = 'dec.%d.' % l
                     wqkv, bqkv = self.w[pf + 'wqkv'], wf[pf + 'bqkv']
-                    ops.gemm(h, wqkv, q, M=1, N=d, K=d, dtype=self.code, bias=bqkv[:d])
-                    ops.gemm(h, wqkv, kvs[l], M=1, N=2 * d, K=d, dtype=self.code, bias=bqkv[d:], b_off=d * d, c_off=i * 2 * d)
+                    ops.gemm(h, wqkv, q, M=1, N=d, K=d, dtype=self.gcode, bias=bqkv[:d])
+                    ops.gemm(h, wqkv, kvs[l], M=1, N=2 * d, K=d, dtype=self.gcode, bias=bqkv[d:], b_off=d * d, c_off=i * 2 * d)
                     self._attn_fwd((q, 0, d), (kvs[l], 0, 2 * d), (kvs[l], d, 2 * d), (ctx, 0, d), None, False, 1, 1, i + 1, save)
                     self._linear(ctx, pf + 'wo', pf + 'bo', a, 1, d, d)
                     ops.add_ln_fwd(h, a, wf[pf + 'ln1.w'], wf[pf + 'ln1.b'], y1, mr[2:3], mr[3:4], LN_EPS, 0, 0, 0.0)
@@ -1496,7 +1502,7 @@ class Engine:
                     out = y2 if h is not y2 else x
                     ops.add_ln_fwd(yc, a, wf[pf + 'ln2.w'], wf[pf + 'ln2.b'], out, mr[6:7], mr[7:8], LN_EPS, 0, 0, 0.0)
                     h = out
-                ops.gemm(h, self.w['head.w'], logits, M=1, N=ops.VOCAB, K=d, dtype=self.code, bias=wf['head.b'], c_f32=True)
+                ops.gemm(h, self.w['head.w'], logits, M=1, N=ops.VOCAB, K=d, dtype=self.gcode, bias=wf['head.b'], c_f32=True)
                 tok = sample_row(logits[0].cpu())
                 if (tok >= pad_cpu).any():
                     break

@@ -43,7 +43,7 @@ def get_args_finetune(argv=None):
     parser.add_argument('--cuda_devices', type=int, nargs='+', default=[2, 5, 6], help='CUDA device ids')
     parser.add_argument('--weight', type=float, default=None, help='weight of regularization')
     parser.add_argument('--error_correction', action='store_true')
-    parser.add_argument('--precision', choices=['bf16', 'fp32'], default='bf16', help='backbone arithmetic (not in the reference)')
+    parser.add_argument('--precision', choices=['bf16', 'fp32', 'bf16x3'], default='bf16', help='backbone arithmetic (not in the reference)')
     args = parser.parse_args(argv)
     if args.class_num is None:
         args.class_num = {'melody': 4, 'velocity': 7, 'composer': 8, 'emotion': 4}[args.task]

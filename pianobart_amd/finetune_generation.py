@@ -46,7 +46,7 @@ def get_args_generation(argv=None):
     parser.add_argument("--cpu", action="store_true")
     parser.add_argument("--cuda_devices", type=int, nargs='+', default=[0], help="HIP device ids (one per process)")
     parser.add_argument("--eval", action="store_true")
-    parser.add_argument('--precision', choices=['bf16', 'fp32'], default='bf16', help='backbone arithmetic (not in the reference)')
+    parser.add_argument('--precision', choices=['bf16', 'fp32', 'bf16x3'], default='bf16', help='backbone arithmetic (not in the reference)')
     return parser.parse_args(argv)
 
 

@@ -162,7 +162,8 @@ def _check_cfg(cfg):
 
 
 class PianoBart(nn.Module):
-    """PianoBart.py:19-91. `precision`: "bf16" (throughput, bf16 MFMA) or "fp32" (exact-f32 parity path)."""
+    """PianoBart.py:19-91. `precision`: "bf16" (throughput, bf16 MFMA), "fp32" (exact-f32 parity path) or "bf16x3" (f32 storage and row
+    kernels, every GEMM as split-bf16 triples on the bf16 matrix cores: parity-grade at a multiple of the f32-MFMA rate)."""
 
     def __init__(self, bartConfig, e2w, w2e, precision='bf16'):
         super().__init__()

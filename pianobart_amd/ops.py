@@ -6,7 +6,7 @@ import os
 
 import torch
 
-from ._lib import (LIB, PB_BF16, PB_F32, GemmDesc, PBError, GEMM_ACCUM, GEMM_C_F32, GEMM_GELU,
+from ._lib import (LIB, PB_BF16, PB_F32, PB_F32X3, GemmDesc, PBError, GEMM_ACCUM, GEMM_C_F32, GEMM_GELU,
                    GEMM_MUL_GELU_GRAD, GEMM_ROWDOT)
 
 SEG_SIZES = [262, 134, 135, 262, 134, 38, 260, 55]          # PianoBart.classes order

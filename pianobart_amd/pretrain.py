@@ -55,7 +55,7 @@ def get_args_pretrain(argv=None):
     parser.add_argument("--cpu", action="store_true")
     parser.add_argument("--cuda_devices", type=int, nargs='+', default=[0], help="HIP device ids (one per process)")
     # build-only additions (absent from the reference)
-    parser.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'fp32'])
+    parser.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
     parser.add_argument('--data_root', type=str, default='Data/output_pretrain')
     parser.add_argument('--quiet', action='store_true', help='do not print the two per-step Loss/Acc lines')
     parser.add_argument('--resume', type=str, default='', help='continue from a checkpoint THIS driver wrote: weights, LM heads, AdamW moments and step, epoch, best_acc')

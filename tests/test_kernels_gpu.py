@@ -711,3 +711,72 @@ def test_one_pass_backward_masked_keys_with_a_very_negative_log_sum_exp(ops):
     err = float((dbuf.double() - bd.grad).abs().max() / bd.grad.abs().max())
     assert err < 8e-2, err             # measured 4.5e-2: at |score| ~ 110 the bf16 rounding of the prescaled K alone moves an exponent by ~0.2
     assert float(dbuf[..., d:].double()[(km == 0)[..., None].expand(B, S, 2 * d)].abs().max()) == 0.0     # masked keys: zero dK / dV rows
+
+
+@pytest.mark.parametrize('M,N,K,akc,bkc', [(512, 384, 256, True, True), (300, 136, 96, True, True), (2048, 768, 768, True, False), (768, 3072, 4096, False, False),
+                                           (264, 72, 40, False, True), (1024, 1280, 768, True, True)])
+def test_gemm_f32x3_against_fp64(ops, M, N, K, akc, bkc):
+    """PB_F32X3 (round 6): f32 operands as split-bf16 triples on the bf16 kernels, f32 C. Against fp64: ~1e-5 of the output scale (the exact-f32
+    kernel gives ~1e-6, the bf16 one ~4e-3), for both operand layouts, ragged sizes (K segments are zero-padded to 64), bias / alpha / accumulate,
+    the GELU pair and the multiply by a stored derivative (f32 aux tensors), column sums, and split-K into slabs."""
+    g = torch.Generator(device='cuda').manual_seed(M + 3 * N + K)
+    rn = lambda *s_: torch.randn(*s_, device='cuda', generator=g)
+    A = rn(M, K) if akc else rn(K, M)
+    B = rn(N, K) if bkc else rn(K, N)
+    bias = rn(N)
+    ref = (A.double() if akc else A.double().t()) @ (B.double().t() if bkc else B.double())
+    scale = float(ref.abs().max())
+    X3 = ops.PB_F32X3
+    C = torch.full((M, N), float('nan'), device='cuda')
+    ops.gemm(A, B, C, M=M, N=N, K=K, dtype=X3, a_kc=akc, b_kc=bkc, c_f32=True)
+    e_plain = float((C.double() - ref).abs().max()) / scale
+    Cb = torch.empty_like(C)
+    ops.gemm(A.to(torch.bfloat16), B.to(torch.bfloat16), Cb, M=M, N=N, K=K, dtype=ops.PB_BF16, a_kc=akc, b_kc=bkc, c_f32=True)
+    e_bf16 = float((Cb.double() - ref).abs().max()) / scale
+    print('f32x3 %dx%dx%d: %.2e of max (bf16 operands: %.2e)' % (M, N, K, e_plain, e_bf16))
+    assert e_plain < 2e-5 and e_plain * 50 < e_bf16
+    C2 = torch.ones(M, N, device='cuda')
+    ops.gemm(A, B, C2, M=M, N=N, K=K, dtype=X3, a_kc=akc, b_kc=bkc, c_f32=True, bias=bias, alpha=0.5, accum=True)
+    want = 1.0 + 0.5 * ref + bias.double()
+    assert float((C2.double() - want).abs().max()) / scale < 2e-5
+    U = torch.empty(M, N, device='cuda'); D = torch.empty(M, N, device='cuda')
+    ops.gemm(A, B, U, M=M, N=N, K=K, dtype=X3, a_kc=akc, b_kc=bkc, c_f32=True, bias=bias, alpha=0.05, gelu_aux_out=D)
+    u = 0.05 * ref + bias.double()
+    cdf = 0.5 * (1 + torch.erf(u / 2 ** 0.5))
+    assert float((U.double() - u * cdf).abs().max()) < 1e-5 * max(1.0, float(u.abs().max()))
+    assert float((D.double() - (cdf + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5)).abs().max()) < 2e-4          # gelu_grad_f: __expf, as in the exact-f32 epilogue
+    G = torch.empty(M, N, device='cuda')
+    cs = torch.zeros(N, device='cuda')
+    ws = torch.empty(int(ops.LIB.query('pb_gemm_colsum_ws_floats', M, N)), device='cuda')
+    ops.gemm(A, B, G, M=M, N=N, K=K, dtype=X3, a_kc=akc, b_kc=bkc, c_f32=True, gelu_grad_aux_in=D, colsum_out=cs, colsum_ws=ws)
+    wantg = ref * D.double()
+    assert float((G.double() - wantg).abs().max()) / scale < 2e-5
+    assert float((cs.double() - wantg.sum(0)).abs().max()) < 1e-4 * float(wantg.sum(0).abs().max() + scale)
+    if K % 64 == 0 and K >= 256:
+        slabs = torch.empty(4 * M * N, device='cuda')
+        S4 = torch.empty(M, N, device='cuda')
+        ops.gemm(A, B, S4, M=M, N=N, K=K, dtype=X3, a_kc=akc, b_kc=bkc, c_f32=True, splitk=4, slabs=slabs)
+        assert float((S4.double() - ref).abs().max()) / scale < 2e-5
+
+
+def test_gemm_f32x3_batched_strided_like_the_unfused_attention(ops):
+    """The unfused attention products of the parity instantiations address heads by stride inside (T, 3d) rows: Q K^T (K = head_dim, NT) and
+    P V (B operand row-contiguous) in PB_F32X3 against fp64."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    B_, H, S, hd = 2, 4, 96, 32
+    d = H * hd
+    qkv = torch.randn(B_ * S, 3 * d, device='cuda', generator=g)
+    scores = torch.empty(B_, H, S, S, device='cuda')
+    ops.gemm(qkv, qkv, scores, M=S, N=S, K=hd, dtype=ops.PB_F32X3, lda=3 * d, ldb=3 * d, ldc=S, c_f32=True, nb1=B_, nb2=H,
+             sA=(S * 3 * d, hd), sB=(S * 3 * d, hd), sC=(H * S * S, S * S), a_off=0, b_off=d)
+    q = qkv[:, :d].view(B_, S, H, hd).permute(0, 2, 1, 3).double()
+    k = qkv[:, d:2 * d].view(B_, S, H, hd).permute(0, 2, 1, 3).double()
+    v = qkv[:, 2 * d:].view(B_, S, H, hd).permute(0, 2, 1, 3).double()
+    ref = q @ k.transpose(-1, -2)
+    assert float((scores.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    P = torch.softmax(scores, -1).contiguous()
+    out = torch.zeros(B_ * S, d, device='cuda')
+    ops.gemm(P, qkv, out, M=S, N=hd, K=S, dtype=ops.PB_F32X3, b_kc=False, lda=S, ldb=3 * d, ldc=d, c_f32=True, nb1=B_, nb2=H,
+             sA=(H * S * S, S * S), sB=(S * 3 * d, hd), sC=(S * d, hd), b_off=2 * d)
+    want = (P.double() @ v).permute(0, 2, 1, 3).reshape(B_ * S, d)
+    assert float((out.double() - want).abs().max()) / float(want.abs().max()) < 2e-5

@@ -52,7 +52,7 @@ def test_state_dict_layout_matches_reference():
     assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == g['cfg1']
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 6e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16x3', 1e-3), ('bf16', 6e-2)])
 def test_g1_forward_golden(precision, tol):
     _need_gpu()
     z = np.load(os.path.join(GOLD, 'g1_forward_cfg1.npz'))
@@ -79,14 +79,14 @@ def test_g1_forward_golden(precision, tol):
     for i in range(8):
         seg = gl[..., offs[i]:offs[i + 1]]
         top2 = seg.topk(2, dim=-1).values
-        clear = (top2[..., 0] - top2[..., 1]) > (1e-4 if precision == 'fp32' else 5e-2) * float(gl.abs().max())
+        clear = (top2[..., 0] - top2[..., 1]) > {'fp32': 1e-4, 'bf16x3': 1e-3, 'bf16': 5e-2}[precision] * float(gl.abs().max())
         mine = logits[..., offs[i]:offs[i + 1]].argmax(-1).cpu()
         assert bool((mine[clear] == torch.from_numpy(z['argmax'][..., i].astype(np.int64))[clear]).all()), 'head %d argmax' % i
-        if precision == 'fp32':
-            assert float(clear.float().mean()) > 0.99
+        if precision != 'bf16':
+            assert float(clear.float().mean()) > (0.99 if precision == 'fp32' else 0.97)
 
 
-@pytest.mark.parametrize('precision,ltol', [('fp32', 1e-4), ('bf16', 2e-2)])
+@pytest.mark.parametrize('precision,ltol', [('fp32', 1e-4), ('bf16x3', 2e-4), ('bf16', 2e-2)])
 def test_g1_fused_loss_acc_argmax(precision, ltol):
     """The fused K9 kernel (no D2H logits) reproduces pretrain.py:163-189 on the golden batch."""
     _need_gpu()
@@ -105,7 +105,7 @@ def test_g1_fused_loss_acc_argmax(precision, ltol):
     total = float((head_loss * w).sum() / w.sum())
     assert abs(total - float(z['total_loss'])) / float(z['total_loss']) < ltol
     assert np.allclose(head_loss.numpy(), z['head_losses'], rtol=ltol * 5, atol=1e-5)
-    if precision == 'fp32':
+    if precision != 'bf16':
         assert np.allclose(head_acc.numpy(), z['head_acc'], atol=1e-6)
 
 
@@ -117,7 +117,7 @@ def _grads_vs_golden(precision, tol_named, tol_norm):
     return z, m, (enc, dec, loss_mask, emask, dmask, target)
 
 
-@pytest.mark.parametrize('precision,tol_named,tol_norm', [('fp32', 1e-3, 2e-3), ('bf16', 1.5e-1, 1e-1)])
+@pytest.mark.parametrize('precision,tol_named,tol_norm', [('fp32', 1e-3, 2e-3), ('bf16x3', 2e-3, 3e-3), ('bf16', 1.5e-1, 1e-1)])
 def test_g4_backward_via_autograd_module_path(precision, tol_named, tol_norm):
     """Drop-in path: PianoBartLM.forward -> list of 8 tensors -> reference-style loss -> .backward()."""
     _need_gpu()
@@ -125,7 +125,7 @@ def test_g4_backward_via_autograd_module_path(precision, tol_named, tol_norm):
     z, m, (enc, dec, loss_mask, emask, dmask, target) = _grads_vs_golden(precision, tol_named, tol_norm)
     y = m(enc, dec, emask, dmask)
     total, *_ = O.pretrain_loss(y, target, loss_mask, E2W)
-    assert abs(float(total) - float(z['total_loss'])) / float(z['total_loss']) < (1e-4 if precision == 'fp32' else 2e-2)
+    assert abs(float(total) - float(z['total_loss'])) / float(z['total_loss']) < {'fp32': 1e-4, 'bf16x3': 2e-4, 'bf16': 2e-2}[precision]
     m.zero_grad()
     total.backward()
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
@@ -285,11 +285,13 @@ def test_generate_against_the_oracle_on_random_prompts(seed):
     assert np.array_equal(st_o, st_m)
 
 
-def test_g10_cfg2_shape_spot_check():
-    """cfg-2 model shape (12L/768/ffn3072/12 heads, S=1024, B=1) against vectors captured from the reference."""
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_g10_cfg2_shape_spot_check(precision):
+    """cfg-2 model shape (12L/768/ffn3072/12 heads, S=1024, B=1) against vectors captured from the reference: both parity-grade
+    instantiations -- exact f32 and the split-bf16 GEMMs (round 6) -- under the north-star bound (logits 1e-3, argmax identical outside near-ties)."""
     _need_gpu()
     z = np.load(os.path.join(GOLD, 'g10_cfg2_spot.npz'))
-    m = _lm(1024, 768, 12, 3072, 12, 41, 'fp32').eval()
+    m = _lm(1024, 768, 12, 3072, 12, 41, precision).eval()
     assert sd_checksum(m.state_dict()) == _sha(z)
     m = m.cuda()
     enc, dec, loss_mask, emask, dmask, target = [t.cuda() for t in synth_octuple_batch(1, 1024, seed=19)]
@@ -297,7 +299,7 @@ def test_g10_cfg2_shape_spot_check():
         y = torch.cat(m(enc, dec, emask, dmask), dim=-1)[0].cpu()
     rows = z['rows']
     rel = float((y[rows] - torch.from_numpy(z['logit_rows'])).abs().max() / float(z['logit_absmax']))
-    print('cfg2 logits rel = %.3e' % rel)
+    print('cfg2 logits rel (%s) = %.3e' % (precision, rel))
     assert rel < 1e-3
     offs = np.cumsum([0, 262, 134, 135, 262, 134, 38, 260, 55])
     arg = torch.stack([y[:, offs[i]:offs[i + 1]].argmax(-1) for i in range(8)], dim=-1).numpy()
