@@ -50,6 +50,8 @@ const char* pb_last_error(void);
                                     Pays for a caller that runs one GEMM at a time (N = 768 at 26 624 rows: +13-17 %): the training
                                     step asks for it in forward; in backward its second stream already fills those CUs     */
 #define PB_GEMM_ROWDOT 131072     /* C = result as usual, and per 64-column group the row sums of C * aux_in go to rowdot_out (see pb_gemm_desc) */
+#define PB_GEMM_LEAVE_CUS 262144  /* persistent grids: launch CUs - pb_gemm_reserve_cus() workgroups instead of one per CU (data parallel: the backward
+                                    GEMMs that run beside RCCL's resident kernels)                                                       */
 #define PB_GEMM_ROW_SPLIT 65536  /* 256x256 kernel: the M tiles of the full rounds of the persistent grid stay with it, the remaining rows go to a
                                     second launch of the 128x128 kernel (no partials). Measured (round 3): -1.8 % on the one-stream step
                                     together with nothing else, +-0 on the shipped two-stream step (its second stream already fills the CUs a
@@ -76,6 +78,9 @@ typedef struct pb_gemm_desc {
                                          (delta_rows). NT layout, M and N multiples of 256, bf16, no other epilogue; refused otherwise */
 } pb_gemm_desc;
 int pb_gemm(const pb_gemm_desc* d, void* stream);
+/* CUs (rounded up to a multiple of 8) that the persistent one-workgroup-per-CU GEMM grids launched with PB_GEMM_LEAVE_CUS leave to other resident kernels -- RCCL's, in a
+ * data-parallel job (the reference: nn.DataParallel's reduce_add on the side, pretrain.py:63-65). Process-wide; 0 = none (default). ABI 8. */
+int pb_gemm_reserve_cus(int32_t n);
 int64_t pb_gemm_colsum_ws_floats(int32_t M, int32_t N);
 
 /* ---- K1/K2: Octuple gather-sum + position + LayerNorm (+dropout) -----------------------------

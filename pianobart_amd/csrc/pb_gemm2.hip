@@ -1214,14 +1214,25 @@ __global__ __launch_bounds__(256) void tail_finish_kernel(const Gemm2Args p) {
 
 // CU count of the current device, rounded down to a multiple of 8 (one persistent workgroup per CU; a grid that is a multiple
 // of 8 keeps every work item of a workgroup on the workgroup's own XCD chunk).
-static int pb_num_cus() {
+#include <atomic>
+static std::atomic<int> g_reserved_cus{0};
+static int pb_num_cus(bool leave_reserved = false) {
     static int cached = 0;
     if (!cached) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
         cached = n / 8 * 8;
     }
-    return cached;
+    const int r = leave_reserved ? g_reserved_cus.load(std::memory_order_relaxed) : 0;
+    return std::max(8, (cached - r) / 8 * 8);
+}
+// CUs the persistent GEMM grids launched with PB_GEMM_LEAVE_CUS leave alone (the count is process-wide): a data-parallel job hands RCCL's resident kernels their share of the chip
+// up front, so that the one-workgroup-per-CU grids keep their form (the next item's loads under the current epilogue) instead of
+// falling back to ordinary grids. Rounded to whole XCD rows of 8; 0 = the whole chip.
+extern "C" int pb_gemm_reserve_cus(int32_t n) {
+    PB_REQUIRE(n >= 0 && n <= 128, "pb_gemm_reserve_cus: %d", n);
+    g_reserved_cus.store((n + 7) / 8 * 8, std::memory_order_relaxed);
+    return 0;
 }
 
 // Called by pb_gemm (pb_gemm.hip) when the problem qualifies. Returns 1 if it declined, 0 on success, <0 on error.
@@ -1272,7 +1283,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
     if ((uintptr_t)d->C % 16 != 0 || d->ldc % cal != 0 || d->sC1 % cal != 0 || d->sC2 % cal != 0) return 1;
     if ((d->aux_in || d->aux_out) && (d->ldaux % 8 != 0 || (uintptr_t)d->aux_in % 16 != 0 || (uintptr_t)d->aux_out % 16 != 0)) return 1;
     if (d->bias && ((uintptr_t)d->bias % 16 != 0)) return 1;
-    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | PB_GEMM_REG_EPILOGUE | 2048 | 4096 | 8192 | 16384 | 32768)))) {
+    if (nsplit > 1 && (!c32 || !d->slabs || d->bias || (d->flags & ~(PB_GEMM_ACCUM | PB_GEMM_C_F32 | PB_GEMM_TILE128 | PB_GEMM_TILE256 | 128 | PB_GEMM_REG_EPILOGUE | 2048 | 4096 | 8192 | 16384 | 32768 | PB_GEMM_LEAVE_CUS)))) {
         pb_set_error("pb_gemm: split-K needs f32 C, a slab workspace and no epilogue other than accumulate");
         return -2;
     }
@@ -1407,7 +1418,7 @@ int pb_gemm2_try(const pb_gemm_desc* d, void* stream_) {
         auto kfn = gemm3_kernel<AK, BK_, 4>;                                                                               \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G3_STAGE_OFF + G3_STAGE_BYTES + 8192); \
         const unsigned items = a.tail_split > 1 ? a.n_full + (grid.x - a.n_full) * a.tail_split : grid.x;                    \
-        dim3 pgrid(std::min<unsigned>(items, (d->flags & 4096) ? items : (unsigned)pb_num_cus()), grid.y, 1);               \
+        dim3 pgrid(std::min<unsigned>(items, (d->flags & 4096) ? items : (unsigned)pb_num_cus((d->flags & PB_GEMM_LEAVE_CUS) != 0)), grid.y, 1); \
         hipLaunchKernelGGL(kfn, pgrid, dim3(512), G3_STAGE_OFF + G3_STAGE_BYTES + 16 * (size_t)lds_tag, stream, a);                       \
         if (a.tail_split > 1) hipLaunchKernelGGL(tail_finish_kernel<4>, dim3((grid.x - a.n_full) * TAIL_FIN_PARTS), dim3(256), 0, stream, a); \
     } while (0)

@@ -28,6 +28,7 @@ _WG_TARGET = 192 if _WGRAD_STREAM & 1 else 256            # split-K work items a
 _NO_DEFER = False                  # settled (round 2): True reduces every bias / LayerNorm gradient right behind its producer
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
 _ROWDOT = int(os.environ.get('PB_ROWDOT', '1'))                                  # 1 = delta of the one-pass attention backward from the out-projection dgrad's epilogue (0: a separate pass)
+_DP_RESERVE_CUS = int(os.environ.get('PB_DP_RESERVE_CUS', '0'))                 # data parallel: 0 = backward GEMMs as ordinary grids (default: +0.45 ms at world 1, profiles/r06_dp_mode_ab.txt); n > 0 = persistent grids that leave n CUs to RCCL's kernels (+1.0 / +1.4 ms for 8 / 16)
 _DECODE_SPEC = int(os.environ.get('PB_DECODE_SPEC', '1'))                       # 1 = device-side sampling ahead of the host where the caller names the sampler (Engine._generate_device_sampled), 0 = one host round trip per token
 _DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop (the persistent-kernel forms of round 4, measured slower, left the library in round 5: profiles/r04_decode_persistent.txt)
 _NO_FUSED_BIAS = False             # settled (round 2): True takes the bias gradients out of the GEMM / attention epilogues
@@ -727,9 +728,13 @@ class Engine:
         return self._csbuf
 
     def _bwd_dbg(self):
-        """Backward GEMMs that can run beside in-flight gradient all-reduces (data parallel: grad_hook set) are launched as ordinary
-        grids (bit 12): a persistent one-workgroup-per-CU grid whose CUs are partly held by RCCL's kernels would run its stragglers as
-        a second full round, twice the time, where an ordinary grid merely loses those CUs' share."""
+        """Backward GEMMs run beside in-flight gradient all-reduces when a grad_hook is set (data parallel). A persistent
+        one-workgroup-per-CU grid whose CUs are partly held by RCCL's kernels would run its stragglers as a second full round, so either
+        they are launched as ordinary grids (bit 12, the default), which merely lose those CUs' share, or -- PB_DP_RESERVE_CUS = n > 0 -- the
+        persistent grids leave RCCL n CUs up front (GradReducer calls pb_gemm_reserve_cus). Measured at world size 1 (profiles/r06_dp_mode_ab.txt):
+        ordinary grids + f32 exchange cost the step +0.45 ms, 8 / 16 reserved CUs +1.0 / +1.4 ms."""
+        if self.grad_hook is not None and _DP_RESERVE_CUS > 0:
+            return 262144                                            # PB_GEMM_LEAVE_CUS
         return 4096 if (self.grad_hook is not None or ((_WGRAD_STREAM & 4) and self._side)) else 0
 
     def _ffn_ln_bwd(self, L, pf, ff, gy, y_in, seed, site, p, T, row_ids=None):

@@ -9,7 +9,9 @@ rank, and the only exchanges are
     backward has been enqueued, on a communication stream of its own, underneath the rest of backward.
 Clip-norm and AdamW then run identically on every rank on the reduced flat buffer.
 
-Gradient exchange, mode "bf16" (default; SURVEY 5 budgets 406 MB per step for cfg 2, half of f32):
+Gradient exchange. Mode "f32" (default since round 6): a plain RCCL all-reduce (SUM) of the f32 bucket -- the arithmetic of the
+reference's fp32 reduce_add_coalesced (pretrain.py:65), 812 MB per step at cfg 2. Mode "bf16" (PB_DP_GRADS=bf16; SURVEY 5 budgets 406 MB
+per step, half of f32; narrower than the reference, so on request only):
 xGMI on an MI355X node is a full mesh of point-to-point links (7 per GPU), so a bucket is exchanged as
 a direct reduce-scatter + all-gather in which every link carries 1/N of the bucket in each phase:
   1. the bucket's f32 gradients are rounded to bf16 and cut into N equal chunks;
@@ -18,7 +20,7 @@ a direct reduce-scatter + all-gather in which every link carries 1/N of the buck
   4. all-gather of the reduced chunks; every rank (the owner included) converts the same bf16 values back
      to f32, so all ranks hold bit-identical gradients.
 Accumulation is in f32 (one rounding of the inputs, one of the sum), unlike a bf16 ring all-reduce
-that rounds after every hop. Mode "f32" is a plain RCCL all-reduce (SUM) of the f32 bucket.
+that rounds after every hop.
 """
 import os
 
@@ -48,7 +50,7 @@ class _HipXfer:
 class GradReducer:
     def __init__(self, engine, world_size, group=None, mode=None, xfer=None):
         self.eng, self.world, self.group = engine, world_size, group
-        self.mode = mode or os.environ.get('PB_DP_GRADS', 'bf16')
+        self.mode = mode or os.environ.get('PB_DP_GRADS', 'f32')
         if self.mode not in ('bf16', 'f32'):
             raise ValueError('gradient exchange mode must be "bf16" or "f32"')
         self.xfer = xfer or _HipXfer
@@ -57,6 +59,19 @@ class GradReducer:
         self._bufs = {}
         self._comm = None
         engine.grad_hook = self._on_ready
+        from . import engine as _E
+        dev = getattr(engine, 'device', None)
+        if _E._DP_RESERVE_CUS > 0 and dev is not None and dev.type == 'cuda':
+            from ._lib import LIB
+            LIB.call('pb_gemm_reserve_cus', _E._DP_RESERVE_CUS)      # the persistent GEMM grids leave RCCL its CUs (Engine._bwd_dbg)
+
+    def close(self):
+        """Uninstall: the engine steps alone again (whole-chip persistent grids)."""
+        self.eng.grad_hook = None
+        dev = getattr(self.eng, 'device', None)
+        if dev is not None and dev.type == 'cuda':
+            from ._lib import LIB
+            LIB.call('pb_gemm_reserve_cus', 0)
 
     def reduce_counts(self, counts):
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
