@@ -23,7 +23,7 @@ extern "C" {
                         bf16 matrix cores with f32 accumulation (~2^-16 relative per product): the parity-grade instantiation that is not bound by
                         the f32-input MFMA rate (precision="bf16x3"); every other op of that instantiation runs its PB_F32 form */
 
-#define PB_ABI_VERSION 8   /* 8 (round 6): + pb_decoder_sampler_init / launch / wait / logs / seek (device-sampled decode), dtype PB_F32X3 in pb_gemm; 7 (round 5): + PB_GEMM_ROWDOT / rowdot_out in pb_gemm_desc, delta_rows in pb_flash_bwd1*; 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
+#define PB_ABI_VERSION 8   /* 8 (round 6): + pb_decoder_sampler_init / launch / wait / logs / seek (device-sampled decode), dtype PB_F32X3 in pb_gemm, pb_flash_*_x3, pb_gemm_reserve_cus; 7 (round 5): + PB_GEMM_ROWDOT / rowdot_out in pb_gemm_desc, delta_rows in pb_flash_bwd1*; 6 (round 5): + pb_flash_bwd1_supported; 5 (round 4): + pb_flash_bwd1*, bh_order in the packed attention calls; 4 (round 3): + pb_decoder_*, pb_nucleus_rows, pb_ids_check */
 int pb_abi_version(void);
 const char* pb_last_error(void);
 
@@ -426,6 +426,21 @@ int pb_decoder_launch(void* dec, int32_t ntok, const int16_t* first_tok8);
 int pb_decoder_wait(void* dec, int32_t ticket);
 int pb_decoder_logs(void* dec, float** logits_rows, int16_t** tok_rows);
 int pb_decoder_seek(void* dec, int32_t pos, const int16_t* tok8);
+
+/* ---- fused attention of the "bf16x3" parity instantiation (round 6, ABI 8): f32 q / k / v / o, every product a split-bf16 triple on the
+ * bf16 matrix cores (see PB_F32X3), softmax in f32 -- instead of the unfused QK^T -> softmax -> PV chain of the exact-f32 path
+ * (modeling_bart.py:115-140 through PianoBart.py:76), whose (B, H, S, S) f32 matrices dominate that path's HBM time. Same masks and
+ * conventions as pb_flash_fwd / pb_flash_bwd (key padding row per batch, bit 0 of `causal`, zero output row + lse = +inf for a query
+ * without a visible key); strides in ELEMENTS, multiples of 4; head_dim 32 / 64 / 128 (pb_flash_x3_supported). delta: (B, H, Sq) f32
+ * scratch, written by the call. */
+int pb_flash_x3_supported(int32_t hd);
+int pb_flash_fwd_x3(const float* q, const float* k, const float* v, float* o, float* lse, const float* key_mask, int32_t B, int32_t H, int32_t Sq,
+                    int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb,
+                    int64_t o_ss, float scale, int32_t causal, void* stream);
+int pb_flash_bwd_x3(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, const float* key_mask,
+                    float* dq, float* dk, float* dv, float* delta, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb,
+                    int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb,
+                    int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, void* stream);
 
 /* ---- K15: deferred parameter-gradient reductions -----------------------------------------------------------------------
  * The bias / LayerNorm-parameter gradients of one backward pass (the `db = grad.sum(0)` of every nn.Linear and nn.LayerNorm autograd

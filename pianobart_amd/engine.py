@@ -29,6 +29,7 @@ _NO_DEFER = False                  # settled (round 2): True reduces every bias 
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
 _ROWDOT = int(os.environ.get('PB_ROWDOT', '1'))                                  # 1 = delta of the one-pass attention backward from the out-projection dgrad's epilogue (0: a separate pass)
 _DP_RESERVE_CUS = int(os.environ.get('PB_DP_RESERVE_CUS', '0'))                 # data parallel: 0 = backward GEMMs as ordinary grids (default: +0.45 ms at world 1, profiles/r06_dp_mode_ab.txt); n > 0 = persistent grids that leave n CUs to RCCL's kernels (+1.0 / +1.4 ms for 8 / 16)
+_X3_FLASH = int(os.environ.get('PB_X3_FLASH', '1'))                            # bf16x3: 1 = fused split-bf16 attention (pb_flash_*_x3), 0 = the unfused QK^T / softmax / PV chain of the exact-f32 path
 _DECODE_SPEC = int(os.environ.get('PB_DECODE_SPEC', '1'))                       # 1 = device-side sampling ahead of the host where the caller names the sampler (Engine._generate_device_sampled), 0 = one host round trip per token
 _DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop (the persistent-kernel forms of round 4, measured slower, left the library in round 5: profiles/r04_decode_persistent.txt)
 _NO_FUSED_BIAS = False             # settled (round 2): True takes the bias gradients out of the GEMM / attention epilogues
@@ -121,7 +122,7 @@ class Engine:
         self.step_count = 0
         self.opt_m = self.opt_v = None
         self._versions = None
-        self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 96, 128))
+        self.use_flash = (self.code == PB_BF16 and self.hd in (32, 64, 96, 128)) or (self.x3 and _X3_FLASH and self.hd in (32, 64, 128))
         self._slabs = None
         self._pack_state = None
         self._pack_prefetch, self._pack_pf_state = [], None     # rowpack.prefetch_counts: requests in flight (oldest first)
@@ -402,6 +403,10 @@ class Engine:
         if rows is not None:
             ops.flash_fwd_packed(q, k, v, out, save['lse'], rows, B, H, hd, hd ** -0.5, causal)
             return
+        if self.use_flash and self.x3:
+            ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
+            ops.flash_fwd_x3(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), save['lse'], key_mask, B, H, Sq, Sk, hd, hd ** -0.5, causal)
+            return
         if self.use_flash:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
             ops.flash_fwd(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), save['lse'], key_mask, B, H, Sq, Sk, hd, hd ** -0.5, causal,
@@ -418,7 +423,7 @@ class Engine:
     def _one_pass_bwd(self, causal, rows, B, Sq, Sk, q_rows):
         """Whether the attention backward of this call is the one-pass kernel (head_dim 64; PB_ATTN_BWD1; its -lse / -delta tables of a whole
         sequence live in LDS: beyond 6144 queries the dQ + dK/dV pair takes the call)."""
-        if not (self.use_flash and self.hd == 64 and _ATTN_BWD1 >= (3 if causal else 2 if rows is not None else 1)):
+        if not (self.use_flash and not self.x3 and self.hd == 64 and _ATTN_BWD1 >= (3 if causal else 2 if rows is not None else 1)):
             return False
         return bool(LIB.query('pb_flash_bwd1_supported', rows.Sq_max if rows is not None else Sq, rows.Sk_max if rows is not None else Sk,
                               self.hd, q_rows, self.H))
@@ -428,6 +433,12 @@ class Engine:
         delta_rows: rowsum(dO * O) per head, [H][rows], already made by the GEMM that produced dout (PB_GEMM_ROWDOT); one-pass kernel only."""
         H, hd = self.H, self.hd
         ws = self._cur_ws
+        if self.use_flash and self.x3:
+            ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
+            assert dout[1] == 0 and dout[2] == out[2]
+            ops.flash_bwd_x3(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
+                             ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal)
+            return False
         if self.use_flash:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
             assert dout[1] == 0 and dout[2] == out[2]

@@ -780,3 +780,46 @@ def test_gemm_f32x3_batched_strided_like_the_unfused_attention(ops):
              sA=(H * S * S, S * S), sB=(S * 3 * d, hd), sC=(S * d, hd), b_off=2 * d)
     want = (P.double() @ v).permute(0, 2, 1, 3).reshape(B_ * S, d)
     assert float((out.double() - want).abs().max()) / float(want.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('hd', [32, 64, 128])
+@pytest.mark.parametrize('causal', [False, True])
+@pytest.mark.parametrize('S', [64, 200, 136])
+def test_flash_attention_x3_fwd_bwd(ops, hd, causal, S):
+    """Fused attention of the bf16x3 instantiation (f32 tensors, split-bf16 triples on the bf16 MFMA, f32 softmax) vs an fp64 reference: key-padding
+    masks, causal, ragged S, a query without a visible key (zero row). ~1e-5 of the output scale, where the bf16 kernels are at 1e-2."""
+    g = torch.Generator(device='cuda').manual_seed(hd + S)
+    B, H = 2, 3
+    d = H * hd
+    qkv = torch.randn(B, S, 3 * d, device='cuda', generator=g) * 1.5
+    km = (torch.rand(B, S, device='cuda', generator=g) > 0.25).float()
+    km[0, 0] = 0
+    km[1, S // 2:] = 0
+    out = torch.full((B, S, d), float('nan'), device='cuda')
+    lse = torch.empty(B, H, S, device='cuda')
+    scale = hd ** -0.5
+    sl = lambda off: (qkv, off, 3 * d, S * 3 * d)
+    ops.flash_fwd_x3(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), lse, km, B, H, S, S, hd, scale, causal)
+    qd = qkv.double().requires_grad_(True)
+    q = qd[..., :d].reshape(B, S, H, hd).permute(0, 2, 1, 3)
+    k = qd[..., d:2 * d].reshape(B, S, H, hd).permute(0, 2, 1, 3)
+    v = qd[..., 2 * d:].reshape(B, S, H, hd).permute(0, 2, 1, 3)
+    vis = (km != 0)[:, None, None, :].expand(B, H, S, S)
+    if causal:
+        vis = vis & torch.ones(S, S, dtype=torch.bool, device='cuda').tril()
+    s = (q @ k.transpose(2, 3) * scale).masked_fill(~vis, float('-inf'))
+    p = torch.nan_to_num(torch.where(vis.any(-1, keepdim=True), torch.softmax(s, -1), torch.zeros_like(s)), nan=0.0)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, S, d)
+    e_out = float((out.double() - ref).abs().max() / ref.abs().max())
+    has = vis.any(-1)
+    e_lse = float((lse.double() - torch.logsumexp(s, -1))[has].abs().max())
+    assert torch.isinf(lse[~has]).all() and bool((out.reshape(B, S, H, hd).permute(0, 2, 1, 3)[~has] == 0).all())
+    dout = torch.randn(B, S, d, device='cuda', generator=g)
+    ref.backward(dout.double())
+    dqkv = torch.full((B, S, 3 * d), float('nan'), device='cuda')
+    delta = torch.empty(B, H, S, device='cuda')
+    dsl = lambda off: (dqkv, off, 3 * d, S * 3 * d)
+    ops.flash_bwd_x3(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), dout, lse, km, dsl(0), dsl(d), dsl(2 * d), delta, B, H, S, S, hd, scale, causal)
+    e_grad = float((dqkv.double() - qd.grad).abs().max() / qd.grad.abs().max())
+    print('flash x3 hd=%d S=%d causal=%d: out %.2e  lse %.2e  grads %.2e' % (hd, S, causal, e_out, e_lse, e_grad))
+    assert e_out < 3e-5 and e_lse < 1e-4 and e_grad < 5e-5
