@@ -93,6 +93,48 @@ __device__ __forceinline__ void xstage_transposed(char* hi_img, char* lo_img, co
         }
     }
 }
+// rows image AND transposed image of one tile from ONE pass over the f32 source (the dKV / dQ kernels need both of Q, dO / K): the
+// thread that owns a 4 x 8 block for the transpose also writes its four row chunks
+template <int HD>
+__device__ __forceinline__ void xstage_both(char* r_hi, char* r_lo, char* t_hi, char* t_lo, const float* __restrict__ g, long ld, int nvalid, int t) {
+    constexpr int NCC = HD / 8;
+    for (int blk = t; blk < 16 * NCC; blk += FX_THREADS) {
+        const int cc = blk % NCC, kg = blk / NCC;
+        bf16x8 vh[4], vl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = kg * 4 + i;
+            float x[8];
+            if (row < nvalid) load8f(g + (long)row * ld + cc * 8, x);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = 0.f;
+            }
+            cut8(x, vh[i], vl[i]);
+            *reinterpret_cast<bf16x8*>(r_hi + xrows_off<HD>(row, cc)) = vh[i];
+            *reinterpret_cast<bf16x8*>(r_lo + xrows_off<HD>(row, cc)) = vl[i];
+        }
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            char* img = part ? t_lo : t_hi;
+            uint4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint4, part ? vl[i] : vh[i]);
+            const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&v[0]);
+            const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&v[1]);
+            const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&v[2]);
+            const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&v[3]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int w = j >> 1;
+                const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                const uint32_t lo = __builtin_amdgcn_perm(w1[w], w0[w], sel);
+                const uint32_t hi = __builtin_amdgcn_perm(w3[w], w2[w], sel);
+                *reinterpret_cast<uint2*>(img + xtr_off(cc * 8 + j, kg * 4)) = make_uint2(lo, hi);
+            }
+        }
+    }
+}
 template <int HD> __device__ __forceinline__ bf16x8 xfrag_rows(const char* lds, int row, int ks, int g) {
     return *reinterpret_cast<const bf16x8*>(lds + xrows_off<HD>(row, ks * 4 + g));
 }
@@ -188,12 +230,12 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fwd_kernel(const FxArgs p) {
         mx = xgrp_max(mx);
         const float mnew = fmaxf(m, mx);
         const float muse = mnew == -INFINITY ? 0.f : mnew;
-        const float alpha = exp2f(m - muse);
+        const float alpha = __builtin_amdgcn_exp2f(m - muse);
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = exp2f(s[kt][r] - muse); s[kt][r] = e; rs += e; }
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - muse); s[kt][r] = e; rs += e; }
         rs = xgrp_sum(rs);
         l = l * alpha + rs;
         m = mnew;
@@ -266,10 +308,14 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dkv_kernel(const FxArgs p) 
     const int qstart = p.causal ? (k0 / XQ) * XQ : 0;
     for (int q0 = qstart; q0 < p.Sq; q0 += XQ) {
         __syncthreads();
-        xstage_rows<HD>(Qh, Ql, Q + (long)q0 * p.q_ss, p.q_ss, p.Sq - q0, t);
-        xstage_transposed<HD>(QTh, QTl, Q + (long)q0 * p.q_ss, p.q_ss, p.Sq - q0, t);
-        xstage_rows<HD>(Oh, Ol, DO + (long)q0 * p.o_ss, p.o_ss, p.Sq - q0, t);
-        xstage_transposed<HD>(OTh, OTl, DO + (long)q0 * p.o_ss, p.o_ss, p.Sq - q0, t);
+        constexpr int NB = 16 * (HD / 8);                        // 4 x 8 blocks per tile: head_dim <= 64 stages Q and dO side by side
+        if (2 * NB <= FX_THREADS) {
+            if (t < NB) xstage_both<HD>(Qh, Ql, QTh, QTl, Q + (long)q0 * p.q_ss, p.q_ss, p.Sq - q0, t);
+            else if (t < 2 * NB) xstage_both<HD>(Oh, Ol, OTh, OTl, DO + (long)q0 * p.o_ss, p.o_ss, p.Sq - q0, t - NB);
+        } else {
+            xstage_both<HD>(Qh, Ql, QTh, QTl, Q + (long)q0 * p.q_ss, p.q_ss, p.Sq - q0, t);
+            xstage_both<HD>(Oh, Ol, OTh, OTl, DO + (long)q0 * p.o_ss, p.o_ss, p.Sq - q0, t);
+        }
         if (t < XQ) {
             const int q = q0 + t;
             const long li = ((long)b * p.H + h) * p.Sq + q;
@@ -295,7 +341,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dkv_kernel(const FxArgs p) 
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + qt * 16 + g * 4 + r;
                 const bool vis = kvis && (!p.causal || mykey <= q);
-                const float pr = vis ? exp2f(s[qt][r] * c - lse[r]) : 0.f;
+                const float pr = vis ? __builtin_amdgcn_exp2f(s[qt][r] * c - lse[r]) : 0.f;
                 s[qt][r] = pr;
                 dp[qt][r] = pr * (dp[qt][r] - dl[r]) * p.scale;
             }
@@ -356,8 +402,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq_kernel(const FxArgs p) {
     const int kend = p.causal ? min(p.Sk, q0 + XQ) : p.Sk;
     for (int k0 = 0; k0 < kend; k0 += XK) {
         __syncthreads();
-        xstage_rows<HD>(Kh, Kl, K + (long)k0 * p.k_ss, p.k_ss, p.Sk - k0, t);
-        xstage_transposed<HD>(KTh, KTl, K + (long)k0 * p.k_ss, p.k_ss, p.Sk - k0, t);
+        xstage_both<HD>(Kh, Kl, KTh, KTl, K + (long)k0 * p.k_ss, p.k_ss, p.Sk - k0, t);
         xstage_rows<HD>(Vh, Vl, V + (long)k0 * p.v_ss, p.v_ss, p.Sk - k0, t);
         if (t < XK) {
             const int key = k0 + t;
@@ -381,7 +426,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq_kernel(const FxArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + kt * 16 + g * 4 + r;
                 const bool vis = vis4[r] != 0.f && (!p.causal || key <= myq);
-                const float pr = vis ? exp2f(s[kt][r] * c - lse) : 0.f;
+                const float pr = vis ? __builtin_amdgcn_exp2f(s[kt][r] * c - lse) : 0.f;
                 dp[kt][r] = pr * (dp[kt][r] - dl) * p.scale;
             }
         }

@@ -34,27 +34,38 @@ template <int ROLE, bool VEC>
 __global__ __launch_bounds__(256) void split_kc_kernel(const float* __restrict__ src, long ld, long s1, long s2, int nb2, int rows, int K, int Kp,
                                                        bf16_t* __restrict__ dst) {
     const int cpr = Kp >> 3;                                       // 8-element chunks per row
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)rows * cpr) return;
-    const int r = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
     const int b = blockIdx.y;
-    const float* p = src + (long)(b / nb2) * s1 + (long)(b % nb2) * s2 + (long)r * ld + c;
-    float x[8];
-    if (VEC && c + 8 <= K) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p), bb = *reinterpret_cast<const f32x4*>(p + 4);
+    const float* base = src + (long)(b / nb2) * s1 + (long)(b % nb2) * s2;
+    const long n = (long)rows * cpr, i0 = (long)blockIdx.x * 1024 + threadIdx.x;     // 4 chunks per thread, all loads in flight before the first store
+    float x[4][8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { x[j] = a[j]; x[4 + j] = bb[j]; }
-    } else {
+    for (int u = 0; u < 4; ++u) {
+        const long idx = i0 + 256 * u;
+        if (idx >= n) continue;
+        const int r = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
+        const float* p = base + (long)r * ld + c;
+        if (VEC && c + 8 <= K) {
+            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)), bb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = (c + j < K) ? p[j] : 0.f;
+            for (int j = 0; j < 4; ++j) { x[u][j] = a[j]; x[u][4 + j] = bb[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[u][j] = (c + j < K) ? p[j] : 0.f;
+        }
     }
-    bf16x8 hi, lo;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { bf16_t h, l; split1(x[j], h, l); hi[j] = h; lo[j] = l; }
-    bf16_t* o = dst + ((long)b * rows + r) * 3 * Kp + c;
-    *reinterpret_cast<bf16x8*>(o) = hi;
-    *reinterpret_cast<bf16x8*>(o + Kp) = ROLE == 0 ? hi : lo;
-    *reinterpret_cast<bf16x8*>(o + 2 * Kp) = ROLE == 0 ? lo : hi;
+    for (int u = 0; u < 4; ++u) {
+        const long idx = i0 + 256 * u;
+        if (idx >= n) continue;
+        const int r = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bf16_t h, l; split1(x[u][j], h, l); hi[j] = h; lo[j] = l; }
+        bf16_t* o = dst + ((long)b * rows + r) * 3 * Kp + c;
+        *reinterpret_cast<bf16x8*>(o) = hi;
+        *reinterpret_cast<bf16x8*>(o + Kp) = ROLE == 0 ? hi : lo;
+        *reinterpret_cast<bf16x8*>(o + 2 * Kp) = ROLE == 0 ? lo : hi;
+    }
 }
 
 // Row-contiguous operand: element (r, k) at src[k ld + r]. dst[batch][3 Kp][Rp]: the three K segments stacked; rows k in [K, Kp) and
@@ -63,30 +74,41 @@ template <int ROLE, bool VEC>
 __global__ __launch_bounds__(256) void split_rc_kernel(const float* __restrict__ src, long ld, long s1, long s2, int nb2, int rows, int K, int Kp, int Rp,
                                                        bf16_t* __restrict__ dst) {
     const int cpr = Rp >> 3;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)Kp * cpr) return;
-    const int k = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
     const int b = blockIdx.y;
-    const float* p = src + (long)(b / nb2) * s1 + (long)(b % nb2) * s2 + (long)k * ld + c;
-    float x[8];
-    if (k >= K) {
+    const float* base = src + (long)(b / nb2) * s1 + (long)(b % nb2) * s2;
+    const long n = (long)Kp * cpr, i0 = (long)blockIdx.x * 1024 + threadIdx.x;
+    float x[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = 0.f;
-    } else if (VEC && c + 8 <= rows) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p), bb = *reinterpret_cast<const f32x4*>(p + 4);
+    for (int u = 0; u < 4; ++u) {
+        const long idx = i0 + 256 * u;
+        if (idx >= n) continue;
+        const int k = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
+        const float* p = base + (long)k * ld + c;
+        if (k >= K) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { x[j] = a[j]; x[4 + j] = bb[j]; }
-    } else {
+            for (int j = 0; j < 8; ++j) x[u][j] = 0.f;
+        } else if (VEC && c + 8 <= rows) {
+            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)), bb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = (c + j < rows) ? p[j] : 0.f;
+            for (int j = 0; j < 4; ++j) { x[u][j] = a[j]; x[u][4 + j] = bb[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[u][j] = (c + j < rows) ? p[j] : 0.f;
+        }
     }
-    bf16x8 hi, lo;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { bf16_t h, l; split1(x[j], h, l); hi[j] = h; lo[j] = l; }
-    bf16_t* o = dst + ((long)b * 3 * Kp + k) * Rp + c;
-    *reinterpret_cast<bf16x8*>(o) = hi;
-    *reinterpret_cast<bf16x8*>(o + (long)Kp * Rp) = ROLE == 0 ? hi : lo;
-    *reinterpret_cast<bf16x8*>(o + 2L * Kp * Rp) = ROLE == 0 ? lo : hi;
+    for (int u = 0; u < 4; ++u) {
+        const long idx = i0 + 256 * u;
+        if (idx >= n) continue;
+        const int k = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bf16_t h, l; split1(x[u][j], h, l); hi[j] = h; lo[j] = l; }
+        bf16_t* o = dst + ((long)b * 3 * Kp + k) * Rp + c;
+        *reinterpret_cast<bf16x8*>(o) = hi;
+        *reinterpret_cast<bf16x8*>(o + (long)Kp * Rp) = ROLE == 0 ? hi : lo;
+        *reinterpret_cast<bf16x8*>(o + 2L * Kp * Rp) = ROLE == 0 ? lo : hi;
+    }
 }
 
 // Row-contiguous operand made K-contiguous on the way: element (r, k) at src[k ld + r] -> dst[batch][r][3 Kp] (the layout of
@@ -201,7 +223,7 @@ int pb_gemm_x3(const pb_gemm_desc* d, void* stream_) {
     const float* A = (const float*)d->A;
     const float* B = (const float*)d->B;
     PB_REQUIRE(nbt <= 65535, "pb_gemm (f32x3): too many batches");
-    auto grid_for = [&](long n) { return dim3((unsigned)((n + 255) / 256), (unsigned)nbt); };
+    auto grid_for = [&](long n) { return dim3((unsigned)((n + 1023) / 1024), (unsigned)nbt); };
     PB_REQUIRE(!(a_tr || b_tr) || (nbt <= 65535 && Kp / 64 <= 65535), "pb_gemm (f32x3): grid of the transposing split");
     if (a_tr) {
         hipLaunchKernelGGL((split_tr_kernel<0>), dim3((d->M + 63) / 64, Kp / 64, nbt), dim3(256), 0, stream, A, (long)d->lda, (long)d->sA1, (long)d->sA2, nb2, d->M, d->K, Kp, A3);
