@@ -37,6 +37,10 @@ def _lm(S, d, L, f, h, seed, precision, dropout=0.1):
     return m
 
 
+# bounds of the bf16 throughput instantiation in the shape sweep (measured maxima x ~2, see the test's printed lines)
+BF16_LOGITS, BF16_LOSS, BF16_NORM = 5e-2, 2e-3, 2e-2          # measured over the 8 shapes (round 6): 2.6e-2, 5.4e-4, 6.6e-3
+
+
 def _rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).abs().max() / b.abs().max())
@@ -52,7 +56,7 @@ def test_state_dict_layout_matches_reference():
     assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == g['cfg1']
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16x3', 1e-3), ('bf16', 6e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16x3', 1e-4), ('bf16', 2.5e-2)])        # measured: 1.2e-6, 1.9e-5, 1.04e-2
 def test_g1_forward_golden(precision, tol):
     _need_gpu()
     z = np.load(os.path.join(GOLD, 'g1_forward_cfg1.npz'))
@@ -79,14 +83,14 @@ def test_g1_forward_golden(precision, tol):
     for i in range(8):
         seg = gl[..., offs[i]:offs[i + 1]]
         top2 = seg.topk(2, dim=-1).values
-        clear = (top2[..., 0] - top2[..., 1]) > {'fp32': 1e-4, 'bf16x3': 1e-3, 'bf16': 5e-2}[precision] * float(gl.abs().max())
+        clear = (top2[..., 0] - top2[..., 1]) > {'fp32': 1e-4, 'bf16x3': 1e-4, 'bf16': 5e-2}[precision] * float(gl.abs().max())
         mine = logits[..., offs[i]:offs[i + 1]].argmax(-1).cpu()
         assert bool((mine[clear] == torch.from_numpy(z['argmax'][..., i].astype(np.int64))[clear]).all()), 'head %d argmax' % i
         if precision != 'bf16':
-            assert float(clear.float().mean()) > (0.99 if precision == 'fp32' else 0.97)
+            assert float(clear.float().mean()) > 0.99
 
 
-@pytest.mark.parametrize('precision,ltol', [('fp32', 1e-4), ('bf16x3', 2e-4), ('bf16', 2e-2)])
+@pytest.mark.parametrize('precision,ltol', [('fp32', 1e-4), ('bf16x3', 1e-4), ('bf16', 2e-2)])
 def test_g1_fused_loss_acc_argmax(precision, ltol):
     """The fused K9 kernel (no D2H logits) reproduces pretrain.py:163-189 on the golden batch."""
     _need_gpu()
@@ -117,7 +121,7 @@ def _grads_vs_golden(precision, tol_named, tol_norm):
     return z, m, (enc, dec, loss_mask, emask, dmask, target)
 
 
-@pytest.mark.parametrize('precision,tol_named,tol_norm', [('fp32', 1e-3, 2e-3), ('bf16x3', 2e-3, 3e-3), ('bf16', 1.5e-1, 1e-1)])
+@pytest.mark.parametrize('precision,tol_named,tol_norm', [('fp32', 1e-3, 2e-3), ('bf16x3', 1e-3, 2e-3), ('bf16', 1e-1, 4e-2)])       # measured: 4.7e-6 / 2.8e-6, 7.7e-5 / 1.4e-5, 4.8e-2 / 1.3e-2
 def test_g4_backward_via_autograd_module_path(precision, tol_named, tol_norm):
     """Drop-in path: PianoBartLM.forward -> list of 8 tensors -> reference-style loss -> .backward()."""
     _need_gpu()
@@ -125,17 +129,21 @@ def test_g4_backward_via_autograd_module_path(precision, tol_named, tol_norm):
     z, m, (enc, dec, loss_mask, emask, dmask, target) = _grads_vs_golden(precision, tol_named, tol_norm)
     y = m(enc, dec, emask, dmask)
     total, *_ = O.pretrain_loss(y, target, loss_mask, E2W)
-    assert abs(float(total) - float(z['total_loss'])) / float(z['total_loss']) < {'fp32': 1e-4, 'bf16x3': 2e-4, 'bf16': 2e-2}[precision]
+    assert abs(float(total) - float(z['total_loss'])) / float(z['total_loss']) < {'fp32': 1e-4, 'bf16x3': 1e-4, 'bf16': 2e-2}[precision]
     m.zero_grad()
     total.backward()
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     assert sorted(grads.keys()) == list(z['param_names'])        # same set of parameters receives gradient
+    worst = 0.0
     for k in z.files:
         if k.startswith('grad__'):
             r = _rel(grads[k[6:]], torch.from_numpy(z[k]))
+            worst = max(worst, r)
             assert r < tol_named, (k, r)
+    print('g4 %s: worst named gradient %.2e' % (precision, worst))
     norms = np.array([float(grads[k].double().norm()) for k in z['param_names']])
     # k_proj.bias gradients are mathematically zero (softmax shift invariance): absolute floor relative to the typical norm
+    print('g4 %s: worst per-parameter norm error %.2e (of norm + 0.1 median)' % (precision, float(np.max(np.abs(norms - z['per_param_grad_norm']) / (z['per_param_grad_norm'] + 1e-1 * np.median(z['per_param_grad_norm']))))))
     bad = np.abs(norms - z['per_param_grad_norm']) > tol_norm * z['per_param_grad_norm'] + tol_norm * 1e-1 * np.median(z['per_param_grad_norm'])
     assert not bad.any(), [(z['param_names'][i], norms[i], z['per_param_grad_norm'][i]) for i in np.nonzero(bad)[0][:5]]
 
@@ -479,11 +487,11 @@ def test_missing_masks_and_other_mask_dtypes():
     (33, 64, 1, 1, 96, 96, 4, 2),           # head_dim 16
     (77, 48, 1, 1, 72, 72, 2, 2),           # head_dim 24, d = 48
 ])
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3', 'bf16'])
 def test_shape_sweep_forward_loss_and_gradients_against_the_oracle(S, d, Le, Ld, fe, fd, h, B, precision):
     """Shapes off the beaten path (odd sequence lengths, head_dim 16 ... 128, ffn sizes that are not tile multiples, unequal encoder /
     decoder depth and width): the exact-f32 instantiation agrees with the oracle on logits, loss and every parameter gradient (the bf16
-    one within its looser bound: logits 8e-2, loss 2e-2, gradient norm 1e-1) -- or the library says loudly that it does not cover the
+    one within its looser bound: logits 5e-2, loss 2e-3, gradient norm 2e-2; the split-bf16 one within 2e-4 / 1e-5 / 1e-4 and every gradient 2e-3) -- or the library says loudly that it does not cover the
     shape; never a silent difference."""
     _need_gpu()
     from oracle import pianobart_oracle as O
@@ -508,20 +516,23 @@ def test_shape_sweep_forward_loss_and_gradients_against_the_oracle(S, d, Le, Ld,
     tot_o, *_ = O.pretrain_loss(yo, target, loss_mask, E2W)
     tot_o.backward()
     f32 = precision == 'fp32'
-    assert _rel(torch.cat(y, -1).detach(), torch.cat(yo, -1).detach()) < (1e-4 if f32 else 8e-2)
-    assert abs(float(tot.detach()) - float(tot_o.detach())) / float(tot_o.detach()) < (1e-4 if f32 else 2e-2)
+    tl, tloss, tnorm, tgrad = {'fp32': (1e-4, 1e-4, 1e-3, 2e-3), 'bf16x3': (2e-4, 1e-5, 1e-4, 2e-3), 'bf16': (BF16_LOGITS, BF16_LOSS, BF16_NORM, None)}[precision]
+    e_l = _rel(torch.cat(y, -1).detach(), torch.cat(yo, -1).detach())
+    e_loss = abs(float(tot.detach()) - float(tot_o.detach())) / float(tot_o.detach())
     go = {k: p.grad for k, p in o.named_parameters() if p.grad is not None}
     gm = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     assert sorted(go) == sorted(gm)
-    if not f32:
-        n_o = float(torch.sqrt(sum((g.double() ** 2).sum() for g in go.values())))
-        n_m = float(torch.sqrt(sum((g.double().cpu() ** 2).sum() for g in gm.values())))
-        assert abs(n_m - n_o) / n_o < 1e-1
+    n_o = float(torch.sqrt(sum((g.double() ** 2).sum() for g in go.values())))
+    n_m = float(torch.sqrt(sum((g.double().cpu() ** 2).sum() for g in gm.values())))
+    e_n = abs(n_m - n_o) / n_o
+    print('sweep %s S=%d d=%d h=%d: logits %.2e loss %.2e grad-norm %.2e' % (precision, S, d, h, e_l, e_loss, e_n))
+    assert e_l < tl and e_loss < tloss and e_n < tnorm, (e_l, e_loss, e_n)
+    if tgrad is None:
         return
     scale = max(float(g.abs().max()) for g in go.values())
     for k, g in go.items():
         err = float((gm[k].cpu().double() - g.double()).abs().max())
-        assert err < 2e-3 * max(float(g.abs().max()), 1e-3 * scale), (k, err, float(g.abs().max()))
+        assert err < tgrad * max(float(g.abs().max()), 1e-3 * scale), (k, err, float(g.abs().max()))
 
 
 def test_head_without_a_loss_position_is_nan_like_the_reference():
