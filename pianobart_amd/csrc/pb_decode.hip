@@ -836,10 +836,10 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int16_t* __restric
 // model.py:68-107 for the 8 heads of ONE position, on the device: logits row -> y = logit / T[h] -> softmax -> nucleus(p[h]) with
 // the uniform draw u[pos][h] the host drew AHEAD for this position (the draws do not depend on the logits, model.py:97 /
 // np.random.choice) -> the 8 ids of the next decoder input, written to tok_dev for the next step's embedding kernel, and -- with the
-// raw logits row -- to pinned host logs indexed by position. The arithmetic follows pb_nucleus_rows above statement for statement
-// (numpy's order: sequential f32 sums, probs /= (sum + 1e-5), descending order with ties by index, candidates up to the first
-// cumsum > p, q = cand / sum(cand), f64 cdf / cdf[-1] > u); what it cannot reproduce bit for bit is the CPU softmax the host path
-// uses (torch's vectorised exp and its summation order: 1 ulp apart), so the HOST remains the authority: it replays every position
+// raw logits row -- to pinned host logs indexed by position. The arithmetic follows pb_nucleus_rows above step for step (probs /= (sum +
+// 1e-5), descending order with ties by index, candidates up to the first cumsum > p, q = cand / sum(cand), f64 cdf / cdf[-1] > u) with
+// wave-parallel prefix sums in place of numpy's left-to-right ones (33 -> ~10 us per token); it cannot reproduce the host path bit
+// for bit anyway (torch's vectorised CPU exp and its summation order are 1 ulp apart), so the HOST remains the authority: it replays every position
 // from the logged logits row with the reference code path and rolls the decoder back on the (rare) position where the device chose
 // differently (Engine.generate). The device result is a PREDICTION that lets the next token start without a host round trip.
 // One workgroup of 512 threads: wave h = head h for the softmax and the scans; the rank counting of the heads with p < 1 uses one
@@ -856,18 +856,29 @@ struct SampleArgs {
     float temp[8], p[8];
 };
 constexpr int SMP_W = 272;                // >= the largest head (262), multiple of 16
+// inclusive prefix sums over a wave (lane order), by shuffles
+__device__ __forceinline__ float wave_scan_f(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+    return v;
+}
+__device__ __forceinline__ double wave_scan_d(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const double u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+    return v;
+}
 __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
-    __shared__ float pn[8][SMP_W];        // normalised probabilities, class order
-    __shared__ float sp[8][SMP_W];        // ... in descending order (heads with p < 1)
+    __shared__ __attribute__((aligned(16))) float pn[8][SMP_W];     // normalised probabilities, class order
+    __shared__ float sp[8][SMP_W + 64];   // ... in descending order (heads with p < 1), zero tail
     __shared__ int si[8][SMP_W];          // class of each sorted entry
-    __shared__ double cdf[8][SMP_W];      // running f64 sum of the candidates' renormalised probabilities
-    __shared__ float hsum[8];
-    __shared__ int hk[8], htok[8];
+    __shared__ int htok[8];
     const int t = threadIdx.x, lane = t & 63, h = t >> 6;
     const int pos = *a.pos;
     const int n = a.n[h], off = a.off[h];
     const float T = a.temp[h];
-    // softmax(logit / T) of head h (torch.softmax(logit / t, dim=-1), model.py:103-104)
+    // softmax(logit / T) of head h (torch.softmax(logit / t, dim=-1), model.py:103-104), then probs /= (sum(probs) + 1e-5) (model.py:85).
+    // The sums here are wave reductions, not numpy's left-to-right ones: a common divisor that differs in its last bit moves every
+    // probability alike, so the order and (but for a 1e-7 neighbourhood of a threshold) the choice stay -- the host checks every position.
     float y[5], e[5];
     float mx = -INFINITY;
 #pragma unroll
@@ -884,19 +895,14 @@ __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) { e[k] = (lane + 64 * k < n) ? expf(y[k] - mx) : 0.f; s += e[k]; }
     s = wave_sum(s);
+    float cs5 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) if (lane + 64 * k < n) pn[h][lane + 64 * k] = e[k] / s;
-    __syncthreads();
-    if (lane == 0) {                                           // np.cumsum(probs)[-1]: left to right in f32
-        float c = pn[h][0];
-        for (int i = 1; i < n; ++i) c = c + pn[h][i];
-        hsum[h] = c + 1e-5f;
-    }
-    __syncthreads();
-    {
-        const float c = hsum[h];
+    for (int k = 0; k < 5; ++k) { e[k] = e[k] / s; cs5 += e[k]; }
+    const float c1 = wave_sum(cs5) + 1e-5f;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) if (lane + 64 * k < n) pn[h][lane + 64 * k] = pn[h][lane + 64 * k] / c;      // probs /= (sum + 1e-5)
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        if (c < SMP_W) pn[h][c] = c < n ? e[k] / c1 : -1.f;     // -1 behind the head's classes: never ranked in front of a class
     }
     __syncthreads();
     // descending order of the heads with p < 1 by rank counting, one thread per (head, class): ties by class index
@@ -910,49 +916,49 @@ __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
         }
         if (hh >= 0) {
             const float v = pn[hh][c];
-            const int nn = a.n[hh];
+            const int nn4 = (a.n[hh] + 3) >> 2;
             int rank = 0;
-            for (int j = 0; j < nn; ++j) {
-                const float w = pn[hh][j];
-                rank += (w > v || (w == v && j < c)) ? 1 : 0;
+            for (int j4 = 0; j4 < nn4; ++j4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&pn[hh][4 * j4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rank += (w[r] > v || (w[r] == v && 4 * j4 + r < c)) ? 1 : 0;
             }
             sp[hh][rank] = v; si[hh][rank] = c;
         }
+        if (t < 8 * 64) sp[t >> 6][SMP_W + (t & 63)] = 0.f;
     }
     __syncthreads();
     const float ph = a.p[h];
-    const bool sorted = ph < 1.0f;                             // wave-uniform; every barrier below is reached by all 8 waves
-    if (sorted && lane == 0) {                                 // candidates: up to and including the first cumsum > p; none -> top 1
-        float cs = sp[h][0];
-        int first = cs > ph ? 0 : -1;
-        for (int i = 1; i < n && first < 0; ++i) { cs = cs + sp[h][i]; if (cs > ph) first = i; }
-        const int k = first < 0 ? 1 : first + 1;
-        float qs = sp[h][0];
-        for (int i = 1; i < k; ++i) qs = qs + sp[h][i];        // np.cumsum(q)[-1]
-        hk[h] = k; hsum[h] = qs;
-    }
-    __syncthreads();
-    if (sorted) {
-        const int k = hk[h];
-        const float qs = hsum[h];
-        for (int i = lane; i < k; i += 64) pn[h][i] = sp[h][i] / qs;                // q (pn is free now)
-    }
-    __syncthreads();
-    if (sorted && lane == 0) {
-        const int k = hk[h];
-        double cum = 0.0;
-        for (int i = 0; i < k; ++i) { cum += (double)pn[h][i]; cdf[h][i] = cum; }
-    }
-    __syncthreads();
-    if (sorted) {
-        const int k = hk[h];
-        const double last = cdf[h][k - 1], u = a.u[(size_t)pos * 8 + h];
-        int best = k - 1;                                      // first index with cdf / cdf[-1] > u
-        for (int i = lane; i < k; i += 64) if (cdf[h][i] / last > u) { best = i; break; }
+    if (ph < 1.0f) {                                            // wave-uniform; no barrier below
+        // lane l owns sorted entries 5 l .. 5 l + 4 (0 behind the head's classes): prefix sums in sorted order
+        float v5[5], pre[5];
+        float run = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const int i = 5 * lane + k; v5[k] = i < n ? sp[h][i] : 0.f; run += v5[k]; pre[k] = run; }
+        const float base = wave_scan_f(run, lane) - run;
+        int first = 0x7fffffff;                                  // candidates: up to and including the first cumsum > p; none -> top 1
+#pragma unroll
+        for (int k = 4; k >= 0; --k) if (5 * lane + k < n && base + pre[k] > ph) first = 5 * lane + k;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+        const int kc = first == 0x7fffffff ? 1 : first + 1;
+        float qpart = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (5 * lane + k < kc) qpart += v5[k];
+        const float qs = wave_sum(qpart);                        // sum of the candidates
+        double dpre[5], drun = 0.0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { if (5 * lane + k < kc) drun += (double)(v5[k] / qs); dpre[k] = drun; }
+        const double dbase = wave_scan_d(drun, lane) - drun;
+        const double last = __shfl(dbase + drun, 63, 64);       // cdf[-1]
+        const double u = a.u[(size_t)pos * 8 + h];
+        int best = kc - 1;                                       // first index with cdf / cdf[-1] > u
+#pragma unroll
+        for (int k = 4; k >= 0; --k) if (5 * lane + k < kc && (dbase + dpre[k]) / last > u) best = 5 * lane + k;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
         if (lane == 0) htok[h] = si[h][best];
-    } else {                                                   // p = 1: the cumsum never exceeds it -> the largest probability (lowest class among equals)
+    } else {                                                     // p = 1: the cumsum never exceeds it -> the largest probability (lowest class among equals)
         float bv = -1.f; int bi = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {

@@ -170,15 +170,16 @@ def test_g4_fused_step_matches_golden_adamw():
     assert np.allclose(psum, z['adamw_param_sum'], rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('lr', [2e-5, 1e-3])
-def test_five_training_steps_follow_the_oracle(lr):
+def test_five_training_steps_follow_the_oracle(lr, precision):
     """pretrain.py:159-196 five times over (fresh batch each step, dropout 0): forward, masked 8-head CE, backward, clip at 3.0, HF AdamW
     with its moments carried from step to step -- the fused HIP loop (pipelined parameter update included) ends on the oracle's
     parameters. lr 1e-3 makes the steps large enough that a wrong bias correction or decay order would show."""
     _need_gpu()
     from oracle import pianobart_oracle as O
     from pianobart_amd import ops
-    m = _lm(48, 64, 2, 128, 4, 61, 'fp32', dropout=0.0).train()
+    m = _lm(48, 64, 2, 128, 4, 61, precision, dropout=0.0).train()
     o = O.PianoBartLM(O.PianoBart(O.BartConfig(max_position_embeddings=48, d_model=64, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=128,
                                                decoder_ffn_dim=128, encoder_attention_heads=4, decoder_attention_heads=4, dropout=0.0), E2W, W2E)).train()
     o.load_state_dict(m.state_dict(), strict=True)
@@ -214,7 +215,8 @@ def test_five_training_steps_follow_the_oracle(lr):
         if po[k].grad is None:
             continue
         worst = max(worst, _rel(p.detach(), po[k].detach()))
-    assert worst < (2e-5 if lr < 1e-4 else 2e-3), worst
+    print('five steps %s lr %g: worst parameter %.2e' % (precision, lr, worst))
+    assert worst < (2e-5 if lr < 1e-4 else 2e-3) * (1 if precision == 'fp32' else 3), worst       # AdamW's first steps are sign-like: a 1e-5 gradient error moves a near-zero-gradient element by lr
 
 
 def test_dropout_train_step_is_consistent():
@@ -363,7 +365,7 @@ def test_generate_kv_cache_equals_full_rerun(precision, d, heads):
     assert int((a[0, :, 0] != 256).sum()) == 48         # every position was generated
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 8e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16x3', 1e-4), ('bf16', 8e-2)])
 def test_head_dim_96(precision, tol):
     """Reference CLI default heads=8 gives head_dim 96 at d=768: fused attention with a half-filled second [64][64] image (bf16);
     GEMM + masked softmax in the exact-f32 instantiation."""
@@ -383,10 +385,10 @@ def test_head_dim_96(precision, tol):
     assert abs(float(total) - float(total_o)) / float(total_o) < tol
     go = dict(o.named_parameters()); gm = dict(m.named_parameters())
     for k in ('pianobart.bart.encoder.layers.0.self_attn.q_proj.weight', 'pianobart.bart.decoder.layers.0.encoder_attn.v_proj.weight', 'pianobart.word_emb.3.lut.weight'):
-        assert _rel(gm[k].grad, go[k].grad) < (1e-3 if precision == 'fp32' else 0.2), k
+        assert _rel(gm[k].grad, go[k].grad) < (1e-3 if precision != 'bf16' else 0.2), k
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 6e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16x3', 1e-4), ('bf16', 6e-2)])
 def test_ragged_length_and_fully_padded_sample(precision, tol):
     """S = 200 (not a multiple of the 64/128-row attention tiles), head_dim 64 (flash64 path in bf16), one sample that is
     PAD from the first row on (every encoder key masked -> zero-row rule), B = 3: logits, loss and grad norm vs the oracle."""
@@ -415,7 +417,7 @@ def test_ragged_length_and_fully_padded_sample(precision, tol):
     total.backward()
     assert abs(float(total) - float(total_o)) / float(total_o) < tol
     gn = lambda mod: float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in mod.parameters() if p.grad is not None)))
-    assert abs(gn(m) - gn(o)) / gn(o) < (1e-3 if precision == 'fp32' else 5e-2)
+    assert abs(gn(m) - gn(o)) / gn(o) < (1e-3 if precision != 'bf16' else 5e-2)
 
 
 def test_tiny_batch_one_short_sequence():

@@ -50,6 +50,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_VALU_MFMA_BUS
 done
 python tools/sq_summary.py $O/p1 $O/p2 $O/p3 $O/p4 > $O/${TAG}_sq_counters_attention.txt 2>&1; rm -rf $O/p[1-4]
 timeout 600 rocprofv3 --kernel-trace -d $R/$O/prof_dec -- python3 bench.py --mode decode --no-cpu-baseline --steps 200 > $O/prof_dec.log 2>&1
-{ echo "# rocprofv3 --kernel-trace -- python3 bench.py --mode decode --no-cpu-baseline --steps 200   (12L/768d, S = 1024, B = 1; one hipGraph replay per token)"; python tools/rocpd_decode.py $(ls $O/prof_dec/*/*.db | head -1); tail -1 $O/prof_dec.log | cut -c1-400; } > $O/${TAG}_decode_kernel_stats.txt 2>&1
+{ echo "# rocprofv3 --kernel-trace -- python3 bench.py --mode decode --no-cpu-baseline --steps 200   (12L/768d, S = 1024, B = 1; device-sampled decode: 8 tokens per hipGraph replay, 75 launches per token)"; python tools/rocpd_decode.py $(ls $O/prof_dec/*/*.db | head -1); tail -1 $O/prof_dec.log | cut -c1-400; } > $O/${TAG}_decode_kernel_stats.txt 2>&1
 rm -rf $O/prof_dec
 ls -la $O; head -12 $O/${TAG}_bench_b32_packed_kernel_stats_two_streams.txt

@@ -5,7 +5,7 @@ db = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if 'kernel_dispatch' in t][0]; ks = [t for t in tabs if 'kernel_symbol' in t][0]
 rows = list(db.execute(f"select d.start,d.end,s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-dec = [r for r in rows if 'gemv' in r[2] or 'attn_decode' in r[2] or 'attn_split' in r[2] or 'decode' in r[2] or 'embed_ln_fwd' in r[2] or 'dec_attn' in r[2] or 'dec_embed' in r[2]]
+dec = [r for r in rows if 'gemv' in r[2] or 'attn_decode' in r[2] or 'attn_split' in r[2] or 'decode' in r[2] or 'embed_ln_fwd' in r[2] or 'dec_attn' in r[2] or 'dec_embed' in r[2] or 'dec_sample' in r[2]]
 c, t = collections.Counter(), collections.Counter()
 for r in dec:
     c[r[2][:70]] += 1; t[r[2][:70]] += (r[1] - r[0]) / 1e3
