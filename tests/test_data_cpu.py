@@ -169,7 +169,7 @@ def test_documented_env_toggles_are_the_ones_the_code_reads():
         read |= set(re.findall(r"environ(?:\.get\(|\[|\.setdefault\()\s*'(PB_[A-Z0-9_]+)'", txt))
         read |= set(re.findall(r"\b(PB_[A-Z0-9_]+)=", txt)) if path.endswith('.sh') else set()
     docs = rd('DESIGN.md') + rd('README.md') + rd('INTEGRATION.md')
-    flags = set(re.findall(r'\bPB_GEMM_[A-Z0-9_]+|\bPB_BF16|\bPB_F32', docs + ''.join(code.values())))       # C-ABI constants, not environment names
+    flags = set(re.findall(r'\bPB_GEMM_[A-Z0-9_]+|\bPB_BF16|\bPB_F32X3|\bPB_F32', docs + ''.join(code.values())))       # C-ABI constants, not environment names
     documented = set(re.findall(r'`(PB_[A-Z0-9_]+)(?:=[^`]*)?`', docs)) - flags
     pkg_read = set()
     for path, txt in code.items():
