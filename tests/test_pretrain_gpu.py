@@ -64,6 +64,41 @@ def test_main_pretrain_cfg1_end_to_end(tmp_path, capsys):
     assert losses[-1] < losses[0]                                                       # it learns
 
 
+def test_main_pretrain_in_the_split_bf16_instantiation(tmp_path, capsys):
+    """`--precision bf16x3` through the whole driver (device corruption, fused step with split-bf16 GEMMs and fused split-bf16 attention, clip, AdamW,
+    validation, checkpoint): the run learns, its checkpoint loads into the reference layout, and its first-epoch losses are the exact-f32 run's to 1e-3
+    (same seeds: the two instantiations draw the same corruption and dropout bits)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from oracle import pianobart_oracle as O
+    from pianobart_amd.pretrain import pretrain
+    data_root = str(tmp_path / 'Data' / 'output_pretrain')
+    _write_dataset(data_root)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    logs = {}
+    try:
+        for prec in ('bf16x3', 'fp32'):
+            np.random.seed(0); torch.manual_seed(0)
+            import random
+            random.seed(0)
+            pretrain(['--dict_file', VOCAB_JSON, '--name', prec, '--datasets', 'syn', '--num_workers', '0', '--batch_size', '2', '--max_seq_len', '128',
+                      '--hs', '128', '--layers', '2', '--ffn_dims', '512', '--heads', '4', '--epochs', '2', '--lr', '1e-3', '--cuda_devices', '0',
+                      '--precision', prec, '--data_root', data_root, '--quiet'])
+            logs[prec] = open('result/pretrain/%s/log' % prec).read().splitlines()
+        ck = torch.load('result/pretrain/bf16x3/model.ckpt', weights_only=False)
+    finally:
+        os.chdir(cwd)
+    capsys.readouterr()
+    cfg = O.BartConfig(max_position_embeddings=128, d_model=128, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512,
+                       decoder_ffn_dim=512, encoder_attention_heads=4, decoder_attention_heads=4)
+    O.PianoBart(cfg, E2W, W2E).load_state_dict(ck['state_dict'], strict=True)
+    loss = lambda l: float(re.search(r'train_loss=([\d.]+)', l).group(1))
+    x3, f32 = [loss(l) for l in logs['bf16x3'][:2]], [loss(l) for l in logs['fp32'][:2]]
+    assert x3[1] < x3[0]
+    assert abs(x3[0] - f32[0]) <= 2e-3 * f32[0] + 1.01e-3, (x3, f32)          # the log rounds to 3 decimals
+
+
 def test_pretrain_resume_continues_the_run(tmp_path, capsys):
     """--resume (the checkpoint's moments had no loader and the heads' moments no weights beside them): the file holds PianoBart's
     state_dict (reference format), and inside 'optimizer' the LM heads + named AdamW moments + step; a resumed run continues epoch numbering,
