@@ -43,7 +43,7 @@ def run(precision, args, batches):
 def overlay(args):
     from tests.golden_util import synth_octuple_batch
     batches = [synth_octuple_batch(args.batch, args.seq, seed=100 + i) for i in range(args.nbatch)]
-    lb = run('bf16', args, batches)
+    lb = run(args.precision, args, batches)
     lf = run('fp32', args, batches)
     return lb, lf
 
@@ -61,15 +61,18 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--lr', type=float, default=1e-4)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'], help='the instantiation laid over the exact-f32 one')
     args = ap.parse_args()
     lb, lf = overlay(args)
     gap = [abs(a - b) / b for a, b in zip(lb, lf)]
     tail = max(1, min(10, args.steps // 4))
     mean = lambda v: sum(v) / len(v)
-    lines = ['# tools/loss_overlay.py --steps %d --batch %d --nbatch %d --lr %g --layers %d --dropout %g   (12L/768d/ffn3072/12h unless said, S = %d; same initial '
+    what = {'bf16': 'the throughput instantiation (bf16 storage / MFMA, f32 accumulation, f32 masters and moments)',
+            'bf16x3': 'the split-bf16 parity instantiation (f32 storage, GEMMs and attention as bf16 triples on the bf16 MFMA)'}[args.precision]
+    lines = ['# tools/loss_overlay.py --precision %s --steps %d --batch %d --nbatch %d --lr %g --layers %d --dropout %g   (12L/768d/ffn3072/12h unless said, S = %d; same initial '
              'weights, same batches in the same order, same Philox dropout seeds; fused step + HF-AdamW; 1x MI355X)' %
-             (args.steps, args.batch, args.nbatch, args.lr, args.layers, args.dropout, args.seq),
-             '# loss_bf16 = the throughput instantiation (bf16 storage / MFMA, f32 accumulation, f32 masters and moments); loss_f32 = the exact-f32 parity instantiation',
+             (args.precision, args.steps, args.batch, args.nbatch, args.lr, args.layers, args.dropout, args.seq),
+             '# loss_bf16 column = %s; loss_f32 = the exact-f32 parity instantiation' % what,
              '# max |gap| over the run %.3e (step %d); mean gap of the last %d steps %.3e; final losses %.6f (bf16) %.6f (f32); first %.6f / %.6f' %
              (max(gap), gap.index(max(gap)), tail, mean(gap[-tail:]), lb[-1], lf[-1], lb[0], lf[0]),
              '# step  loss_bf16  loss_f32  rel_gap']
