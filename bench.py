@@ -502,7 +502,7 @@ def other_instantiations(args, cfgkw, dev):
     except Exception as ex:                                            # noqa: BLE001
         out["fp32_parity_step"] = {"error": repr(ex)[:200]}
     try:
-        for B3 in (4, 16):
+        for B3 in (4, 16, args.batch):
             ms, fl, rows = side_model_step(cfgkw, 'bf16x3', B3, args.seq, dev, 3)
             key = "bf16x3_parity_step" if B3 == 4 else "bf16x3_parity_step_b%d" % B3
             out[key] = {"ms_per_step": ms, "batch": B3, "tokens_per_s": B3 * args.seq / (ms * 1e-3), "rows": rows,

@@ -1005,6 +1005,7 @@ struct Decoder {
     float* logits_host = nullptr;          // pinned
     hipEvent_t ev = nullptr;
     int launches = 0, use_graph = 1, ck_cross = 0, nsplit_cross = 0;
+    int ns_self = PB_DECODE_MAX_SPLITS, ns_cross = PB_DECODE_MAX_SPLITS;    // workgroups per head of the two attention launches (records per head)
     int steps = 0;                         // tokens decoded since the last reset: the device position must stay inside the caches (plan.S rows)
     size_t lds_attn = 0;
 };
@@ -1036,7 +1037,7 @@ static int decoder_issue(Decoder* D, hipStream_t st, int* count) {
     char* x = (char*)p->x; char* alt = (char*)p->y2;
     char* h = x;
     LnIn ln{nullptr, nullptr, nullptr, nullptr};
-    const MergeIn mg{p->attn_part, PB_DECODE_MAX_SPLITS, hd, hd + 4};
+    const MergeIn mg_self{p->attn_part, D->ns_self, hd, hd + 4}, mg_cross{p->attn_part, D->ns_cross, hd, hd + 4};
     for (int l = 0; l < p->n_layers; ++l) {
         const pb_decode_layer& L = p->layers[l];
         DecAttnArgs a{};
@@ -1045,11 +1046,11 @@ static int decoder_issue(Decoder* D, hipStream_t st, int* count) {
         a.x_in = (const bf16_t*)h; a.res = (const bf16_t*)ln.res; a.add = (const bf16_t*)p->a; a.gamma = ln.gamma; a.beta = ln.beta; a.ln_out = (bf16_t*)ln.out;
         a.Wq = (const bf16_t*)L.wqkv; a.bq = L.bqkv;
         a.Wk = a.Wq + (size_t)d * d; a.bk = L.bqkv + d; a.Wv = a.Wq + (size_t)2 * d * d; a.bv = L.bqkv + 2 * d;
-        a.kc = (bf16_t*)L.kv_self; a.vc = a.kc + d; a.key_mask = nullptr; a.nreg = PB_DECODE_MAX_SPLITS - 1; a.ck_fixed = 0; a.Sk_fixed = 0;
-        if (dec_attn_launch(a, true, H, hd, PB_DECODE_MAX_SPLITS, D->lds_attn, st)) return -1;
+        a.kc = (bf16_t*)L.kv_self; a.vc = a.kc + d; a.key_mask = nullptr; a.nreg = D->ns_self - 1; a.ck_fixed = 0; a.Sk_fixed = 0;
+        if (dec_attn_launch(a, true, H, hd, D->ns_self, D->lds_attn, st)) return -1;
         ++n;
         if (ln.res) h = alt;
-        if (gemv_launch(L.wo, p->ctx, L.bo, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, mg)) return -1;
+        if (gemv_launch(L.wo, p->ctx, L.bo, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, mg_self)) return -1;
         ++n;
         // cross-attention: LN1(h + a) -> y1, q_c, the cached encoder keys
         DecAttnArgs c{};
@@ -1057,9 +1058,9 @@ static int decoder_issue(Decoder* D, hipStream_t st, int* count) {
         c.x_in = nullptr; c.res = (const bf16_t*)h; c.add = (const bf16_t*)p->a; c.gamma = L.ln1_w; c.beta = L.ln1_b; c.ln_out = (bf16_t*)p->y1;
         c.Wq = (const bf16_t*)L.wq_c; c.bq = L.bq_c;
         c.kc = (bf16_t*)const_cast<void*>(L.kv_cross); c.vc = c.kc + d; c.key_mask = p->enc_mask; c.nreg = D->nsplit_cross; c.ck_fixed = D->ck_cross; c.Sk_fixed = p->S_enc;
-        if (dec_attn_launch(c, false, H, hd, PB_DECODE_MAX_SPLITS, D->lds_attn, st)) return -1;
+        if (dec_attn_launch(c, false, H, hd, D->ns_cross, D->lds_attn, st)) return -1;
         ++n;
-        if (gemv_launch(L.wo_c, p->ctx, L.bo_c, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, mg)) return -1;
+        if (gemv_launch(L.wo_c, p->ctx, L.bo_c, p->a, nullptr, d, d, d, dt, 0, 0, st, LnIn{nullptr, nullptr, nullptr, nullptr}, mg_cross)) return -1;
         ++n;
         // FFN: fc1 applies LNc(y1 + a) -> yc
         if (gemv_launch(L.w1, p->a, L.b1, p->g, nullptr, f, f, d, dt, 0, 1, st, LnIn{p->y1, L.lnc_w, L.lnc_b, p->yc})) return -1;
@@ -1094,10 +1095,15 @@ extern "C" int pb_decoder_create(const pb_decode_plan* plan, void** out) {
         return -1;
     }
     // cross-attention: <= 16 splits of >= 64 keys over the visible encoder positions (fixed for the prompt)
-    int ck = (plan->S_enc + PB_DECODE_MAX_SPLITS - 1) / PB_DECODE_MAX_SPLITS;
+    // Every (head, split) workgroup projects q of its head itself (hd rows of W_q: 98 KB at cfg 2), so the split count trades K / V rows
+    // per workgroup against re-reads of W_q: PB_DECODE_SPLITS_SELF / _CROSS (2 .. 16; developer A/B, profiles/r06_decode_splits_ab.txt)
+    auto env_splits = [](const char* name, int dflt) { const char* e = getenv(name); int v = e ? atoi(e) : dflt; return v < 2 ? 2 : (v > PB_DECODE_MAX_SPLITS ? PB_DECODE_MAX_SPLITS : v); };
+    D->ns_self = env_splits("PB_DECODE_SPLITS_SELF", PB_DECODE_MAX_SPLITS);
+    D->ns_cross = env_splits("PB_DECODE_SPLITS_CROSS", PB_DECODE_MAX_SPLITS);
+    int ck = (plan->S_enc + D->ns_cross - 1) / D->ns_cross;
     ck = ck < 64 ? 64 : (ck + 15) & ~15;
-    D->ck_cross = ck; D->nsplit_cross = PB_DECODE_MAX_SPLITS;
-    int ck_self = (plan->S + PB_DECODE_MAX_SPLITS - 2) / (PB_DECODE_MAX_SPLITS - 1);
+    D->ck_cross = ck; D->nsplit_cross = D->ns_cross;
+    int ck_self = (plan->S + D->ns_self - 2) / (D->ns_self - 1);
     ck_self = ck_self < 64 ? 64 : (ck_self + 15) & ~15;
     D->lds_attn = sizeof(float) * (size_t)(5 * hd + (ck > ck_self ? ck : ck_self) + 16);
     *out = D;
