@@ -431,14 +431,15 @@ int pb_decoder_seek(void* dec, int32_t pos, const int16_t* tok8);
  * bf16 matrix cores (see PB_F32X3), softmax in f32 -- instead of the unfused QK^T -> softmax -> PV chain of the exact-f32 path
  * (modeling_bart.py:115-140 through PianoBart.py:76), whose (B, H, S, S) f32 matrices dominate that path's HBM time. Same masks and
  * conventions as pb_flash_fwd / pb_flash_bwd (key padding row per batch, bit 0 of `causal`, zero output row + lse = +inf for a query
- * without a visible key); strides in ELEMENTS, multiples of 4; head_dim 32 / 64 / 128 (pb_flash_x3_supported). delta: (B, H, Sq) f32
- * scratch, written by the call. */
+ * without a visible key); strides in ELEMENTS, multiples of 4; head_dim 32 / 64 / 128 (pb_flash_x3_supported). kmax (may be NULL): per batch
+ * row 1 + the last visible key (pb_key_extent of the mask): key tiles behind it are skipped, results unchanged. delta: (B, H, Sq) f32 scratch,
+ * written by the call. */
 int pb_flash_x3_supported(int32_t hd);
-int pb_flash_fwd_x3(const float* q, const float* k, const float* v, float* o, float* lse, const float* key_mask, int32_t B, int32_t H, int32_t Sq,
+int pb_flash_fwd_x3(const float* q, const float* k, const float* v, float* o, float* lse, const float* key_mask, const int32_t* kmax, int32_t B, int32_t H, int32_t Sq,
                     int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb,
                     int64_t o_ss, float scale, int32_t causal, void* stream);
 int pb_flash_bwd_x3(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, const float* key_mask,
-                    float* dq, float* dk, float* dv, float* delta, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb,
+                    const int32_t* kmax, float* dq, float* dk, float* dv, float* delta, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb,
                     int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb,
                     int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, void* stream);
 

@@ -166,6 +166,7 @@ struct FxArgs {
     const float *q, *k, *v, *o, *dout;
     float *out, *dq, *dk, *dv;
     float* lse; const float* delta; const float* key_mask;
+    const int* kmax;                                          // per batch row: 1 + last visible key (keys at and behind it are masked for every query), or NULL
     int B, H, Sq, Sk;
     long q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
     float scale; int causal;
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fwd_kernel(const FxArgs p) {
     for (int i = 0; i < DT; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
     const float c = p.scale * XLOG2E;
-    const int kend = p.causal ? min(p.Sk, q0 + XQ) : p.Sk;
+    int kend = p.causal ? min(p.Sk, q0 + XQ) : p.Sk;
+    if (p.kmax) kend = min(kend, p.kmax[b]);                  // key tiles behind the last visible key contribute exact zeros: skipped
     for (int k0 = 0; k0 < kend; k0 += XK) {
         __syncthreads();
         xstage_rows<HD>(Kh, Kl, K + (long)k0 * p.k_ss, p.k_ss, p.Sk - k0, t);
@@ -301,6 +303,16 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dkv_kernel(const FxArgs p) 
         xfrag_global(V, p.v_ss, mykey, p.Sk, ks * 32 + g * 8, vh[ks], vl[ks]);
     }
     const bool kvis = mykey < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + mykey] != 0.f);
+    if (p.kmax && k0 >= p.kmax[b]) {                          // no visible key in this block: its keys receive zero gradient
+        for (int i = t; i < XK * (HD / 4); i += FX_THREADS) {
+            const int key = k0 + i / (HD / 4), c4 = (i % (HD / 4)) * 4;
+            if (key < p.Sk) {
+                *reinterpret_cast<f32x4*>(p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HD + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HD + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        return;
+    }
     f32x4 dk[DT], dv[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -399,7 +411,8 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq_kernel(const FxArgs p) {
 #pragma unroll
     for (int i = 0; i < DT; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c = p.scale * XLOG2E;
-    const int kend = p.causal ? min(p.Sk, q0 + XQ) : p.Sk;
+    int kend = p.causal ? min(p.Sk, q0 + XQ) : p.Sk;
+    if (p.kmax) kend = min(kend, p.kmax[b]);                  // key tiles behind the last visible key contribute exact zeros: skipped
     for (int k0 = 0; k0 < kend; k0 += XK) {
         __syncthreads();
         xstage_both<HD>(Kh, Kl, KTh, KTl, K + (long)k0 * p.k_ss, p.k_ss, p.Sk - k0, t);
@@ -467,7 +480,7 @@ template <class F> int opt_in_lds(F fn, size_t bytes) {
 
 extern "C" int pb_flash_x3_supported(int32_t hd) { return (hd == 32 || hd == 64 || hd == 128) ? 1 : 0; }
 
-extern "C" int pb_flash_fwd_x3(const float* q, const float* k, const float* v, float* o, float* lse, const float* key_mask, int32_t B, int32_t H, int32_t Sq,
+extern "C" int pb_flash_fwd_x3(const float* q, const float* k, const float* v, float* o, float* lse, const float* key_mask, const int32_t* kmax, int32_t B, int32_t H, int32_t Sq,
                                int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb,
                                int64_t o_ss, float scale, int32_t causal, void* stream_) {
     const long st[8] = {q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss};
@@ -475,7 +488,7 @@ extern "C" int pb_flash_fwd_x3(const float* q, const float* k, const float* v, f
     PB_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "pb_flash_fwd_x3: operands must be 16-byte aligned");
     if (B <= 0 || H <= 0 || Sq <= 0) return 0;
     FxArgs a = {};
-    a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.key_mask = key_mask;
+    a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.key_mask = key_mask; a.kmax = key_mask ? kmax : nullptr;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal & 1;
     dim3 grid((Sq + XQ - 1) / XQ, H, B);
@@ -486,7 +499,7 @@ extern "C" int pb_flash_fwd_x3(const float* q, const float* k, const float* v, f
 }
 
 extern "C" int pb_flash_bwd_x3(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, const float* key_mask,
-                               float* dq, float* dk, float* dv, float* delta, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb,
+                               const int32_t* kmax, float* dq, float* dk, float* dv, float* delta, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb,
                                int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb,
                                int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -496,7 +509,7 @@ extern "C" int pb_flash_bwd_x3(const float* q, const float* k, const float* v, c
                "pb_flash_bwd_x3: operands must be 16-byte aligned");
     if (B <= 0 || H <= 0 || Sq <= 0) return 0;
     FxArgs a = {};
-    a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask; a.kmax = key_mask ? kmax : nullptr;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
     a.scale = scale; a.causal = causal & 1;

@@ -405,7 +405,8 @@ class Engine:
             return
         if self.use_flash and self.x3:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
-            ops.flash_fwd_x3(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), save['lse'], key_mask, B, H, Sq, Sk, hd, hd ** -0.5, causal)
+            ops.flash_fwd_x3(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), save['lse'], key_mask, B, H, Sq, Sk, hd, hd ** -0.5, causal,
+                             kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None)
             return
         if self.use_flash:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
@@ -437,7 +438,7 @@ class Engine:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
             assert dout[1] == 0 and dout[2] == out[2]
             ops.flash_bwd_x3(ex(q, Sq), ex(k, Sk), ex(v, Sk), ex(out, Sq), dout[0], save['lse'], key_mask, ex(dq, Sq), ex(dk, Sk), ex(dv, Sk),
-                             ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal)
+                             ws['delta'], B, H, Sq, Sk, hd, hd ** -0.5, causal, kmax=self._kmax.get(id(key_mask)) if key_mask is not None else None)
             return False
         if self.use_flash:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
@@ -511,7 +512,7 @@ class Engine:
         self._tables_ready = False
         # per-batch-row key extents (1 + last visible key): the attention kernels skip the masked PAD tail tile-wise
         self._kmax = {}
-        if self.use_flash and self.hd in (64, 96, 128) and pack is None:
+        if self.use_flash and (self.x3 or self.hd in (64, 96, 128)) and pack is None:
             for msk in (emask, dmask):
                 if msk is not None and id(msk) not in self._kmax:
                     km = torch.empty(msk.shape[0], dtype=torch.int32, device=msk.device)

@@ -247,19 +247,19 @@ def flash_bwd(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, 
              _p(dbias[2]) if dbias else None, _p(dbias_ws) if dbias else None, _stream())
 
 
-def flash_fwd_x3(q, k, v, o, lse, key_mask, B, H, Sq, Sk, hd, scale, causal):
+def flash_fwd_x3(q, k, v, o, lse, key_mask, B, H, Sq, Sk, hd, scale, causal, kmax=None):
     """Fused attention of the bf16x3 instantiation. q,k,v,o: (tensor, element offset, row stride, batch stride) f32."""
     (qt, qo, qs, qb), (kt, ko, ks, kb), (vt, vo, vs, vb), (ot, oo, os_, ob) = q, k, v, o
     pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
-    LIB.call('pb_flash_fwd_x3', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(lse), _p(key_mask), B, H, Sq, Sk, hd,
+    LIB.call('pb_flash_fwd_x3', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(lse), _p(key_mask), _p(kmax), B, H, Sq, Sk, hd,
              qb, qs, kb, ks, vb, vs, ob, os_, scale, int(causal), _stream())
 
 
-def flash_bwd_x3(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal):
+def flash_bwd_x3(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, Sk, hd, scale, causal, kmax=None):
     (qt, qo, qs, qb), (kt, ko, ks, kb), (vt, vo, vs, vb), (ot, oo, os_, ob) = q, k, v, o
     (dqt, dqo, dqs, dqb), (dkt, dko, dks, dkb), (dvt, dvo, dvs, dvb) = dq, dk, dv
     pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
-    LIB.call('pb_flash_bwd_x3', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), _p(key_mask), pp(dqt, dqo), pp(dkt, dko),
+    LIB.call('pb_flash_bwd_x3', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), _p(key_mask), _p(kmax), pp(dqt, dqo), pp(dkt, dko),
              pp(dvt, dvo), _p(delta), B, H, Sq, Sk, hd, qb, qs, kb, ks, vb, vs, ob, os_, dqb, dqs, dkb, dks, dvb, dvs, scale, int(causal), _stream())
 
 

@@ -823,3 +823,11 @@ def test_flash_attention_x3_fwd_bwd(ops, hd, causal, S):
     e_grad = float((dqkv.double() - qd.grad).abs().max() / qd.grad.abs().max())
     print('flash x3 hd=%d S=%d causal=%d: out %.2e  lse %.2e  grads %.2e' % (hd, S, causal, e_out, e_lse, e_grad))
     assert e_out < 3e-5 and e_lse < 1e-4 and e_grad < 5e-5
+    # key extents (1 + last visible key per batch row): the tiles behind them are skipped, the results do not change by a bit
+    kmax = torch.empty(B, dtype=torch.int32, device='cuda')
+    ops.key_extent(km, kmax)
+    out2 = torch.full_like(out, float('nan')); lse2 = torch.empty_like(lse); dqkv2 = torch.full_like(dqkv, float('nan'))
+    d2 = lambda off: (dqkv2, off, 3 * d, S * 3 * d)
+    ops.flash_fwd_x3(sl(0), sl(d), sl(2 * d), (out2, 0, d, S * d), lse2, km, B, H, S, S, hd, scale, causal, kmax=kmax)
+    ops.flash_bwd_x3(sl(0), sl(d), sl(2 * d), (out2, 0, d, S * d), dout, lse2, km, d2(0), d2(d), d2(2 * d), delta, B, H, S, S, hd, scale, causal, kmax=kmax)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2) and torch.equal(dqkv, dqkv2)
