@@ -784,7 +784,7 @@ def test_gemm_f32x3_batched_strided_like_the_unfused_attention(ops):
 
 @pytest.mark.parametrize('hd', [32, 64, 128])
 @pytest.mark.parametrize('causal', [False, True])
-@pytest.mark.parametrize('S', [64, 200, 136])
+@pytest.mark.parametrize('S', [64, 200, 136, 328])          # 328: at 256 rows and more the operands are cut into bf16 planes by a prepass
 def test_flash_attention_x3_fwd_bwd(ops, hd, causal, S):
     """Fused attention of the bf16x3 instantiation (f32 tensors, split-bf16 triples on the bf16 MFMA, f32 softmax) vs an fp64 reference: key-padding
     masks, causal, ragged S, a query without a visible key (zero row). ~1e-5 of the output scale, where the bf16 kernels are at 1e-2."""
