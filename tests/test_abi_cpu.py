@@ -44,3 +44,17 @@ def test_persistent_gemm_isa_has_no_spills_and_no_copies_of_in_flight_fragments(
     spec.loader.exec_module(mod)
     errs, meta = mod.check(mod.disassemble())
     assert len(meta) == 2 and not errs, errs[:5]
+
+
+def test_persistent_gemm_waits_for_exactly_what_its_epilogues_issue():
+    """tools/check_gemm_epilogue_vmem.py: the persistent GEMM's cross-item wait (`pend`) is a hand count of the VMEM instructions each epilogue
+    variant leaves in flight; the check compiles every variant alone (probe kernels over the textually included pb_gemm2.hip), counts its global loads and
+    stores in the gfx950 ISA and compares with the `pend` literals of the kernel source -- one store more or fewer in an epilogue fails here instead of racing."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('check_gemm_epilogue_vmem', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'check_gemm_epilogue_vmem.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    errs, got, table = mod.check()
+    assert len(got) == 7 and not errs, errs
+    assert table == {'plain': 16, 'wide': 32, 'epf': 32, 'epf_cs': 36, 'epf3': 40}
