@@ -359,3 +359,18 @@ def test_bf16_loss_curve_follows_the_exact_f32_curve():
     assert gap[0] < 1e-4                                                  # the same forward at step 0 (measured 2e-6 at B = 8)
     assert max(gap) < 3e-2 and sum(gap[-4:]) / 4 < 2e-2                   # measured at B = 2: max 1.07e-2 (the B = 8 / 200-step run peaks at 3.5e-2)
     assert lf[-1] < 0.8 * lf[0] and lb[-1] < 0.8 * lb[0]                  # both learn
+
+
+def test_split_bf16_loss_curve_stays_on_the_exact_f32_curve():
+    """The bf16x3 parity instantiation as a TRAINING run against the exact-f32 one (same weights, batches, Philox dropout bits; tools/loss_overlay.py
+    --precision bf16x3; 200 steps at B = 8 are committed as profiles/r06_loss_overlay_bf16x3.txt: gap <= 4e-7 for 50 steps, 8e-4 at most). Here: B = 2, 24 steps."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import types
+    from tools import loss_overlay as LO
+    args = types.SimpleNamespace(steps=24, batch=2, nbatch=4, seq=1024, layers=12, hs=768, ffn=3072, heads=12, dropout=0.1, lr=1e-4, precision='bf16x3')
+    lx, lf = LO.overlay(args)
+    gap = [abs(a - b) / b for a, b in zip(lx, lf)]
+    print('bf16x3 vs f32 loss, 24 steps: first %.6f / %.6f, last %.6f / %.6f, max gap %.2e' % (lx[0], lf[0], lx[-1], lf[-1], max(gap)))
+    assert gap[0] < 1e-6 and max(gap) < 1e-4
+    assert lf[-1] < 0.8 * lf[0]

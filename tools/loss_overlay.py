@@ -43,7 +43,7 @@ def run(precision, args, batches):
 def overlay(args):
     from tests.golden_util import synth_octuple_batch
     batches = [synth_octuple_batch(args.batch, args.seq, seed=100 + i) for i in range(args.nbatch)]
-    lb = run(args.precision, args, batches)
+    lb = run(getattr(args, 'precision', 'bf16'), args, batches)
     lf = run('fp32', args, batches)
     return lb, lf
 
