@@ -29,6 +29,7 @@ _NO_DEFER = False                  # settled (round 2): True reduces every bias 
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
 _ROWDOT = int(os.environ.get('PB_ROWDOT', '1'))                                  # 1 = delta of the one-pass attention backward from the out-projection dgrad's epilogue (0: a separate pass)
 _DP_RESERVE_CUS = int(os.environ.get('PB_DP_RESERVE_CUS', '0'))                 # data parallel: 0 = backward GEMMs as ordinary grids (default: +0.45 ms at world 1, profiles/r06_dp_mode_ab.txt); n > 0 = persistent grids that leave n CUs to RCCL's kernels (+1.0 / +1.4 ms for 8 / 16)
+_SIDE_PRIORITY = int(os.environ.get('PB_SIDE_PRIORITY', '0'))                      # HIP priority of the second stream (1 = low, -1 = high; developer A/B)
 _X3_FLASH = int(os.environ.get('PB_X3_FLASH', '1'))                            # bf16x3: 1 = fused split-bf16 attention (pb_flash_*_x3), 0 = the unfused QK^T / softmax / PV chain of the exact-f32 path
 _DECODE_SPEC = int(os.environ.get('PB_DECODE_SPEC', '1'))                       # 1 = device-side sampling ahead of the host where the caller names the sampler (Engine._generate_device_sampled), 0 = one host round trip per token
 _DECODE_GRAPH = int(os.environ.get('PB_DECODE_GRAPH', '1'))                     # 1 = one hipGraph replay per token (6 launches per layer), 0 = the same launches issued directly, -1 = the round-2 per-launch loop (the persistent-kernel forms of round 4, measured slower, left the library in round 5: profiles/r04_decode_persistent.txt)
@@ -84,6 +85,21 @@ class _Slot:
     def __init__(self, off, shape):
         self.off, self.shape = off, tuple(shape)
         self.numel = int(np.prod(shape))
+
+
+def _new_stream(device):
+    """A HIP stream for the engine's second stream. PB_SIDE_PRIORITY=1 (developer A/B) makes it a LOW-priority one: torch clamps priorities to
+    [-1, 0], HIP has -1 / 0 / 1, so the stream is created through the runtime and wrapped."""
+    if _SIDE_PRIORITY == 0:
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipStreamCreateWithPriority(ctypes.byref(st), 1, _SIDE_PRIORITY)          # 1 = hipStreamNonBlocking
+    if rc != 0 or not st.value:
+        return torch.cuda.Stream(device=device)
+    return torch.cuda.ExternalStream(st.value, device=device)
 
 
 class Engine:
@@ -660,7 +676,7 @@ class Engine:
             tiny = torch.empty(64, dtype=torch.float32, device=self.device)
             self._side_pool = []
             for _ in range(12):
-                cand = torch.cuda.Stream(device=self.device)
+                cand = _new_stream(self.device)
                 self._side_pool.append(cand)            # keep the rejected ones referenced so the pool hands out a different stream next
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 torch.cuda.synchronize(self.device)
