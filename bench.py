@@ -729,7 +729,7 @@ def main():
     value = tokens / dt
     fpt = train_flops_per_token(S, args.hs, args.layers, args.ffn)
     ref_tflops_per_gpu = fpt * B * S / (ms_per_step * 1e-3) / 1e12               # the reference graph: every padded row credited
-    peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else 157.3
+    peak = PEAK_BF16_TFLOPS if args.precision in ('bf16', 'bf16x3') else 157.3         # bf16x3 runs on the bf16 matrix cores (3 MFMAs per algorithmic product)
     T = B * S
     Te, Td, _, Ts = eng.last_rows
     live_flops = train_flops_live_rows(Te, Td, eng.last_pairs, args.hs, args.layers, args.ffn, Ts=Ts)

@@ -443,6 +443,16 @@ int pb_flash_bwd_x3(const float* q, const float* k, const float* v, const float*
                     int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb,
                     int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, void* stream);
 
+/* the same on packed rows (the layout of pb_flash_fwd_packed / pb_flash_bwd_packed: per-sequence q_off / q_len / k_off / k_len and the visible-key count k_vis
+ * instead of a key mask; Sq_max / Sk_max = the longest sequence) */
+int pb_flash_fwd_x3_packed(const float* q, const float* k, const float* v, float* o, float* lse, const int32_t* q_off, const int32_t* q_len, const int32_t* k_off,
+                           const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss,
+                           int64_t k_ss, int64_t v_ss, int64_t o_ss, float scale, int32_t causal, void* stream);
+int pb_flash_bwd_x3_packed(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, float* dq, float* dk, float* dv,
+                           float* delta, const int32_t* q_off, const int32_t* q_len, const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis,
+                           int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss,
+                           int64_t dq_ss, int64_t dk_ss, int64_t dv_ss, float scale, int32_t causal, void* stream);
+
 /* ---- K15: deferred parameter-gradient reductions -----------------------------------------------------------------------
  * The bias / LayerNorm-parameter gradients of one backward pass (the `db = grad.sum(0)` of every nn.Linear and nn.LayerNorm autograd
  * node under BartModel, modeling_bart.py:280-390) leave their kernels as per-workgroup partial rows. Between pb_defer_begin and

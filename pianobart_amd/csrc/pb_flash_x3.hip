@@ -167,10 +167,21 @@ struct FxArgs {
     float *out, *dq, *dk, *dv;
     float* lse; const float* delta; const float* key_mask;
     const int* kmax;                                          // per batch row: 1 + last visible key (keys at and behind it are masked for every query), or NULL
+    const int *vq_off, *vq_len, *vk_off, *vk_len, *vk_vis;    // packed rows (all NULL, or all set): batch row b owns query rows vq_off[b] .. + vq_len[b] - 1 and key rows
+                                                              // vk_off[b] .. + vk_len[b] - 1 of ONE (rows, H HD) tensor, its first vk_vis[b] keys visible; Sq / Sk are the maxima
     int B, H, Sq, Sk;
     long q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
     float scale; int causal;
 };
+// the view of batch row b: dense (batch strides, the call's Sq / Sk, key mask) or packed (row offsets, this row's own lengths, visible prefix)
+struct XView { long qrow, krow; int Sq, Sk, kvis; bool packed; };
+__device__ __forceinline__ XView xview(const FxArgs& p, int b) {
+    XView v;
+    v.packed = p.vq_off != nullptr;
+    if (v.packed) { v.qrow = p.vq_off[b]; v.krow = p.vk_off[b]; v.Sq = p.vq_len[b]; v.Sk = p.vk_len[b]; v.kvis = min(p.vk_vis[b], v.Sk); }
+    else { v.qrow = 0; v.krow = 0; v.Sq = p.Sq; v.Sk = p.Sk; v.kvis = p.kmax ? min(p.kmax[b], p.Sk) : p.Sk; }
+    return v;
+}
 __device__ __forceinline__ float xgrp_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float xgrp_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
@@ -184,28 +195,29 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fwd_kernel(const FxArgs p) {
     float* ldsB = reinterpret_cast<float*>(smem + 4 * TB);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * XQ, h = blockIdx.y, b = blockIdx.z;
-    const float* Q = p.q + b * p.q_sb + h * HD;
-    const float* K = p.k + b * p.k_sb + h * HD;
-    const float* V = p.v + b * p.v_sb + h * HD;
+    const XView w = xview(p, b);
+    if (q0 >= w.Sq) return;                                    // packed rows: a shorter sequence than the longest one
+    const float* Q = p.q + b * p.q_sb + w.qrow * p.q_ss + h * HD;
+    const float* K = p.k + b * p.k_sb + w.krow * p.k_ss + h * HD;
+    const float* V = p.v + b * p.v_sb + w.krow * p.v_ss + h * HD;
     const int myq = q0 + wave * 16 + lr;
     constexpr int KS = HD / 32, DT = HD / 16;
     bf16x8 qh[KS], ql[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xfrag_global(Q, p.q_ss, myq, p.Sq, ks * 32 + g * 8, qh[ks], ql[ks]);
+    for (int ks = 0; ks < KS; ++ks) xfrag_global(Q, p.q_ss, myq, w.Sq, ks * 32 + g * 8, qh[ks], ql[ks]);
     f32x4 oacc[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
     const float c = p.scale * XLOG2E;
-    int kend = p.causal ? min(p.Sk, q0 + XQ) : p.Sk;
-    if (p.kmax) kend = min(kend, p.kmax[b]);                  // key tiles behind the last visible key contribute exact zeros: skipped
+    const int kend = min(p.causal ? min(w.Sk, q0 + XQ) : w.Sk, w.kvis);     // key tiles behind the last visible key contribute exact zeros: skipped
     for (int k0 = 0; k0 < kend; k0 += XK) {
         __syncthreads();
-        xstage_rows<HD>(Kh, Kl, K + (long)k0 * p.k_ss, p.k_ss, p.Sk - k0, t);
-        xstage_transposed<HD>(Vh, Vl, V + (long)k0 * p.v_ss, p.v_ss, p.Sk - k0, t);
+        xstage_rows<HD>(Kh, Kl, K + (long)k0 * p.k_ss, p.k_ss, w.Sk - k0, t);
+        xstage_transposed<HD>(Vh, Vl, V + (long)k0 * p.v_ss, p.v_ss, w.Sk - k0, t);
         if (t < XK) {
             const int key = k0 + t;
-            const bool vis = key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
+            const bool vis = key < w.kvis && (w.packed || !p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
             ldsB[t] = vis ? 0.f : -INFINITY;
         }
         __syncthreads();
@@ -252,9 +264,9 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fwd_kernel(const FxArgs p) {
             oacc[dt] = XM3(xfrag_perm(Vh, dt * 16 + lr, 1, g), xfrag_perm(Vl, dt * 16 + lr, 1, g), p1h, p1l, oacc[dt]);
         }
     }
-    if (myq < p.Sq) {
+    if (myq < w.Sq) {
         const float inv = l > 0.f ? 1.0f / l : 0.f;
-        float* O = p.out + b * p.o_sb + (long)myq * p.o_ss + h * HD;
+        float* O = p.out + b * p.o_sb + (w.qrow + myq) * p.o_ss + h * HD;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(O + dt * 16 + g * 4) = oacc[dt] * inv;
         if (g == 0) p.lse[((long)b * p.H + h) * p.Sq + myq] = l > 0.f ? (m + log2f(l)) / XLOG2E : INFINITY;
@@ -263,12 +275,15 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fwd_kernel(const FxArgs p) {
 
 // ================================================================== delta = rowsum(dO * O), f32
 template <int HD>
-__global__ void fx_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout, float* __restrict__ delta, int B, int H, int Sq, long o_sb, long o_ss) {
+__global__ void fx_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout, float* __restrict__ delta, int B, int H, int Sq, long o_sb, long o_ss,
+                                const int* __restrict__ q_off, const int* __restrict__ q_len) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * H * Sq) return;
     const int q = (int)(idx % Sq), h = (int)((idx / Sq) % H), b = (int)(idx / ((long)Sq * H));
-    const float* op = o + b * o_sb + (long)q * o_ss + h * HD;
-    const float* dp = dout + b * o_sb + (long)q * o_ss + h * HD;
+    if (q_off && q >= q_len[b]) { delta[idx] = 0.f; return; }
+    const long row = q_off ? (long)q_off[b] + q : q;
+    const float* op = o + b * o_sb + row * o_ss + h * HD;
+    const float* dp = dout + b * o_sb + row * o_ss + h * HD;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
@@ -290,25 +305,29 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dkv_kernel(const FxArgs p) 
     float* ldsL = reinterpret_cast<float*>(smem + 8 * TB);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
     const int k0 = blockIdx.x * XK, h = blockIdx.y, b = blockIdx.z;
-    const float* Q = p.q + b * p.q_sb + h * HD;
-    const float* K = p.k + b * p.k_sb + h * HD;
-    const float* V = p.v + b * p.v_sb + h * HD;
-    const float* DO = p.dout + b * p.o_sb + h * HD;
+    const XView w = xview(p, b);
+    if (k0 >= w.Sk) return;                                    // packed rows: a shorter sequence than the longest one
+    const float* Q = p.q + b * p.q_sb + w.qrow * p.q_ss + h * HD;
+    const float* K = p.k + b * p.k_sb + w.krow * p.k_ss + h * HD;
+    const float* V = p.v + b * p.v_sb + w.krow * p.v_ss + h * HD;
+    const float* DO = p.dout + b * p.o_sb + w.qrow * p.o_ss + h * HD;
+    float* DKb = p.dk + b * p.dk_sb + w.krow * p.dk_ss + h * HD;
+    float* DVb = p.dv + b * p.dv_sb + w.krow * p.dv_ss + h * HD;
     constexpr int KS = HD / 32, DT = HD / 16;
     const int mykey = k0 + wave * 16 + lr;
     bf16x8 kh[KS], kl[KS], vh[KS], vl[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        xfrag_global(K, p.k_ss, mykey, p.Sk, ks * 32 + g * 8, kh[ks], kl[ks]);
-        xfrag_global(V, p.v_ss, mykey, p.Sk, ks * 32 + g * 8, vh[ks], vl[ks]);
+        xfrag_global(K, p.k_ss, mykey, w.Sk, ks * 32 + g * 8, kh[ks], kl[ks]);
+        xfrag_global(V, p.v_ss, mykey, w.Sk, ks * 32 + g * 8, vh[ks], vl[ks]);
     }
-    const bool kvis = mykey < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + mykey] != 0.f);
-    if (p.kmax && k0 >= p.kmax[b]) {                          // no visible key in this block: its keys receive zero gradient
+    const bool kvis = mykey < w.kvis && (w.packed || !p.key_mask || p.key_mask[(long)b * p.Sk + mykey] != 0.f);
+    if (k0 >= w.kvis) {                                        // no visible key in this block: its keys receive zero gradient
         for (int i = t; i < XK * (HD / 4); i += FX_THREADS) {
             const int key = k0 + i / (HD / 4), c4 = (i % (HD / 4)) * 4;
-            if (key < p.Sk) {
-                *reinterpret_cast<f32x4*>(p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HD + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HD + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (key < w.Sk) {
+                *reinterpret_cast<f32x4*>(DKb + (long)key * p.dk_ss + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(DVb + (long)key * p.dv_ss + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         return;
@@ -318,21 +337,21 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dkv_kernel(const FxArgs p) 
     for (int i = 0; i < DT; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float c = p.scale * XLOG2E;
     const int qstart = p.causal ? (k0 / XQ) * XQ : 0;
-    for (int q0 = qstart; q0 < p.Sq; q0 += XQ) {
+    for (int q0 = qstart; q0 < w.Sq; q0 += XQ) {
         __syncthreads();
         constexpr int NB = 16 * (HD / 8);                        // 4 x 8 blocks per tile: head_dim <= 64 stages Q and dO side by side
         if (2 * NB <= FX_THREADS) {
-            if (t < NB) xstage_both<HD>(Qh, Ql, QTh, QTl, Q + (long)q0 * p.q_ss, p.q_ss, p.Sq - q0, t);
-            else if (t < 2 * NB) xstage_both<HD>(Oh, Ol, OTh, OTl, DO + (long)q0 * p.o_ss, p.o_ss, p.Sq - q0, t - NB);
+            if (t < NB) xstage_both<HD>(Qh, Ql, QTh, QTl, Q + (long)q0 * p.q_ss, p.q_ss, w.Sq - q0, t);
+            else if (t < 2 * NB) xstage_both<HD>(Oh, Ol, OTh, OTl, DO + (long)q0 * p.o_ss, p.o_ss, w.Sq - q0, t - NB);
         } else {
-            xstage_both<HD>(Qh, Ql, QTh, QTl, Q + (long)q0 * p.q_ss, p.q_ss, p.Sq - q0, t);
-            xstage_both<HD>(Oh, Ol, OTh, OTl, DO + (long)q0 * p.o_ss, p.o_ss, p.Sq - q0, t);
+            xstage_both<HD>(Qh, Ql, QTh, QTl, Q + (long)q0 * p.q_ss, p.q_ss, w.Sq - q0, t);
+            xstage_both<HD>(Oh, Ol, OTh, OTl, DO + (long)q0 * p.o_ss, p.o_ss, w.Sq - q0, t);
         }
         if (t < XQ) {
             const int q = q0 + t;
             const long li = ((long)b * p.H + h) * p.Sq + q;
-            ldsL[t] = q < p.Sq ? p.lse[li] * XLOG2E : INFINITY;
-            ldsL[64 + t] = q < p.Sq ? p.delta[li] : 0.f;
+            ldsL[t] = q < w.Sq ? p.lse[li] * XLOG2E : INFINITY;
+            ldsL[64 + t] = q < w.Sq ? p.delta[li] : 0.f;
         }
         __syncthreads();
         f32x4 s[4], dp[4];
@@ -372,9 +391,9 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dkv_kernel(const FxArgs p) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int key = k0 + wave * 16 + g * 4 + r;
-        if (key < p.Sk) {
-            float* DK = p.dk + b * p.dk_sb + (long)key * p.dk_ss + h * HD;
-            float* DV = p.dv + b * p.dv_sb + (long)key * p.dv_ss + h * HD;
+        if (key < w.Sk) {
+            float* DK = DKb + (long)key * p.dk_ss;
+            float* DV = DVb + (long)key * p.dv_ss;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) { DK[dt * 16 + lr] = dk[dt][r]; DV[dt * 16 + lr] = dv[dt][r]; }
         }
@@ -392,34 +411,35 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq_kernel(const FxArgs p) {
     float* ldsB = reinterpret_cast<float*>(smem + 6 * TB);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * XQ, h = blockIdx.y, b = blockIdx.z;
-    const float* Q = p.q + b * p.q_sb + h * HD;
-    const float* K = p.k + b * p.k_sb + h * HD;
-    const float* V = p.v + b * p.v_sb + h * HD;
-    const float* DO = p.dout + b * p.o_sb + h * HD;
+    const XView w = xview(p, b);
+    if (q0 >= w.Sq) return;                                    // packed rows: a shorter sequence than the longest one
+    const float* Q = p.q + b * p.q_sb + w.qrow * p.q_ss + h * HD;
+    const float* K = p.k + b * p.k_sb + w.krow * p.k_ss + h * HD;
+    const float* V = p.v + b * p.v_sb + w.krow * p.v_ss + h * HD;
+    const float* DO = p.dout + b * p.o_sb + w.qrow * p.o_ss + h * HD;
     constexpr int KS = HD / 32, DT = HD / 16;
     const int myq = q0 + wave * 16 + lr;
     bf16x8 qh[KS], ql[KS], oh[KS], ol[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        xfrag_global(Q, p.q_ss, myq, p.Sq, ks * 32 + g * 8, qh[ks], ql[ks]);
-        xfrag_global(DO, p.o_ss, myq, p.Sq, ks * 32 + g * 8, oh[ks], ol[ks]);
+        xfrag_global(Q, p.q_ss, myq, w.Sq, ks * 32 + g * 8, qh[ks], ql[ks]);
+        xfrag_global(DO, p.o_ss, myq, w.Sq, ks * 32 + g * 8, oh[ks], ol[ks]);
     }
     const long li = ((long)b * p.H + h) * p.Sq + myq;
-    const float lse = myq < p.Sq ? p.lse[li] * XLOG2E : INFINITY;
-    const float dl = myq < p.Sq ? p.delta[li] : 0.f;
+    const float lse = myq < w.Sq ? p.lse[li] * XLOG2E : INFINITY;
+    const float dl = myq < w.Sq ? p.delta[li] : 0.f;
     f32x4 dq[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c = p.scale * XLOG2E;
-    int kend = p.causal ? min(p.Sk, q0 + XQ) : p.Sk;
-    if (p.kmax) kend = min(kend, p.kmax[b]);                  // key tiles behind the last visible key contribute exact zeros: skipped
+    const int kend = min(p.causal ? min(w.Sk, q0 + XQ) : w.Sk, w.kvis);     // key tiles behind the last visible key contribute exact zeros: skipped
     for (int k0 = 0; k0 < kend; k0 += XK) {
         __syncthreads();
-        xstage_both<HD>(Kh, Kl, KTh, KTl, K + (long)k0 * p.k_ss, p.k_ss, p.Sk - k0, t);
-        xstage_rows<HD>(Vh, Vl, V + (long)k0 * p.v_ss, p.v_ss, p.Sk - k0, t);
+        xstage_both<HD>(Kh, Kl, KTh, KTl, K + (long)k0 * p.k_ss, p.k_ss, w.Sk - k0, t);
+        xstage_rows<HD>(Vh, Vl, V + (long)k0 * p.v_ss, p.v_ss, w.Sk - k0, t);
         if (t < XK) {
             const int key = k0 + t;
-            ldsB[t] = (key < p.Sk && (!p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f)) ? 1.f : 0.f;
+            ldsB[t] = (key < w.kvis && (w.packed || !p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f)) ? 1.f : 0.f;
         }
         __syncthreads();
         f32x4 s[4], dp[4];
@@ -451,8 +471,8 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq_kernel(const FxArgs p) {
             dq[dt] = XM3(xfrag_perm(KTh, dt * 16 + lr, 1, g), xfrag_perm(KTl, dt * 16 + lr, 1, g), d1h, d1l, dq[dt]);
         }
     }
-    if (myq < p.Sq) {
-        float* DQ = p.dq + b * p.dq_sb + (long)myq * p.dq_ss + h * HD;
+    if (myq < w.Sq) {
+        float* DQ = p.dq + b * p.dq_sb + (w.qrow + myq) * p.dq_ss + h * HD;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(DQ + dt * 16 + g * 4) = dq[dt];
     }
@@ -480,15 +500,16 @@ template <class F> int opt_in_lds(F fn, size_t bytes) {
 
 extern "C" int pb_flash_x3_supported(int32_t hd) { return (hd == 32 || hd == 64 || hd == 128) ? 1 : 0; }
 
-extern "C" int pb_flash_fwd_x3(const float* q, const float* k, const float* v, float* o, float* lse, const float* key_mask, const int32_t* kmax, int32_t B, int32_t H, int32_t Sq,
-                               int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb,
-                               int64_t o_ss, float scale, int32_t causal, void* stream_) {
+static int fx_fwd_impl(const float* q, const float* k, const float* v, float* o, float* lse, const float* key_mask, const int32_t* kmax, int32_t B, int32_t H, int32_t Sq,
+                       int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb,
+                       int64_t o_ss, float scale, int32_t causal, void* stream_, const int* const* vl) {
     const long st[8] = {q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss};
     if (xcheck("pb_flash_fwd_x3", hd, st, 8)) return -2;
     PB_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "pb_flash_fwd_x3: operands must be 16-byte aligned");
     if (B <= 0 || H <= 0 || Sq <= 0) return 0;
     FxArgs a = {};
     a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.key_mask = key_mask; a.kmax = key_mask ? kmax : nullptr;
+    if (vl) { a.vq_off = vl[0]; a.vq_len = vl[1]; a.vk_off = vl[2]; a.vk_len = vl[3]; a.vk_vis = vl[4]; }
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal & 1;
     dim3 grid((Sq + XQ - 1) / XQ, H, B);
@@ -498,10 +519,10 @@ extern "C" int pb_flash_fwd_x3(const float* q, const float* k, const float* v, f
     return 0;
 }
 
-extern "C" int pb_flash_bwd_x3(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, const float* key_mask,
-                               const int32_t* kmax, float* dq, float* dk, float* dv, float* delta, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb,
-                               int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb,
-                               int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, void* stream_) {
+static int fx_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, const float* key_mask,
+                       const int32_t* kmax, float* dq, float* dk, float* dv, float* delta, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb,
+                       int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb,
+                       int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, void* stream_, const int* const* vl) {
     hipStream_t stream = (hipStream_t)stream_;
     const long st[14] = {q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss};
     if (xcheck("pb_flash_bwd_x3", hd, st, 14)) return -2;
@@ -510,11 +531,12 @@ extern "C" int pb_flash_bwd_x3(const float* q, const float* k, const float* v, c
     if (B <= 0 || H <= 0 || Sq <= 0) return 0;
     FxArgs a = {};
     a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.key_mask = key_mask; a.kmax = key_mask ? kmax : nullptr;
+    if (vl) { a.vq_off = vl[0]; a.vq_len = vl[1]; a.vk_off = vl[2]; a.vk_len = vl[3]; a.vk_vis = vl[4]; }
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
     a.scale = scale; a.causal = causal & 1;
     const long nrow = (long)B * H * Sq;
-    FX_DISPATCH(hd, hipLaunchKernelGGL((fx_delta_kernel<HD>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, o, dout, delta, B, H, Sq, (long)o_sb, (long)o_ss));
+    FX_DISPATCH(hd, hipLaunchKernelGGL((fx_delta_kernel<HD>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, o, dout, delta, B, H, Sq, (long)o_sb, (long)o_ss, vl ? vl[0] : nullptr, vl ? vl[1] : nullptr));
     PB_LAUNCH_CHECK();
     dim3 gk((Sk + XK - 1) / XK, H, B), gq((Sq + XQ - 1) / XQ, H, B);
     const size_t lds_kv = 8 * 64 * (size_t)hd * 2 + 512, lds_q = 6 * 64 * (size_t)hd * 2 + 256;
@@ -523,4 +545,35 @@ extern "C" int pb_flash_bwd_x3(const float* q, const float* k, const float* v, c
     FX_DISPATCH(hd, if (opt_in_lds(&fx_bwd_dq_kernel<HD>, lds_q)) return -1; hipLaunchKernelGGL((fx_bwd_dq_kernel<HD>), gq, dim3(FX_THREADS), lds_q, stream, a));
     PB_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int pb_flash_fwd_x3(const float* q, const float* k, const float* v, float* o, float* lse, const float* key_mask, const int32_t* kmax, int32_t B, int32_t H, int32_t Sq,
+                               int32_t Sk, int32_t hd, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb,
+                               int64_t o_ss, float scale, int32_t causal, void* stream_) {
+    return fx_fwd_impl(q, k, v, o, lse, key_mask, kmax, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, scale, causal, stream_, nullptr);
+}
+extern "C" int pb_flash_bwd_x3(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, const float* key_mask,
+                               const int32_t* kmax, float* dq, float* dk, float* dv, float* delta, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t hd, int64_t q_sb,
+                               int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, int64_t o_sb, int64_t o_ss, int64_t dq_sb,
+                               int64_t dq_ss, int64_t dk_sb, int64_t dk_ss, int64_t dv_sb, int64_t dv_ss, float scale, int32_t causal, void* stream_) {
+    return fx_bwd_impl(q, k, v, o, dout, lse, key_mask, kmax, dq, dk, dv, delta, B, H, Sq, Sk, hd, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, dq_sb, dq_ss, dk_sb, dk_ss,
+                       dv_sb, dv_ss, scale, causal, stream_, nullptr);
+}
+// packed rows (see pb_flash_fwd_packed): the rows of the batch's sequences lie back to back in (rows, H hd) tensors; q_off / q_len / k_off / k_len / k_vis are
+// device int32 (B) arrays, Sq_max / Sk_max the longest sequence (grid, lse / delta row length)
+extern "C" int pb_flash_fwd_x3_packed(const float* q, const float* k, const float* v, float* o, float* lse, const int32_t* q_off, const int32_t* q_len, const int32_t* k_off,
+                                      const int32_t* k_len, const int32_t* k_vis, int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss,
+                                      int64_t k_ss, int64_t v_ss, int64_t o_ss, float scale, int32_t causal, void* stream_) {
+    PB_REQUIRE(q_off && q_len && k_off && k_len && k_vis, "pb_flash_fwd_x3_packed: the five row descriptors are required");
+    const int* vl[5] = {q_off, q_len, k_off, k_len, k_vis};
+    return fx_fwd_impl(q, k, v, o, lse, nullptr, nullptr, B, H, Sq_max, Sk_max, hd, 0, q_ss, 0, k_ss, 0, v_ss, 0, o_ss, scale, causal, stream_, vl);
+}
+extern "C" int pb_flash_bwd_x3_packed(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, float* dq, float* dk, float* dv,
+                                      float* delta, const int32_t* q_off, const int32_t* q_len, const int32_t* k_off, const int32_t* k_len, const int32_t* k_vis,
+                                      int32_t B, int32_t H, int32_t Sq_max, int32_t Sk_max, int32_t hd, int64_t q_ss, int64_t k_ss, int64_t v_ss, int64_t o_ss,
+                                      int64_t dq_ss, int64_t dk_ss, int64_t dv_ss, float scale, int32_t causal, void* stream_) {
+    PB_REQUIRE(q_off && q_len && k_off && k_len && k_vis, "pb_flash_bwd_x3_packed: the five row descriptors are required");
+    const int* vl[5] = {q_off, q_len, k_off, k_len, k_vis};
+    return fx_bwd_impl(q, k, v, o, dout, lse, nullptr, nullptr, dq, dk, dv, delta, B, H, Sq_max, Sk_max, hd, 0, q_ss, 0, k_ss, 0, v_ss, 0, o_ss, 0, dq_ss, 0, dk_ss, 0, dv_ss,
+                       scale, causal, stream_, vl);
 }

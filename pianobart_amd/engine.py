@@ -416,6 +416,9 @@ class Engine:
         """q,k,v,out: (tensor, elem offset, row stride). Unfused form: QK^T -> masked softmax -> PV. rows: packed-row descriptors."""
         H, hd = self.H, self.hd
         ws = self._cur_ws
+        if rows is not None and self.x3:
+            ops.flash_fwd_x3_packed(q, k, v, out, save['lse'], rows, B, H, hd, hd ** -0.5, causal)
+            return
         if rows is not None:
             ops.flash_fwd_packed(q, k, v, out, save['lse'], rows, B, H, hd, hd ** -0.5, causal)
             return
@@ -450,6 +453,10 @@ class Engine:
         delta_rows: rowsum(dO * O) per head, [H][rows], already made by the GEMM that produced dout (PB_GEMM_ROWDOT); one-pass kernel only."""
         H, hd = self.H, self.hd
         ws = self._cur_ws
+        if self.use_flash and self.x3 and rows is not None:
+            assert dout[1] == 0 and dout[2] == out[2]
+            ops.flash_bwd_x3_packed(q, k, v, out, dout[0], save['lse'], dq, dk, dv, ws['delta'], rows, B, H, hd, hd ** -0.5, causal)
+            return False
         if self.use_flash and self.x3:
             ex = lambda a, n: (a[0], a[1], a[2], n * a[2])
             assert dout[1] == 0 and dout[2] == out[2]
@@ -609,7 +616,7 @@ class Engine:
                 Tq, ids_q, r_x = sub.T, sub.src, sub.cross
                 Lq = {k: L[k][:Tq] for k in ('qc', 'ctxc', 'ac', 'yc', 'mc', 'rc', 'u', 'g', 'a2', 'y2', 'm2', 'r2')}
                 y1 = Lq['y1s'] = self._y1s(ws, L['y1'])[:Tq]
-                ops.gather_rows16(L['y1'], sub.idx, y1, Tq, 2 * d)
+                ops.gather_rows16(L['y1'], sub.idx, y1, Tq, d * y1.element_size())
                 Lq['attnc'] = L['attnc']
                 sub_layer = Lq
             self._linear(y1, pf + 'wq_c', pf + 'bq_c', Lq['qc'], Tq, d, d)

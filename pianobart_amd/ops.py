@@ -263,6 +263,23 @@ def flash_bwd_x3(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, B, H, Sq, S
              pp(dvt, dvo), _p(delta), B, H, Sq, Sk, hd, qb, qs, kb, ks, vb, vs, ob, os_, dqb, dqs, dkb, dks, dvb, dvs, scale, int(causal), _stream())
 
 
+def flash_fwd_x3_packed(q, k, v, o, lse, rows, B, H, hd, scale, causal):
+    """q,k,v,o: (tensor, element offset, row stride) f32 over packed rows (bf16x3 instantiation)."""
+    (qt, qo, qs), (kt, ko, ks), (vt, vo, vs), (ot, oo, os_) = q, k, v, o
+    pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
+    LIB.call('pb_flash_fwd_x3_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(lse), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off),
+             _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd, qs, ks, vs, os_, scale, int(causal), _stream())
+
+
+def flash_bwd_x3_packed(q, k, v, o, dout, lse, dq, dk, dv, delta, rows, B, H, hd, scale, causal):
+    (qt, qo, qs), (kt, ko, ks), (vt, vo, vs), (ot, oo, os_) = q, k, v, o
+    (dqt, dqo, dqs), (dkt, dko, dks), (dvt, dvo, dvs) = dq, dk, dv
+    pp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
+    LIB.call('pb_flash_bwd_x3_packed', pp(qt, qo), pp(kt, ko), pp(vt, vo), pp(ot, oo), _p(dout), _p(lse), pp(dqt, dqo), pp(dkt, dko), pp(dvt, dvo),
+             _p(delta), _p(rows.q_off), _p(rows.q_len), _p(rows.k_off), _p(rows.k_len), _p(rows.k_vis), B, H, rows.Sq_max, rows.Sk_max, hd,
+             qs, ks, vs, os_, dqs, dks, dvs, scale, int(causal), _stream())
+
+
 class PackedRows:
     """Row descriptors of one packed attention call (include/pianobart_hip.h, pb_flash_*_packed): device int32 (B) tensors plus
     the two maxima."""

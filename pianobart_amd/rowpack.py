@@ -16,6 +16,7 @@ PACK_TILE = 256                 # packed row counts are rounded up to whole GEMM
 PACK_MIN_GAIN = 0.97            # stay dense unless at least 3 % of the rows go
 SUB_LAST = int(os.environ.get('PB_SUB_LAST', '1'))     # last decoder layer: query side and LM heads on the loss rows only
 SUB_MIN_GAIN = 0.75             # ... unless more than 3/4 of the decoder rows carry a loss term
+X3_PACK = int(os.environ.get('PB_X3_PACK', '1'))            # dead-row compaction also for the bf16x3 instantiation (0: its step stays padded, for A/B)
 ORDER_PAIRS = int(os.environ.get('PB_ORDER_PAIRS', '1'))   # attention grids take the (batch, head) pairs longest first (0: batch order, for A/B)
 
 
@@ -57,6 +58,16 @@ def dispatch_order(cost, H):
 _TICKET = [0]
 
 
+def _packable(eng):
+    """The instantiations whose attention kernels take packed rows: bf16 (pipelined family, head_dim 64 / 96 / 128) and, since round 6, bf16x3 (fused
+    split-bf16 kernels, head_dim 32 / 64 / 128)."""
+    if not eng.use_flash:
+        return False
+    if getattr(eng, 'x3', False):
+        return X3_PACK and eng.hd in (32, 64, 128)
+    return eng.code == PB_BF16 and eng.hd in (64, 96, 128)
+
+
 def _issue_ticket(loss_mask, emask, dmask):
     """A prefetch request and the batch it was made for are matched by a ticket, not by addresses: the kernels write the masks through raw
     pointers (no version bump) and the caching allocator hands the next batch the same addresses. The ticket queues up on the
@@ -88,7 +99,7 @@ def prefetch_counts(eng, loss_mask, emask, dmask, stream=None):
     stream has been given so far. The tensors must not be modified between this call and the step; request and batch are matched by a
     ticket that travels on the tensor objects (a batch without the right ticket just takes the synchronous path)."""
     B, S = emask.shape[:2]
-    if not (eng.use_flash and eng.hd in (64, 96, 128) and eng.code == PB_BF16 and (B * S) % PACK_TILE == 0 and eng.mlm is not None):
+    if not (_packable(eng) and (B * S) % PACK_TILE == 0 and eng.mlm is not None):
         return
     pf = eng._pack_pf_state
     if pf is None or pf['shape'] != (B, S):
@@ -118,7 +129,7 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
     synchronisation: the packed row counts size every later launch."""
     B, S = enc16.shape[:2]
     T = B * S
-    if not (eng.use_flash and eng.hd in (64, 96, 128) and eng.code == PB_BF16 and T % PACK_TILE == 0 and emask is not None
+    if not (_packable(eng) and T % PACK_TILE == 0 and emask is not None
             and dmask is not None and eng.mlm is not None):
         return None
     st = eng._pack_state

@@ -587,3 +587,70 @@ def test_one_pass_backward_hands_sequences_beyond_6144_rows_to_the_kernel_pair(o
         ops.flash_bwd1((q, 0, 3 * d, S * 3 * d), (q, d, 3 * d, S * 3 * d), (q, 2 * d, 3 * d, S * 3 * d), (o, 0, d, S * d), o, lse, None,
                        (q, 0, 3 * d, S * 3 * d), (q, d, 3 * d, S * 3 * d), (q, 2 * d, 3 * d, S * 3 * d), torch.zeros(B, 1, S, device='cuda'),
                        B, 1, S, S, 64, 0.125, False)
+
+
+@pytest.mark.parametrize('heads,d,tail_loss,hole,dropout,sparse', [(4, 256, False, False, 0.0, False), (4, 256, True, True, 0.1, True), (2, 256, True, False, 0.1, True),
+                                                                   (4, 128, True, False, 0.1, True)])
+def test_packed_step_of_the_split_bf16_instantiation(ops, monkeypatch, heads, d, tail_loss, hole, dropout, sparse):
+    """Dead-row compaction under precision='bf16x3' (round 6: packed rows through pb_flash_*_x3_packed, head_dim 32 / 64 / 128): the packed step gives the
+    padded step's loss sums and every gradient slot to 1e-4 (f32 storage: what differs is the summation order of the GEMM tiles and of the f32 atomics of
+    the embedding gradients), dropout included, with loss rows outside the visible prefix and a hole in the encoder mask; and, dropout off, the CPU oracle's
+    loss (1e-5) and every parameter gradient (2e-3 of the tensor's largest element) on the PADDED batch -- pretrain.py:112-118, 159-196."""
+    from oracle import pianobart_oracle as O
+    from pianobart_amd.model import BartConfig, PianoBart, PianoBartLM
+    from tests.golden_util import load_vocab, randomize_params, synth_octuple_batch
+    e2w, w2e = load_vocab()
+    B, S = 6, 256
+    kw = dict(max_position_embeddings=S, d_model=d, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+              encoder_attention_heads=heads, decoder_attention_heads=heads, dropout=dropout)
+    m = PianoBartLM(PianoBart(BartConfig(**kw), e2w, w2e, precision='bf16x3'))
+    randomize_params(m, 11)
+    o = O.PianoBartLM(O.PianoBart(O.BartConfig(**kw), e2w, w2e)).train()
+    o.load_state_dict(m.state_dict(), strict=True)
+    m = m.train().cuda()
+    eng = m._get_engine()
+    eng.bind(torch.device('cuda', 0))
+    enc, dec, loss_mask, emask, dmask, target = synth_octuple_batch(B, S, seed=9)
+    rng = np.random.default_rng(3)
+    Le, Ld = rng.integers(40, S + 1, size=B), rng.integers(40, S + 1, size=B)
+    Le[0], Ld[1] = S, S
+    emask, dmask, loss_mask = emask.clone().float(), dmask.clone().float(), loss_mask.clone().float()
+    for b in range(B):
+        emask[b, :Le[b]] = 1; emask[b, Le[b]:] = 0
+        if hole:
+            emask[b, 3] = 0
+        dmask[b, :Ld[b]] = 1; dmask[b, Ld[b]:] = 0
+        loss_mask[b] = 0
+        loss_mask[b, :Ld[b]] = torch.from_numpy((rng.random((Ld[b], 8)) < (0.15 if sparse else 1.1)).astype(np.float32))
+        loss_mask[b, 1, :] = 1
+        if tail_loss and Ld[b] + 5 < S:
+            loss_mask[b, Ld[b] + 2, :] = 1
+            loss_mask[b, S - 1, 2] = 1
+    dev = lambda t: t.cuda()
+    args = (ops.ids_to_i16(dev(enc)), ops.ids_to_i16(dev(dec)), ops.ids_to_i16(dev(target)), dev(loss_mask).contiguous(), dev(emask), dev(dmask))
+    s0, g0, r0 = _step(eng, args, False, monkeypatch)
+    s1, g1, r1 = _step(eng, args, True, monkeypatch)
+    assert r0 == (B * S,) * 4 and r1[0] < B * S and r1[1] < B * S, (r0, r1)          # it really packed
+    assert (r1[3] < r1[1]) if sparse else r1[3] == r1[1], r1
+    assert torch.equal(s0[8:16], s1[8:16]) and torch.allclose(s0[:8], s1[:8], rtol=2e-5), (s0 - s1).abs().max()
+    worst = ('', 0.0)
+    for name, sl in eng.slots.items():
+        a, b_ = g0[sl.off:sl.off + sl.numel], g1[sl.off:sl.off + sl.numel]
+        worst = max(worst, (name, float((a - b_).norm()) / (float(a.norm()) + 1e-12)), key=lambda t: t[1])
+    print('bf16x3 packed vs padded: worst gradient slot', worst, 'rows', r1)
+    assert torch.isfinite(g1).all() and worst[1] < 1e-4, worst
+    if dropout == 0.0:
+        total_o, *_ = O.pretrain_loss(o(enc, dec, emask, dmask), target, loss_mask, e2w)
+        total_o.backward()
+        s = s1.double().cpu()
+        w = torch.tensor([262, 134, 262, 134, 38, 135, 55, 260], dtype=torch.double)
+        loss = float(((s[0:8] / s[8:16]) * w).sum() / w.sum())
+        assert abs(loss - float(total_o)) / float(total_o) < 1e-5, (loss, float(total_o))
+        views = {id(p): g for p, g in zip(eng.params, eng.grad_views_of(g1))}
+        scale = max(float(p.grad.abs().max()) for p in o.parameters() if p.grad is not None)
+        for k, p in m.named_parameters():
+            go = dict(o.named_parameters())[k].grad
+            if go is None or id(p) not in views:
+                continue
+            err = float((views[id(p)].double().cpu() - go.double()).abs().max())
+            assert err < 2e-3 * max(float(go.abs().max()), 1e-3 * scale), (k, err, float(go.abs().max()))
