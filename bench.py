@@ -509,7 +509,7 @@ def other_instantiations(args, cfgkw, dev):
                         "step_tflops_algorithmic": fl / (ms * 1e-3) / 1e12, "frac_of_bf16_mfma_peak_algorithmic": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                         "note": "precision='bf16x3': f32 storage and row kernels, every GEMM as split-bf16 triples (a_hi b_hi + a_hi b_lo + a_lo b_hi, f32 "
                                 "accumulate) on the bf16 MFMA -- 3x the matrix work per algorithmic FLOP; logits within 1e-3 of the CPU reference "
-                                "(tests/test_model_gpu.py: G1, G4, G10: measured 2e-5); same model shape, padded rows, fused split-bf16 attention, 3 steps"}
+                                "(tests/test_model_gpu.py: G1, G4, G10: measured 2e-5); same model shape, dead rows dropped like the bf16 step, fused split-bf16 attention, 3 steps"}
         if "ms_per_step" in out.get("fp32_parity_step", {}):
             out["bf16x3_parity_step"]["speedup_over_fp32_parity_step"] = out["fp32_parity_step"]["ms_per_step"] / out["bf16x3_parity_step"]["ms_per_step"]
         ms32, _, _ = side_model_step(cfgkw, 'fp32', 16, args.seq, dev, 2)            # the exact-f32 step at the larger batch, for the same ratio there
