@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int16_t* __restric
 // np.random.choice) -> the 8 ids of the next decoder input, written to tok_dev for the next step's embedding kernel, and -- with the
 // raw logits row -- to pinned host logs indexed by position. The arithmetic follows pb_nucleus_rows above step for step (probs /= (sum +
 // 1e-5), descending order with ties by index, candidates up to the first cumsum > p, q = cand / sum(cand), f64 cdf / cdf[-1] > u) with
-// wave-parallel prefix sums in place of numpy's left-to-right ones (33 -> ~10 us per token); it cannot reproduce the host path bit
+// wave-parallel prefix sums in place of numpy's left-to-right ones (33.6 -> 19.3 us per token under the profiler); it cannot reproduce the host path bit
 // for bit anyway (torch's vectorised CPU exp and its summation order are 1 ulp apart), so the HOST remains the authority: it replays every position
 // from the logged logits row with the reference code path and rolls the decoder back on the (rare) position where the device chose
 // differently (Engine.generate). The device result is a PREDICTION that lets the next token start without a host round trip.
@@ -862,11 +862,6 @@ __device__ __forceinline__ float wave_scan_f(float v, int lane) {
     for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
     return v;
 }
-__device__ __forceinline__ double wave_scan_d(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const double u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
-    return v;
-}
 __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
     __shared__ __attribute__((aligned(16))) float pn[8][SMP_W];     // normalised probabilities, class order
     __shared__ float sp[8][SMP_W + 64];   // ... in descending order (heads with p < 1), zero tail
@@ -876,6 +871,7 @@ __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
     const int pos = *a.pos;
     const int n = a.n[h], off = a.off[h];
     const float T = a.temp[h];
+    const double u_draw = a.u[(size_t)pos * 8 + h];            // requested now: a load that depends on *pos would otherwise sit at the end of the chain
     // softmax(logit / T) of head h (torch.softmax(logit / t, dim=-1), model.py:103-104), then probs /= (sum(probs) + 1e-5) (model.py:85).
     // The sums here are wave reductions, not numpy's left-to-right ones: a common divisor that differs in its last bit moves every
     // probability alike, so the order and (but for a 1e-7 neighbourhood of a threshold) the choice stay -- the host checks every position.
@@ -895,14 +891,13 @@ __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) { e[k] = (lane + 64 * k < n) ? expf(y[k] - mx) : 0.f; s += e[k]; }
     s = wave_sum(s);
-    float cs5 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { e[k] = e[k] / s; cs5 += e[k]; }
-    const float c1 = wave_sum(cs5) + 1e-5f;
+    // probs = e / s, then probs /= (sum(probs) + 1e-5) with sum(probs) = 1 to rounding: one division by s (1 + 1e-5). A common factor a few ulps off
+    // numpy's moves every probability alike (same order, same candidates but for a 1e-6 neighbourhood of the threshold): the host checks.
+    const float inv = 1.0f / (s * 1.00001f);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int c = lane + 64 * k;
-        if (c < SMP_W) pn[h][c] = c < n ? e[k] / c1 : -1.f;     // -1 behind the head's classes: never ranked in front of a class
+        if (c < SMP_W) pn[h][c] = c < n ? e[k] * inv : -1.f;     // -1 behind the head's classes: never ranked in front of a class
     }
     __syncthreads();
     // descending order of the heads with p < 1 by rank counting, one thread per (head, class): ties by class index
@@ -916,9 +911,9 @@ __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
         }
         if (hh >= 0) {
             const float v = pn[hh][c];
-            const int nn4 = (a.n[hh] + 3) >> 2;
             int rank = 0;
-            for (int j4 = 0; j4 < nn4; ++j4) {
+#pragma unroll 17                                              // fixed trip count (the tail holds -1: never in front of a class), four independent LDS reads in flight
+            for (int j4 = 0; j4 < SMP_W / 4; ++j4) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(&pn[hh][4 * j4]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rank += (w[r] > v || (w[r] == v && 4 * j4 + r < c)) ? 1 : 0;
@@ -942,19 +937,16 @@ __global__ __launch_bounds__(512) void dec_sample_kernel(const SampleArgs a) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
         const int kc = first == 0x7fffffff ? 1 : first + 1;
-        float qpart = 0.f;
+        // q = cand / sum(cand), cdf = cumsum(q) / cdf[-1] > u  <=>  prefix_i > u * prefix_{kc - 1}: the prefix sums of the threshold test serve again
+        // (numpy renormalises in f32 and accumulates the cdf in f64: a relative 1e-7 against a uniform u)
+        float myqs = 0.f;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) if (5 * lane + k < kc) qpart += v5[k];
-        const float qs = wave_sum(qpart);                        // sum of the candidates
-        double dpre[5], drun = 0.0;
+        for (int k = 0; k < 5; ++k) if (5 * lane + k == kc - 1) myqs = base + pre[k];
+        const float qs = wave_sum(myqs);                         // exactly one lane holds a non-zero term
+        const float thr = (float)(u_draw * (double)qs);
+        int best = kc - 1;                                       // first candidate whose running sum exceeds u times the candidates' total
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { if (5 * lane + k < kc) drun += (double)(v5[k] / qs); dpre[k] = drun; }
-        const double dbase = wave_scan_d(drun, lane) - drun;
-        const double last = __shfl(dbase + drun, 63, 64);       // cdf[-1]
-        const double u = a.u[(size_t)pos * 8 + h];
-        int best = kc - 1;                                       // first index with cdf / cdf[-1] > u
-#pragma unroll
-        for (int k = 4; k >= 0; --k) if (5 * lane + k < kc && (dbase + dpre[k]) / last > u) best = 5 * lane + k;
+        for (int k = 4; k >= 0; --k) if (5 * lane + k < kc && base + pre[k] > thr) best = 5 * lane + k;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
         if (lane == 0) htok[h] = si[h][best];
