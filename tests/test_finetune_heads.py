@@ -175,7 +175,8 @@ def _write_finetune_sets(root, prefix, seq, gen=False):
 
 
 @pytest.mark.gpu
-def test_finetune_driver_writes_one_log_line_per_epoch(tmp_path):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_finetune_driver_writes_one_log_line_per_epoch(tmp_path, precision):
     """finetune() (main.py:103-215) end to end on a tiny synthetic composer set: the log holds the header line and ONE line per
     epoch (real newlines), checkpoints carry the reference's keys."""
     if not torch.cuda.is_available():
@@ -191,7 +192,7 @@ def test_finetune_driver_writes_one_log_line_per_epoch(tmp_path):
     try:
         finetune(['--task', 'composer', '--dataset', 'Pianist8', '--dataroot', root, '--dict_file', str(tmp_path / 'dict.pkl'), '--name', 't',
                   '--num_workers', '0', '--batch_size', '2', '--max_seq_len', str(S), '--hs', str(D), '--layers', '1', '--ffn_dims', '128',
-                  '--heads', '4', '--epochs', '2', '--nopretrain', '--cuda_devices', '0', '--precision', 'fp32'])
+                  '--heads', '4', '--epochs', '2', '--nopretrain', '--cuda_devices', '0', '--precision', precision])
         log = open('result/finetune/composer_t/log').read()
         ck = torch.load('result/finetune/composer_t/model.ckpt', weights_only=False)
     finally:
@@ -203,7 +204,8 @@ def test_finetune_driver_writes_one_log_line_per_epoch(tmp_path):
 
 
 @pytest.mark.gpu
-def test_generation_driver_end_to_end(tmp_path, capsys):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_generation_driver_end_to_end(tmp_path, capsys, precision):
     """finetune_generation() (main.py:214-321): args, data files, per-epoch train/valid/test, log + checkpoint; the FAD metrics that
     need the absent `shapesimilarity` package are reported as n/a / None, never as numbers."""
     if not torch.cuda.is_available():
@@ -220,7 +222,7 @@ def test_generation_driver_end_to_end(tmp_path, capsys):
     try:
         tr = finetune_generation(['--datasets', 'maestro', '--dataroot', root, '--dict_file', os.path.abspath(vocab), '--name', 'g', '--num_workers', '0',
                                   '--batch_size', '2', '--max_seq_len', str(S), '--hs', str(D), '--layers', '1', '--ffn_dims', '128', '--heads', '4',
-                                  '--epochs', '2', '--nopretrain', '--lr', '1e-3', '--cuda_devices', '0', '--precision', 'fp32'])
+                                  '--epochs', '2', '--nopretrain', '--lr', '1e-3', '--cuda_devices', '0', '--precision', precision])
         out = capsys.readouterr().out
         log = open('result/finetune/generation_g/log').read().split('\n')
         ck = torch.load('result/finetune/generation_g/model.ckpt', weights_only=False)
