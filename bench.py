@@ -333,7 +333,13 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
         pad = int(pb.bar_pad_word)
         em_r, dm_r = (enc_r[:, :, 0] != pad).float(), (dec_r[:, :, 0] != pad).float()
 
+        pf = not os.environ.get('PB_NO_PACK_PREFETCH')
+        if pf:
+            eng.prefetch_pack(lm_r, em_r, dm_r)                      # as in the headline loop (and the Pretrainer): the next batch's row counts are requested a step ahead
+
         def real_step():
+            if pf:
+                eng.prefetch_pack(lm_r, em_r, dm_r)
             eng.loss_and_grads(enc_r, dec_r, tgt16, lm_r, em_r, dm_r, train=True, ids_checked=True)
             eng.optimizer_step(lr=2e-5, gscale=1.0)
         real_step(); torch.cuda.synchronize()
@@ -386,11 +392,17 @@ def extra_measurements(args, model, eng, ops, step, peak, dev):
                 dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
             red = GradReducer(eng, 1)
             try:
+                pfd = not os.environ.get('PB_NO_PACK_PREFETCH')
+                if pfd:
+                    eng.prefetch_pack(*step.batch[3:6])
+
                 def dp_step():
+                    if pfd:
+                        eng.prefetch_pack(*step.batch[3:6])          # the headline loop's pipeline hint: without it every step drains the stream for its row counts
                     eng.loss_and_grads(*step.batch, train=True, count_hook=red.reduce_counts, ids_checked=True)
                     red.all_reduce_grads()
                     eng.optimizer_step(lr=2e-5, gscale=1.0)
-                dp_step(); torch.cuda.synchronize()
+                dp_step(); dp_step(); torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(10):
                     dp_step()
@@ -467,7 +479,10 @@ def side_model_step(cfgkw, precision, B, S, dev, nsteps, seed=1234):
     enc, dec, loss_mask, emask, dmask, target = [x.to(dev) for x in synth_octuple_batch(B, S, seed)]
     b = (ops.ids_to_i16(enc), ops.ids_to_i16(dec), ops.ids_to_i16(target), loss_mask.contiguous(), emask, dmask)
 
+    eng.prefetch_pack(b[3], b[4], b[5])                           # the headline loop's pipeline hint (a no-op for instantiations that do not pack)
+
     def one():
+        eng.prefetch_pack(b[3], b[4], b[5])
         eng.loss_and_grads(*b, train=True, ids_checked=True)
         eng.optimizer_step(lr=2e-5, gscale=1.0)
     one(); one(); torch.cuda.synchronize()
