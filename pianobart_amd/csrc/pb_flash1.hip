@@ -138,7 +138,8 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     block_map(nkb0, pin.a.H, pin.a.B, rb, h, b, pin.a.bh_order);
     const int k0 = rb * KB1;
     Fa64Args p = pin.a;
-    varlen_localize(p, b);
+    const long qrow0 = pin.a.vl_q_off ? (long)pin.a.vl_q_off[b] : (long)b * pin.a.Sq;     // first row of this sequence on the q side: read ONCE, beside varlen_localize's own
+    varlen_localize(p, b);                                                                  // scalar loads (a second, vector load of it further down cost a memory round trip each)
     const int lse_ld = pin.a.Sq, d_model = p.H * HDT;
     const int kvis_end = p.kmax ? min(p.Sk, p.kmax[b]) : p.Sk;
     const int nt = (p.Sq + 63) / 64;
@@ -164,14 +165,16 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     asm volatile("" ::: PB_ALL_AGPRS);                                     // the kernel descriptor allocates all 256 accumulator registers
 #ifdef PB_FA1_STAMPS
     const unsigned st_t0 = (unsigned)__builtin_amdgcn_s_memtime();
-    unsigned st_p[6] = {};
+    unsigned st_p[6] = {}, st_q[4] = {};
 #define PSTAMP(i) st_p[i] = (unsigned)__builtin_amdgcn_s_memtime();
+#define QSTAMP(i) st_q[i] = (unsigned)__builtin_amdgcn_s_memtime();
 #else
 #define PSTAMP(i)
+#define QSTAMP(i)
 #endif
     const bf16_t* Q = p.q + b * p.q_sb + h * HDT;
     const bf16_t* DO = p.dout + b * p.o_sb + h * HDT;
-    bf16_t* slab = pin.slab + (long)rb * pin.slab_stride + (pin.a.vl_q_off ? (long)pin.a.vl_q_off[b] * d_model : (long)b * pin.slab_sb) + h * HDT;
+    bf16_t* slab = pin.slab + (long)rb * pin.slab_stride + (pin.a.vl_q_off ? qrow0 * d_model : (long)b * pin.slab_sb) + h * HDT;
     const float c = p.scale * LOG2E;
     // ---- prologue. Everything is requested before anything is waited for (one memory round trip, not one per loop iteration): the
     // ordinary loads first -- K / V fragments of this wave's 64 keys, the -lse / -delta rows of the sequence -- then the DMA of the 4 K
@@ -186,11 +189,12 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
             vfr[kt][ks] = frag_global(V, p.v_ss, key, p.Sk, ks * 32 + g * 8);
         }
     }
+    QSTAMP(0);
     float* ldsNL = reinterpret_cast<float*>(smem + OFF_TAB);
     float* ldsND = ldsNL + nt * 64;
     float* ldsVis = reinterpret_cast<float*>(smem + OFF_DS);               // 1 / 0 per key of the block (the dS buffers are not in use yet)
     const long li0 = ((long)b * p.H + h) * lse_ld;
-    const float* dsrc = pin.delta_rows ? pin.delta_rows + (long)h * pin.delta_ld + (pin.a.vl_q_off ? (long)pin.a.vl_q_off[b] : (long)b * pin.a.Sq) : p.delta + li0;
+    const float* dsrc = pin.delta_rows ? pin.delta_rows + (long)h * pin.delta_ld + qrow0 : p.delta + li0;
     float tl[4], td[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
         tl[i] = q < p.Sq ? p.lse[li0 + q] : INFINITY;
         td[i] = q < p.Sq ? dsrc[q] : 0.f;
     }
+    QSTAMP(1);
     const int key_t = k0 + t;                                              // FT = KB1 = 256: one key per thread
     const float vis_t = (key_t < kvis_end && (!p.key_mask || p.key_mask[(long)b * p.Sk + key_t] != 0.f)) ? 1.f : 0.f;
     // {K, Q, dO} tiles by buffer_load ... lds: a descriptor per operand that ends with this sequence's last row (rows beyond it read as
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lds_t)(st + 8192), 16, voO0, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (lds_t)(st + 8192 + 1024), 16, voO1, so, 0, 0);
     };
+    QSTAMP(2);
     const int npre = min(3, nt - it0);                                     // tiles requested up front (the ring is empty)
     stage(it0, 0);
     if (npre > 1) stage(it0 + 1, 1);
@@ -683,6 +689,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
         atomicAdd(pin.stamps + 18, (st_p[0] - st_t0) >> 4); atomicAdd(pin.stamps + 19, (st_p[1] - st_p[0]) >> 4); atomicAdd(pin.stamps + 20, (st_p[2] - st_p[1]) >> 4);
         atomicAdd(pin.stamps + 21, (st_p[3] - st_p[2]) >> 4); atomicAdd(pin.stamps + 22, (st_p[4] - st_p[3]) >> 4); atomicAdd(pin.stamps + 23, (st_p[5] - st_p[4]) >> 4);
         atomicAdd(pin.stamps + 24, (st_t1 - st_p[5]) >> 4);
+        atomicAdd(pin.stamps + 28, (st_q[0] - st_t0) >> 4); atomicAdd(pin.stamps + 29, (st_q[1] - st_q[0]) >> 4); atomicAdd(pin.stamps + 30, (st_q[2] - st_q[1]) >> 4); atomicAdd(pin.stamps + 31, (st_p[0] - st_q[2]) >> 4);
         atomicAdd(pin.stamps + 25, (st_e0 - st_t2) >> 4); atomicAdd(pin.stamps + 26, (st_e1 - st_e0) >> 4); atomicAdd(pin.stamps + 27, (st_t3 - st_e1) >> 4);
     }
 #endif
