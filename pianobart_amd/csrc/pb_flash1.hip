@@ -133,6 +133,9 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#ifdef PB_FA1_STAMPS
+    const unsigned long long st_in = __builtin_amdgcn_s_memtime();          // workgroup trace: entry / exit times and the CU it ran on (tools/flash1_stamps.py --gaps)
+#endif
     const int nkb0 = (pin.a.Sk + KB1 - 1) / KB1;
     int rb, h, b;
     block_map(nkb0, pin.a.H, pin.a.B, rb, h, b, pin.a.bh_order);
@@ -682,6 +685,18 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
 #ifdef PB_FA1_STAMPS
     if (pin.stamps && lane == 0) {
         const unsigned st_t3 = (unsigned)__builtin_amdgcn_s_memtime();
+        const unsigned ntrace = pin.stamps[32];                            // word 32 != 0: TRACE mode -- one record per workgroup behind word 64, no sums (28 atomics per wave on 32 words slow the kernel 4x)
+        if (ntrace) {
+            if (wave == 0 && blockIdx.x < ntrace) {
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                const unsigned long long st_out = __builtin_amdgcn_s_memtime();
+                unsigned long long* rec = reinterpret_cast<unsigned long long*>(pin.stamps + 64) + 4 * (size_t)blockIdx.x;
+                rec[0] = ((unsigned long long)(xcc & 15) << 32) | hw; rec[1] = st_in; rec[2] = st_out;
+                rec[3] = ((unsigned long long)(st_t1 - st_t0) << 32) | (unsigned)(st_t3 - st_t2);          // prologue | epilogue (cycles)
+            }
+        } else {
         for (int i = 0; i < 10; ++i) atomicAdd(pin.stamps + i, st_acc[i] >> 4);
         atomicAdd(pin.stamps + 16, st_steps);
         atomicAdd(pin.stamps + 10, (st_t1 - st_t0) >> 4); atomicAdd(pin.stamps + 11, (st_t2 - st_t1) >> 4); atomicAdd(pin.stamps + 12, (st_t3 - st_t2) >> 4);
@@ -691,6 +706,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
         atomicAdd(pin.stamps + 24, (st_t1 - st_p[5]) >> 4);
         atomicAdd(pin.stamps + 28, (st_q[0] - st_t0) >> 4); atomicAdd(pin.stamps + 29, (st_q[1] - st_q[0]) >> 4); atomicAdd(pin.stamps + 30, (st_q[2] - st_q[1]) >> 4); atomicAdd(pin.stamps + 31, (st_p[0] - st_q[2]) >> 4);
         atomicAdd(pin.stamps + 25, (st_e0 - st_t2) >> 4); atomicAdd(pin.stamps + 26, (st_e1 - st_e0) >> 4); atomicAdd(pin.stamps + 27, (st_t3 - st_e1) >> 4);
+        }
     }
 #endif
 }
