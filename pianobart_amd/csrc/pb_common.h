@@ -88,6 +88,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// (row block, head, batch row) of a workgroup of a (row blocks, H, B) grid -- the mapping of pb_fa_tiles.h's block_map for the kernels launched on 3-D grids:
+// the heads of an XCD (linear workgroup id & 7) keep their row blocks together (their K / V stay in ITS L2), and the row block is rotated by the head's position so
+// that no XCD and no shader engine collects the long row blocks of causal calls (x fastest put query blocks {x, x + 8} of EVERY head on XCD x: 10 : 24 units of causal work).
+__device__ __forceinline__ void grid_map3(int& rb, int& h, int& b) {
+    const int nrb = gridDim.x, H = gridDim.y, BH = gridDim.y * gridDim.z;
+    const int L = blockIdx.x + nrb * (blockIdx.y + H * blockIdx.z);
+    int bh;
+    if ((BH & 7) == 0) { const int x = L & 7, slot = L >> 3, j = slot / nrb; bh = j * 8 + x; rb = (slot - j * nrb + j) % nrb; }
+    else { bh = L / nrb; rb = (L - bh * nrb + bh) % nrb; }
+    h = bh % H; b = bh / H;
+}
+
 // ---- exact-erf GELU (activation_function="gelu") -----------------------------------
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

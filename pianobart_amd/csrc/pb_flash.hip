@@ -128,7 +128,9 @@ __global__ __launch_bounds__(FA_THREADS) void fa_fwd_kernel(const FaArgs p) {
     char* ldsV = smem + 64 * HD * 2;           // transposed   [HD][64]
     float* ldsB = reinterpret_cast<float*>(smem + 2 * 64 * HD * 2);   // key bias [64]: 0 or -inf
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * TQ, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    grid_map3(rb_, h, b);
+    const int q0 = rb_ * TQ;
     const bf16_t* Q = p.q + b * p.q_sb + h * HD;
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;
@@ -237,7 +239,9 @@ __global__ __launch_bounds__(FA_THREADS) void fa_bwd_dkv_kernel(const FaArgs p) 
     char* ldsOT = smem + 3 * TB;        // dO transposed
     float* ldsL = reinterpret_cast<float*>(smem + 4 * TB);        // lse[64] (log2 units), delta[64]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * TK, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    grid_map3(rb_, h, b);
+    const int k0 = rb_ * TK;
     const bf16_t* Q = p.q + b * p.q_sb + h * HD;
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;
@@ -327,7 +331,9 @@ __global__ __launch_bounds__(FA_THREADS) void fa_bwd_dq_kernel(const FaArgs p) {
     char* ldsV = smem + 2 * TB;         // rows image
     float* ldsB = reinterpret_cast<float*>(smem + 3 * TB);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * TQ, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    grid_map3(rb_, h, b);
+    const int q0 = rb_ * TQ;
     const bf16_t* Q = p.q + b * p.q_sb + h * HD;
     const bf16_t* K = p.k + b * p.k_sb + h * HD;
     const bf16_t* V = p.v + b * p.v_sb + h * HD;

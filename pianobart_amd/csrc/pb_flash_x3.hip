@@ -194,7 +194,9 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fwd_kernel(const FxArgs p) {
     char* Vh = smem + 2 * TB; char* Vl = smem + 3 * TB;     // transposed [HD][64 keys]
     float* ldsB = reinterpret_cast<float*>(smem + 4 * TB);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * XQ, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    grid_map3(rb_, h, b);
+    const int q0 = rb_ * XQ;
     const XView w = xview(p, b);
     if (q0 >= w.Sq) return;                                    // packed rows: a shorter sequence than the longest one
     const float* Q = p.q + b * p.q_sb + w.qrow * p.q_ss + h * HD;
@@ -304,7 +306,9 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dkv_kernel(const FxArgs p) 
     char* OTh = smem + 6 * TB;  char* OTl = smem + 7 * TB;       // dO transposed
     float* ldsL = reinterpret_cast<float*>(smem + 8 * TB);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * XK, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    grid_map3(rb_, h, b);
+    const int k0 = rb_ * XK;
     const XView w = xview(p, b);
     if (k0 >= w.Sk) return;                                    // packed rows: a shorter sequence than the longest one
     const float* Q = p.q + b * p.q_sb + w.qrow * p.q_ss + h * HD;
@@ -410,7 +414,9 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq_kernel(const FxArgs p) {
     char* Vh = smem + 4 * TB;  char* Vl = smem + 5 * TB;
     float* ldsB = reinterpret_cast<float*>(smem + 6 * TB);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * XQ, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    grid_map3(rb_, h, b);
+    const int q0 = rb_ * XQ;
     const XView w = xview(p, b);
     if (q0 >= w.Sq) return;                                    // packed rows: a shorter sequence than the longest one
     const float* Q = p.q + b * p.q_sb + w.qrow * p.q_ss + h * HD;
