@@ -18,6 +18,7 @@ SUB_LAST = int(os.environ.get('PB_SUB_LAST', '1'))     # last decoder layer: que
 SUB_MIN_GAIN = 0.75             # ... unless more than 3/4 of the decoder rows carry a loss term
 X3_PACK = int(os.environ.get('PB_X3_PACK', '1'))            # dead-row compaction also for the bf16x3 instantiation (0: its step stays padded, for A/B)
 ORDER_PAIRS = int(os.environ.get('PB_ORDER_PAIRS', '1'))   # attention grids take the (batch, head) pairs longest first (0: batch order, for A/B)
+ORDER_CAUSAL = int(os.environ.get('PB_ORDER_CAUSAL', '1'))  # ... the decoder's causal self-attention too (0: batch order there, the choice before round 6's rotated row blocks)
 
 
 def plan_packed_rows(live, S, tile=PACK_TILE):
@@ -220,7 +221,9 @@ def pack_batch(eng, enc16, dec16, tgt16, loss_mask, emask, dmask):
         order.copy_(order_h, non_blocking=True)
     o = (lambda i: order[i]) if ORDER_PAIRS else (lambda i: None)
     pk.enc = ops.PackedRows(desc[0], desc[1], desc[0], desc[1], desc[2], me, me, 'enc', order=o(0))
-    pk.dec = ops.PackedRows(desc[3], desc[4], desc[3], desc[4], desc[5], md, md, 'dec')      # causal: batch order (longest first measured 4 - 10 % SLOWER there)
+    # causal: until round 6 batch order (longest first measured 4 - 10 % SLOWER: with the row blocks of a head in order one shader engine of an XCD collected the long ones,
+    # pb_fa_tiles.h block_map); with the rotated row blocks longest first wins here too (forward 94.5 -> 88 us, backward pair 252 -> 239: profiles/r06_attention_dispatch_trace.txt)
+    pk.dec = ops.PackedRows(desc[3], desc[4], desc[3], desc[4], desc[5], md, md, 'dec', order=o(1) if ORDER_CAUSAL else None)
     pk.cross = ops.PackedRows(desc[3], desc[4], desc[0], desc[1], desc[2], md, me, 'cross', order=o(2))
     pk.sub = None
     if sub:

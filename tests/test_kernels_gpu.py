@@ -532,10 +532,12 @@ def test_one_pass_attention_backward(ops, causal, S, layout):
     assert float((delta.double() - dsum).abs().max()) < 1e-4 * max(1.0, float(dsum.abs().max()))
 
 
-def test_dispatch_order_changes_no_result(ops):
+@pytest.mark.parametrize('causal', [False, True])
+def test_dispatch_order_changes_no_result(ops, causal):
     """bh_order (the order in which a packed attention grid takes the (batch, head) pairs, rowpack.dispatch_order: longest first, dealt in
     snake order over the XCDs) only re-orders the work: forward, kernel-pair backward and one-pass backward give bit-identical outputs
-    with and without it. Ragged packed batch, head_dim 64."""
+    with and without it. Ragged packed batch, head_dim 64; non-causal (encoder / cross form) and causal (the decoder's form: ordered too since
+    round 6, rowpack.ORDER_CAUSAL)."""
     from pianobart_amd._lib import LIB
     from pianobart_amd.rowpack import dispatch_order
     hd, B, H, S = 64, 8, 4, 600
@@ -554,17 +556,17 @@ def test_dispatch_order_changes_no_result(ops):
     q, k, v = (qkv, 0, 3 * d), (qkv, d, 3 * d), (qkv, 2 * d, 3 * d)
     res = []
     for o in (None, order):
-        rows = ops.PackedRows(i32(off), i32(qlen), i32(off), i32(qlen), i32(kvis), int(qlen.max()), int(qlen.max()), 'enc', order=o)
+        rows = ops.PackedRows(i32(off), i32(qlen), i32(off), i32(qlen), i32(kvis), int(qlen.max()), int(qlen.max()), 'dec' if causal else 'enc', order=o)
         out = torch.full((T, d), float('nan'), device='cuda', dtype=torch.bfloat16)
         lse = torch.zeros(B, H, rows.Sq_max, device='cuda')
-        ops.flash_fwd_packed(q, k, v, (out, 0, d), lse, rows, B, H, hd, hd ** -0.5, False)
+        ops.flash_fwd_packed(q, k, v, (out, 0, d), lse, rows, B, H, hd, hd ** -0.5, causal)
         grads = []
         for one in (False, True):
             dqkv = torch.full((T, 3 * d), float('nan'), device='cuda', dtype=torch.bfloat16)
             delta = torch.zeros(B, H, rows.Sq_max, device='cuda')
             db = [torch.zeros(d, device='cuda') for _ in range(3)]
             ws = torch.empty(int(LIB.query('pb_flash_bias_ws_floats', B, H, rows.Sq_max, rows.Sk_max, hd)), device='cuda')
-            args = (q, k, v, (out, 0, d), dout, lse, (dqkv, 0, 3 * d), (dqkv, d, 3 * d), (dqkv, 2 * d, 3 * d), delta, rows, B, H, hd, hd ** -0.5, False)
+            args = (q, k, v, (out, 0, d), dout, lse, (dqkv, 0, 3 * d), (dqkv, d, 3 * d), (dqkv, 2 * d, 3 * d), delta, rows, B, H, hd, hd ** -0.5, causal)
             if one:
                 ops.flash_bwd1_packed(*args, T, dbias=db, dbias_ws=ws)
             else:
