@@ -1,5 +1,8 @@
-"""Per-phase cycle anatomy of the one-pass backward's 32-query step (diagnostic build of the library:
-PB_EXTRA_HIPCC_FLAGS=-DPB_FA1_STAMPS python pianobart_amd/build.py --force, into a separate PB_LIB_PATH). Means over every wave and step."""
+"""Anatomy of the one-pass attention backward from the diagnostic build of the library
+(PB_LIB_OUT=ab/stamps.so PB_EXTRA_HIPCC_FLAGS=-DPB_FA1_STAMPS python pianobart_amd/build.py; -DPB_FA1_STAMPS=2 adds the per-phase stamps of the 32-query step):
+  PB_LIB_PATH=ab/stamps.so python tools/flash1_stamps.py dense|causal|enc|dec|cross            per-phase / prologue / epilogue cycle means over every wave (the sums are atomics: the kernel runs ~4x slower)
+  PB_LIB_PATH=ab/stamps.so python tools/flash1_stamps.py dense|causal|enc|dec|cross --gaps     WORKGROUP TRACE: CU (HW_ID / XCC_ID), entry and exit time of every workgroup of the last launch --
+                                                                                                idle time per CU between two workgroups, workgroup -> shader engine table (profiles/r06_attention_dispatch_trace.txt)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
