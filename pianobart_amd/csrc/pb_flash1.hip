@@ -134,7 +134,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
     const int t = threadIdx.x, lane = t & 63, lr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 #ifdef PB_FA1_STAMPS
-    const unsigned long long st_in = __builtin_amdgcn_s_memtime();          // workgroup trace: entry / exit times and the CU it ran on (tools/flash1_stamps.py --gaps)
+    const unsigned long long st_in = __builtin_amdgcn_s_memrealtime();      // workgroup trace: entry / exit times (the 100 MHz counter all XCDs share; s_memtime is per XCD at best) and the CU it ran on (tools/flash1_stamps.py --gaps)
 #endif
     const int nkb0 = (pin.a.Sk + KB1 - 1) / KB1;
     int rb, h, b;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(FT) void fa1_bwd_kernel(const Fa1Args pin) {
                 unsigned hw, xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                const unsigned long long st_out = __builtin_amdgcn_s_memtime();
+                const unsigned long long st_out = __builtin_amdgcn_s_memrealtime();
                 unsigned long long* rec = reinterpret_cast<unsigned long long*>(pin.stamps + 64) + 4 * (size_t)blockIdx.x;
                 rec[0] = ((unsigned long long)(xcc & 15) << 32) | hw; rec[1] = st_in; rec[2] = st_out;
                 rec[3] = ((unsigned long long)(st_t1 - st_t0) << 32) | (unsigned)(st_t3 - st_t2);          // prologue | epilogue (cycles)

@@ -24,7 +24,7 @@ if GAPS:
     rec = st[64:].cpu().numpy().view(np.uint64).reshape(NREC, 4)
     rec = rec[rec[:, 1] != 0]                                    # the last launch's records (every launch overwrites them)
     cu = (rec[:, 0] >> np.uint64(32)) * np.uint64(1 << 16) + ((rec[:, 0] >> np.uint64(8)) & np.uint64(0xf)) + ((rec[:, 0] >> np.uint64(12)) & np.uint64(1)) * np.uint64(16) + ((rec[:, 0] >> np.uint64(13)) & np.uint64(7)) * np.uint64(32)
-    t_in, t_out = rec[:, 1].astype(np.int64), rec[:, 2].astype(np.int64)
+    t_in, t_out = rec[:, 1].astype(np.int64) * 24, rec[:, 2].astype(np.int64) * 24          # s_memrealtime: 10 ns ticks -> cycles at 2.4 GHz
     pro, epi = (rec[:, 3] >> np.uint64(32)).astype(np.int64), (rec[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
     t0 = t_in.min()
     span = t_out.max() - t0
@@ -34,10 +34,18 @@ if GAPS:
         o = np.argsort(t_in[m]); a, b = t_in[m][o], t_out[m][o]
         gaps += list(a[1:] - b[:-1]); busy.append((b - a).sum()); first.append(a[0] - t0); last.append(t_out.max() - b[-1])
     gaps = np.array(gaps)
-    print('%d workgroups on %d CUs; kernel span %d ticks of s_memtime' % (len(rec), len(np.unique(cu)), span))
+    xc = (rec[:, 0] >> np.uint64(32)).astype(np.int64)
+    util, tails = [], []
+    for x_ in np.unique(xc):                                      # the counters of different XCDs are not synchronised: spans per XCD
+        m = xc == x_
+        sp = t_out[m].max() - t_in[m].min()
+        ncu = len(np.unique(cu[m]))
+        util.append((t_out[m] - t_in[m]).sum() / (ncu * sp))
+        tails.append(np.mean([t_out[m].max() - t_out[m][cu[m] == c].max() for c in np.unique(cu[m])]) / sp)
+    print('%d workgroups on %d CUs; per XCD: CUs hold a workgroup %.1f %% of the kernel span (min %.1f, max %.1f), a CU idles %.1f %% of it behind its last workgroup' % (
+        len(rec), len(np.unique(cu)), 100 * np.mean(util), 100 * min(util), 100 * max(util), 100 * np.mean(tails)))
     print('per workgroup: lifetime mean %.0f | prologue %.0f | epilogue %.0f' % ((t_out - t_in).mean(), pro.mean(), epi.mean()))
-    print('per CU: busy %.1f %% of the span | first entry %.0f after the earliest | idle behind its last exit %.0f | gap exit -> next entry: mean %.0f, median %.0f, p90 %.0f (x %.2f per CU)' % (
-        100 * np.mean(busy) / span, np.mean(first), np.mean(last), gaps.mean(), np.median(gaps), np.percentile(gaps, 90), len(gaps) / len(np.unique(cu))))
+    print('per CU: gap exit -> next entry: mean %.0f, median %.0f, p90 %.0f (x %.2f per CU)' % (gaps.mean(), np.median(gaps), np.percentile(gaps, 90), len(gaps) / len(np.unique(cu))))
     idx = np.nonzero(st[64:].cpu().numpy().view(np.uint64).reshape(NREC, 4)[:, 1] != 0)[0]          # blockIdx of each record
     se = ((rec[:, 0] >> np.uint64(13)) & np.uint64(7)).astype(np.int64); xcc = (rec[:, 0] >> np.uint64(32)).astype(np.int64)
     slot = idx >> 3
