@@ -182,6 +182,17 @@ __device__ __forceinline__ XView xview(const FxArgs& p, int b) {
     else { v.qrow = 0; v.krow = 0; v.Sq = p.Sq; v.Sk = p.Sk; v.kvis = p.kmax ? min(p.kmax[b], p.Sk) : p.Sk; }
     return v;
 }
+// dS = p (dP - delta) scale with the operation order pinned (subtract, multiply, multiply): left to itself the compiler forms different multiply-adds in the one- and the
+// two-tile kernels (seen at head_dim 32: dQ differed in the last bits), and the two forms of a kernel must round alike
+__device__ __forceinline__ float xds(float pr, float dp, float dl, float scale) {
+    float t = dp - dl;
+    asm volatile("" : "+v"(t));
+    t = pr * t;
+    asm volatile("" : "+v"(t));
+    t = t * scale;
+    asm volatile("" : "+v"(t));                 // ... and the product is ROUNDED before it is cut: fused into the cut's subtraction (x - hi) it changes which way lo rounds
+    return t;
+}
 __device__ __forceinline__ float xgrp_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float xgrp_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fwd_kernel(const FxArgs p) {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = s[kt][r] * c + bias[r];
+                float x = __builtin_fmaf(s[kt][r], c, bias[r]);            // explicit: the one- and two-tile kernels must round alike whatever the compiler would contract
                 if (p.causal && (k0 + kt * 16 + g * 4 + r) > myq) x = -INFINITY;
                 s[kt][r] = x;
                 mx = fmaxf(mx, x);
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fwd_kernel(const FxArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - muse); s[kt][r] = e; rs += e; }
         rs = xgrp_sum(rs);
-        l = l * alpha + rs;
+        l = __builtin_fmaf(l, alpha, rs);
         m = mnew;
 #pragma unroll
         for (int i = 0; i < DT; ++i) oacc[i] *= alpha;
@@ -376,9 +387,9 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dkv_kernel(const FxArgs p) 
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + qt * 16 + g * 4 + r;
                 const bool vis = kvis && (!p.causal || mykey <= q);
-                const float pr = vis ? __builtin_amdgcn_exp2f(s[qt][r] * c - lse[r]) : 0.f;
+                const float pr = vis ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][r], c, -lse[r])) : 0.f;
                 s[qt][r] = pr;
-                dp[qt][r] = pr * (dp[qt][r] - dl[r]) * p.scale;
+                dp[qt][r] = xds(pr, dp[qt][r], dl[r], p.scale);
             }
         }
         bf16x8 p0h, p0l, p1h, p1l, d0h, d0l, d1h, d1l;
@@ -465,8 +476,8 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq_kernel(const FxArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + kt * 16 + g * 4 + r;
                 const bool vis = vis4[r] != 0.f && (!p.causal || key <= myq);
-                const float pr = vis ? __builtin_amdgcn_exp2f(s[kt][r] * c - lse) : 0.f;
-                dp[kt][r] = pr * (dp[kt][r] - dl) * p.scale;
+                const float pr = vis ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, -lse)) : 0.f;
+                dp[kt][r] = xds(pr, dp[kt][r], dl, p.scale);
             }
         }
         bf16x8 d0h, d0l, d1h, d1l;
@@ -484,6 +495,220 @@ __global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq_kernel(const FxArgs p) {
     }
 }
 
+// ================================================================== forward and dQ with NT = 2 tiles of 16 queries per wave (round 6, late)
+// With one tile per wave the staged K / V fragments are read from LDS once per 16 queries, and the LDS port, not the matrix pipe, sets the pace (32 KiB of fragment
+// reads per wave and key tile against 48 MFMAs); two tiles per wave -- blocks of 128 queries -- use every fragment twice: forward 330 -> 277 us, backward 1 108 -> 995 us at
+// B = 16 (tools/flash_x3_bench.py). Taken for head_dim <= 64 when blocks of 128 queries still fill the chip twice over (fx_nt); a query's arithmetic is the same in both forms
+// (test_flash_attention_x3_two_tiles_per_wave_changes_no_bit). The key-stationary dK / dV kernel stays at one tile: K, V fragments and two accumulator sets per tile need 376
+// registers for two (one wave per SIMD; measured slower).
+template <int HD, int NT>
+__global__ __launch_bounds__(FX_THREADS) void fx_fwd2_kernel(const FxArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * HD * 2, XQB = XQ * NT;
+    char* Kh = smem; char* Kl = smem + TB;                  // rows images [64 keys][HD]
+    char* Vh = smem + 2 * TB; char* Vl = smem + 3 * TB;     // transposed [HD][64 keys]
+    float* ldsB = reinterpret_cast<float*>(smem + 4 * TB);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
+    int rb_, h, b;
+    grid_map3(rb_, h, b);
+    const int q0 = rb_ * XQB;
+    const XView w = xview(p, b);
+    if (q0 >= w.Sq) return;                                    // packed rows: a shorter sequence than the longest one
+    const float* Q = p.q + b * p.q_sb + w.qrow * p.q_ss + h * HD;
+    const float* K = p.k + b * p.k_sb + w.krow * p.k_ss + h * HD;
+    const float* V = p.v + b * p.v_sb + w.krow * p.v_ss + h * HD;
+    constexpr int KS = HD / 32, DT = HD / 16;
+    int myq[NT];
+    bf16x8 qh[NT][KS], ql[NT][KS];
+    f32x4 oacc[NT][DT];
+    float m[NT], l[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        myq[n] = q0 + (wave * NT + n) * 16 + lr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xfrag_global(Q, p.q_ss, myq[n], w.Sq, ks * 32 + g * 8, qh[n][ks], ql[n][ks]);
+#pragma unroll
+        for (int i = 0; i < DT; ++i) oacc[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m[n] = -INFINITY; l[n] = 0.f;
+    }
+    const float c = p.scale * XLOG2E;
+    const int kend = min(p.causal ? min(w.Sk, q0 + XQB) : w.Sk, w.kvis);    // key tiles behind the last visible key contribute exact zeros: skipped
+    for (int k0 = 0; k0 < kend; k0 += XK) {
+        __syncthreads();
+        xstage_rows<HD>(Kh, Kl, K + (long)k0 * p.k_ss, p.k_ss, w.Sk - k0, t);
+        xstage_transposed<HD>(Vh, Vl, V + (long)k0 * p.v_ss, p.v_ss, w.Sk - k0, t);
+        if (t < XK) {
+            const int key = k0 + t;
+            const bool vis = key < w.kvis && (w.packed || !p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f);
+            ldsB[t] = vis ? 0.f : -INFINITY;
+        }
+        __syncthreads();
+        f32x4 s[NT][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) s[n][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfh = xfrag_rows<HD>(Kh, kt * 16 + lr, ks, g), kfl = xfrag_rows<HD>(Kl, kt * 16 + lr, ks, g);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) s[n][kt] = XM3(kfh, kfl, qh[n][ks], ql[n][ks], s[n][kt]);
+            }
+        }
+        bf16x8 p0h[NT], p0l[NT], p1h[NT], p1l[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = __builtin_fmaf(s[n][kt][r], c, bias[r]);
+                    if (p.causal && (k0 + kt * 16 + g * 4 + r) > myq[n]) x = -INFINITY;
+                    s[n][kt][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+            mx = xgrp_max(mx);
+            const float mnew = fmaxf(m[n], mx);
+            const float muse = mnew == -INFINITY ? 0.f : mnew;
+            const float alpha = __builtin_amdgcn_exp2f(m[n] - muse);
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[n][kt][r] - muse); s[n][kt][r] = e; rs += e; }
+            rs = xgrp_sum(rs);
+            l[n] = __builtin_fmaf(l[n], alpha, rs);
+            m[n] = mnew;
+#pragma unroll
+            for (int i = 0; i < DT; ++i) oacc[n][i] *= alpha;
+            xpack_pair(s[n][0], s[n][1], p0h[n], p0l[n]);
+            xpack_pair(s[n][2], s[n][3], p1h[n], p1l[n]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 v0h = xfrag_perm(Vh, dt * 16 + lr, 0, g), v0l = xfrag_perm(Vl, dt * 16 + lr, 0, g);
+            const bf16x8 v1h = xfrag_perm(Vh, dt * 16 + lr, 1, g), v1l = xfrag_perm(Vl, dt * 16 + lr, 1, g);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                oacc[n][dt] = XM3(v0h, v0l, p0h[n], p0l[n], oacc[n][dt]);
+                oacc[n][dt] = XM3(v1h, v1l, p1h[n], p1l[n], oacc[n][dt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        if (myq[n] < w.Sq) {
+            const float inv = l[n] > 0.f ? 1.0f / l[n] : 0.f;
+            float* O = p.out + b * p.o_sb + (w.qrow + myq[n]) * p.o_ss + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(O + dt * 16 + g * 4) = oacc[n][dt] * inv;
+            if (g == 0) p.lse[((long)b * p.H + h) * p.Sq + myq[n]] = l[n] > 0.f ? (m[n] + log2f(l[n])) / XLOG2E : INFINITY;
+        }
+}
+
+template <int HD, int NT>
+__global__ __launch_bounds__(FX_THREADS) void fx_bwd_dq2_kernel(const FxArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * HD * 2, XQB = XQ * NT;              // NT query tiles of 16 per wave (see fx_fwd2_kernel)
+    char* Kh = smem;           char* Kl = smem + TB;
+    char* KTh = smem + 2 * TB; char* KTl = smem + 3 * TB;
+    char* Vh = smem + 4 * TB;  char* Vl = smem + 5 * TB;
+    float* ldsB = reinterpret_cast<float*>(smem + 6 * TB);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
+    int rb_, h, b;
+    grid_map3(rb_, h, b);
+    const int q0 = rb_ * XQB;
+    const XView w = xview(p, b);
+    if (q0 >= w.Sq) return;                                    // packed rows: a shorter sequence than the longest one
+    const float* Q = p.q + b * p.q_sb + w.qrow * p.q_ss + h * HD;
+    const float* K = p.k + b * p.k_sb + w.krow * p.k_ss + h * HD;
+    const float* V = p.v + b * p.v_sb + w.krow * p.v_ss + h * HD;
+    const float* DO = p.dout + b * p.o_sb + w.qrow * p.o_ss + h * HD;
+    constexpr int KS = HD / 32, DT = HD / 16;
+    int myq[NT];
+    bf16x8 qh[NT][KS], ql[NT][KS], oh[NT][KS], ol[NT][KS];
+    float lse[NT], dl[NT];
+    f32x4 dq[NT][DT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        myq[n] = q0 + (wave * NT + n) * 16 + lr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            xfrag_global(Q, p.q_ss, myq[n], w.Sq, ks * 32 + g * 8, qh[n][ks], ql[n][ks]);
+            xfrag_global(DO, p.o_ss, myq[n], w.Sq, ks * 32 + g * 8, oh[n][ks], ol[n][ks]);
+        }
+        const long li = ((long)b * p.H + h) * p.Sq + myq[n];
+        lse[n] = myq[n] < w.Sq ? p.lse[li] * XLOG2E : INFINITY;
+        dl[n] = myq[n] < w.Sq ? p.delta[li] : 0.f;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) dq[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c = p.scale * XLOG2E;
+    const int kend = min(p.causal ? min(w.Sk, q0 + XQB) : w.Sk, w.kvis);    // key tiles behind the last visible key contribute exact zeros: skipped
+    for (int k0 = 0; k0 < kend; k0 += XK) {
+        __syncthreads();
+        xstage_both<HD>(Kh, Kl, KTh, KTl, K + (long)k0 * p.k_ss, p.k_ss, w.Sk - k0, t);
+        xstage_rows<HD>(Vh, Vl, V + (long)k0 * p.v_ss, p.v_ss, w.Sk - k0, t);
+        if (t < XK) {
+            const int key = k0 + t;
+            ldsB[t] = (key < w.kvis && (w.packed || !p.key_mask || p.key_mask[(long)b * p.Sk + key] != 0.f)) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        f32x4 s[NT][4], dp[NT][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { s[n][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[n][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfh = xfrag_rows<HD>(Kh, kt * 16 + lr, ks, g), kfl = xfrag_rows<HD>(Kl, kt * 16 + lr, ks, g);
+                const bf16x8 vfh = xfrag_rows<HD>(Vh, kt * 16 + lr, ks, g), vfl = xfrag_rows<HD>(Vl, kt * 16 + lr, ks, g);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    s[n][kt] = XM3(kfh, kfl, qh[n][ks], ql[n][ks], s[n][kt]);
+                    dp[n][kt] = XM3(vfh, vfl, oh[n][ks], ol[n][ks], dp[n][kt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f32x4 vis4 = *reinterpret_cast<const f32x4*>(ldsB + kt * 16 + g * 4);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + g * 4 + r;
+                    const bool vis = vis4[r] != 0.f && (!p.causal || key <= myq[n]);
+                    const float pr = vis ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[n][kt][r], c, -lse[n])) : 0.f;
+                    dp[n][kt][r] = xds(pr, dp[n][kt][r], dl[n], p.scale);
+                }
+        }
+        bf16x8 d0h[NT], d0l[NT], d1h[NT], d1l[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { xpack_pair(dp[n][0], dp[n][1], d0h[n], d0l[n]); xpack_pair(dp[n][2], dp[n][3], d1h[n], d1l[n]); }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 k0h = xfrag_perm(KTh, dt * 16 + lr, 0, g), k0l = xfrag_perm(KTl, dt * 16 + lr, 0, g);
+            const bf16x8 k1h = xfrag_perm(KTh, dt * 16 + lr, 1, g), k1l = xfrag_perm(KTl, dt * 16 + lr, 1, g);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                dq[n][dt] = XM3(k0h, k0l, d0h[n], d0l[n], dq[n][dt]);
+                dq[n][dt] = XM3(k1h, k1l, d1h[n], d1l[n], dq[n][dt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        if (myq[n] < w.Sq) {
+            float* DQ = p.dq + b * p.dq_sb + (w.qrow + myq[n]) * p.dq_ss + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(DQ + dt * 16 + g * 4) = dq[n][dt];
+        }
+}
+
 int xcheck(const char* who, int hd, const long* st, int n) {
     PB_REQUIRE(hd == 32 || hd == 64 || hd == 128, "%s: head_dim %d (32 / 64 / 128)", who, hd);
     for (int i = 0; i < n; ++i) PB_REQUIRE(st[i] % 4 == 0, "%s: strides must be multiples of 4 elements (16-byte f32 rows)", who);
@@ -496,6 +721,8 @@ int xcheck(const char* who, int hd, const long* st, int n) {
         case 64: { constexpr int HD = 64; __VA_ARGS__; } break; \
         default: { constexpr int HD = 128; __VA_ARGS__; } break; \
     }
+
+static int fx_nt(int hd, int B, int H, int Sq) { return (hd <= 64 && (long)B * H * ((Sq + 2 * XQ - 1) / (2 * XQ)) >= 1024) ? 2 : 1; }
 
 template <class F> int opt_in_lds(F fn, size_t bytes) {
     PB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -518,9 +745,15 @@ static int fx_fwd_impl(const float* q, const float* k, const float* v, float* o,
     if (vl) { a.vq_off = vl[0]; a.vq_len = vl[1]; a.vk_off = vl[2]; a.vk_len = vl[3]; a.vk_vis = vl[4]; }
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss;
     a.o_sb = o_sb; a.o_ss = o_ss; a.scale = scale; a.causal = causal & 1;
-    dim3 grid((Sq + XQ - 1) / XQ, H, B);
+    const int nt = fx_nt(hd, B, H, Sq);
+    dim3 grid((Sq + XQ * nt - 1) / (XQ * nt), H, B);
     const size_t lds = 4 * 64 * (size_t)hd * 2 + 256;
-    FX_DISPATCH(hd, if (opt_in_lds(&fx_fwd_kernel<HD>, lds)) return -1; hipLaunchKernelGGL((fx_fwd_kernel<HD>), grid, dim3(FX_THREADS), lds, (hipStream_t)stream_, a));
+    if (nt == 2) {
+        if (hd == 32) { if (opt_in_lds(&fx_fwd2_kernel<32, 2>, lds)) return -1; hipLaunchKernelGGL((fx_fwd2_kernel<32, 2>), grid, dim3(FX_THREADS), lds, (hipStream_t)stream_, a); }
+        else { if (opt_in_lds(&fx_fwd2_kernel<64, 2>, lds)) return -1; hipLaunchKernelGGL((fx_fwd2_kernel<64, 2>), grid, dim3(FX_THREADS), lds, (hipStream_t)stream_, a); }
+    } else {
+        FX_DISPATCH(hd, if (opt_in_lds(&fx_fwd_kernel<HD>, lds)) return -1; hipLaunchKernelGGL((fx_fwd_kernel<HD>), grid, dim3(FX_THREADS), lds, (hipStream_t)stream_, a));
+    }
     PB_LAUNCH_CHECK();
     return 0;
 }
@@ -544,11 +777,17 @@ static int fx_bwd_impl(const float* q, const float* k, const float* v, const flo
     const long nrow = (long)B * H * Sq;
     FX_DISPATCH(hd, hipLaunchKernelGGL((fx_delta_kernel<HD>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, stream, o, dout, delta, B, H, Sq, (long)o_sb, (long)o_ss, vl ? vl[0] : nullptr, vl ? vl[1] : nullptr));
     PB_LAUNCH_CHECK();
-    dim3 gk((Sk + XK - 1) / XK, H, B), gq((Sq + XQ - 1) / XQ, H, B);
+    const int nt = fx_nt(hd, B, H, Sq);
+    dim3 gk((Sk + XK - 1) / XK, H, B), gq((Sq + XQ * nt - 1) / (XQ * nt), H, B);
     const size_t lds_kv = 8 * 64 * (size_t)hd * 2 + 512, lds_q = 6 * 64 * (size_t)hd * 2 + 256;
     FX_DISPATCH(hd, if (opt_in_lds(&fx_bwd_dkv_kernel<HD>, lds_kv)) return -1; hipLaunchKernelGGL((fx_bwd_dkv_kernel<HD>), gk, dim3(FX_THREADS), lds_kv, stream, a));
     PB_LAUNCH_CHECK();
-    FX_DISPATCH(hd, if (opt_in_lds(&fx_bwd_dq_kernel<HD>, lds_q)) return -1; hipLaunchKernelGGL((fx_bwd_dq_kernel<HD>), gq, dim3(FX_THREADS), lds_q, stream, a));
+    if (nt == 2) {
+        if (hd == 32) { if (opt_in_lds(&fx_bwd_dq2_kernel<32, 2>, lds_q)) return -1; hipLaunchKernelGGL((fx_bwd_dq2_kernel<32, 2>), gq, dim3(FX_THREADS), lds_q, stream, a); }
+        else { if (opt_in_lds(&fx_bwd_dq2_kernel<64, 2>, lds_q)) return -1; hipLaunchKernelGGL((fx_bwd_dq2_kernel<64, 2>), gq, dim3(FX_THREADS), lds_q, stream, a); }
+    } else {
+        FX_DISPATCH(hd, if (opt_in_lds(&fx_bwd_dq_kernel<HD>, lds_q)) return -1; hipLaunchKernelGGL((fx_bwd_dq_kernel<HD>), gq, dim3(FX_THREADS), lds_q, stream, a));
+    }
     PB_LAUNCH_CHECK();
     return 0;
 }

@@ -833,3 +833,34 @@ def test_flash_attention_x3_fwd_bwd(ops, hd, causal, S):
     ops.flash_fwd_x3(sl(0), sl(d), sl(2 * d), (out2, 0, d, S * d), lse2, km, B, H, S, S, hd, scale, causal, kmax=kmax)
     ops.flash_bwd_x3(sl(0), sl(d), sl(2 * d), (out2, 0, d, S * d), dout, lse2, km, d2(0), d2(d), d2(2 * d), delta, B, H, S, S, hd, scale, causal, kmax=kmax)
     assert torch.equal(out, out2) and torch.equal(lse, lse2) and torch.equal(dqkv, dqkv2)
+
+
+@pytest.mark.parametrize('hd', [32, 64])
+@pytest.mark.parametrize('causal', [False, True])
+def test_flash_attention_x3_two_tiles_per_wave_changes_no_bit(ops, hd, causal):
+    """The query-stationary split-bf16 kernels (forward, dQ) give a wave TWO 16-query tiles -- blocks of 128 queries -- once the grid is large enough
+    (pb_flash_x3.hip fx_nt: head_dim <= 64 and >= 1024 workgroups; every staged K / V fragment is then used twice). A query's arithmetic does not depend on the
+    blocking: the whole batch (large grid, two tiles per wave) equals its batch rows run one at a time (small grids, one tile per wave) bit for bit -- ragged
+    key masks, causal (the 128-query block visits a key tile more, fully masked for its first half)."""
+    g = torch.Generator(device='cuda').manual_seed(7 + hd)
+    B, H, S = 8, 16, 1000                       # 8 x 16 x ceil(1000 / 128) = 1024 workgroups of 128 queries
+    d = H * hd
+    qkv = torch.randn(B, S, 3 * d, device='cuda', generator=g)
+    km = (torch.rand(B, S, device='cuda', generator=g) > 0.2).float()
+    km[1, S // 3:] = 0
+    dout = torch.randn(B, S, d, device='cuda', generator=g)
+    scale = hd ** -0.5
+
+    def run(qkv_, km_, dout_, Bn):
+        out = torch.full((Bn, S, d), float('nan'), device='cuda'); lse = torch.empty(Bn, H, S, device='cuda')
+        dqkv = torch.full((Bn, S, 3 * d), float('nan'), device='cuda'); delta = torch.empty(Bn, H, S, device='cuda')
+        sl = lambda off: (qkv_, off, 3 * d, S * 3 * d)
+        dsl = lambda off: (dqkv, off, 3 * d, S * 3 * d)
+        ops.flash_fwd_x3(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), lse, km_, Bn, H, S, S, hd, scale, causal)
+        ops.flash_bwd_x3(sl(0), sl(d), sl(2 * d), (out, 0, d, S * d), dout_, lse, km_, dsl(0), dsl(d), dsl(2 * d), delta, Bn, H, S, S, hd, scale, causal)
+        return out, lse, dqkv
+    out, lse, dqkv = run(qkv, km, dout, B)
+    assert torch.isfinite(out).all() and torch.isfinite(dqkv).all()
+    for b in range(B):
+        o1, l1, g1 = run(qkv[b:b + 1].contiguous(), km[b:b + 1].contiguous(), dout[b:b + 1].contiguous(), 1)
+        assert torch.equal(o1[0], out[b]) and torch.equal(l1[0], lse[b]) and torch.equal(g1[0], dqkv[b]), b
