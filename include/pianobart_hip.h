@@ -282,6 +282,10 @@ int pb_adamw_step(float* p, const float* g, float* m, float* v, void* shadow /*b
                   const float* clip_coef /*device, may be NULL*/, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, void* stream);
 int pb_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* x (n f32, n % 8 == 0) -> hi = bf16(x), lo = bf16(x - hi): the two planes of the split-bf16 arithmetic (precision="bf16x3") as separate arrays, for products whose
+ * other operand is exact in bf16 (the one-hot matrix of the embedding-table gradient: Onehot^T dz = Onehot^T dz_hi + Onehot^T dz_lo). Replaces nothing in the
+ * reference: torch.nn.Embedding's backward (index_add in f32) is what the pair of GEMMs computes. */
+int pb_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
 int pb_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 int pb_fill_f32(float* dst, float value, int64_t n, void* stream);
 /* Transposed copies of the weight matrices inside the flat bf16 shadow: table (device, n_matrices x 4 int32) = {element offset, R, C,

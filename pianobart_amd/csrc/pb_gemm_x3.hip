@@ -282,3 +282,33 @@ int pb_gemm_x3(const pb_gemm_desc* d, void* stream_) {
     if (d->colsum_out) return pb_colsum(d->C, d->ldc, d->colsum_out, d->colsum_ws, d->M, d->N, PB_F32, 1, stream_);
     return 0;
 }
+
+// x (n f32) -> hi = bf16(x), lo = bf16(x - hi) as two separate bf16 arrays (n % 8 == 0, 16-byte aligned). For products whose OTHER operand is exact in bf16
+// (the one-hot matrix of the embedding-table gradient): A x = A x_hi + A x_lo, two plain bf16 GEMMs, the second accumulating.
+namespace {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + 8 * i), b = *reinterpret_cast<const f32x4*>(x + 8 * i + 4);
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16_t h0, l0, h1, l1;
+            split1(a[j], h0, l0); split1(b[j], h1, l1);
+            h[j] = h0; l[j] = l0; h[4 + j] = h1; l[4 + j] = l1;
+        }
+        *reinterpret_cast<bf16x8*>(hi + 8 * i) = h;
+        *reinterpret_cast<bf16x8*>(lo + 8 * i) = l;
+    }
+}
+}  // namespace
+
+extern "C" int pb_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+    PB_REQUIRE(x && hi && lo && n >= 0 && n % 8 == 0, "pb_split_bf16: n must be a multiple of 8");
+    PB_REQUIRE(((uintptr_t)x | (uintptr_t)hi | (uintptr_t)lo) % 16 == 0, "pb_split_bf16: operands must be 16-byte aligned");
+    if (n == 0) return 0;
+    const long n8 = n / 8;
+    const int grid = (int)std::min<long>(4096, (n8 + 255) / 256);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n8);
+    PB_LAUNCH_CHECK();
+    return 0;
+}

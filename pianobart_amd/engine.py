@@ -373,7 +373,9 @@ class Engine:
                   scores=None if self.use_flash else f(B, H, S, S), dS=None if self.use_flash else e(B, H, S, S), delta=f(B, H, S),
                   gy=[e(T, d), e(T, d)], gA=e(T, d), gB=e(T, d), gC=e(T, d), dqkv=e(T, 3 * d), dq=e(T, d),
                   du=e(T, max(self.fe, self.fd)), genc=e(T, d), dlogits=e(T, ops.VOCAB) if self.mlm is not None else None,
-                  dz=e(2 * T, d) if self.code == PB_BF16 else None, onehot=e(2 * T, ops.TAB_TOTAL) if self.code == PB_BF16 else None)
+                  dz=e(2 * T, d) if (self.code == PB_BF16 or self.x3) else None,
+                  onehot=torch.empty(2 * T, ops.TAB_TOTAL, dtype=torch.bfloat16, device=self.device) if (self.code == PB_BF16 or self.x3) else None,
+                  dz_planes=torch.empty(2, 2 * T, d, dtype=torch.bfloat16, device=self.device) if self.x3 else None)    # bf16x3: dz cut into (hi, lo) for the one-hot GEMMs
         ws['Te'] = ws['Td'] = T
         self._ws_cache = {key: ws}          # keep one shape resident
         return ws
@@ -855,7 +857,7 @@ class Engine:
         emask, dmask = sv['emask'], sv['dmask']
         gy, galt = (t[:Td] for t in ws['gy'])
         genc = ws['genc'][:Te]
-        onehot_route = self.code == PB_BF16 and Te % 64 == 0 and Td % 64 == 0
+        onehot_route = (self.code == PB_BF16 or self.x3) and Te % 64 == 0 and Td % 64 == 0      # dP = Onehot^T dz on the matrix cores, no atomics (bf16x3: dz as two bf16 planes, two GEMMs)
         dec_tab_done = None                                  # event: the decoder tokens' half of dP has been written
         base = ws.get('_base', ws)
         if not _NO_DEFER:
@@ -1016,8 +1018,21 @@ class Engine:
         need = 16 * ops.TAB_TOTAL * d
         if self._slabs_oh[which] is None:
             self._slabs_oh[which] = torch.empty(need, dtype=torch.float32, device=self.device)
-        launch = lambda: ops.gemm(onehot, dz, self.dptab, M=ops.TAB_TOTAL, N=d, K=K, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.TAB_TOTAL, ldb=d,
-                                  dbg=self._bwd_dbg(), ldc=d, c_f32=True, accum=accum, splitk=16, slabs=self._slabs_oh[which], tile256=True)
+        one = lambda b, acc: ops.gemm(onehot, b, self.dptab, M=ops.TAB_TOTAL, N=d, K=K, dtype=PB_BF16, a_kc=False, b_kc=False, lda=ops.TAB_TOTAL, ldb=d,
+                                      dbg=self._bwd_dbg(), ldc=d, c_f32=True, accum=acc, splitk=16, slabs=self._slabs_oh[which], tile256=True)
+        if self.x3:
+            # the one-hot matrix is exact in bf16, so the split-bf16 product is Onehot^T dz_hi + Onehot^T dz_lo: two bf16 GEMMs over dz's two planes (the exact-f32
+            # instantiation scatters with f32 atomics: 1.4 ms per side at B = 16 and a summation order that changes from run to run)
+            planes = self._cur_ws.get('_base', self._cur_ws)['dz_planes']
+            r0 = (dz.data_ptr() - self._cur_ws.get('_base', self._cur_ws)['dz'].data_ptr()) // (4 * d)
+            hi, lo = planes[0, r0:r0 + K], planes[1, r0:r0 + K]
+
+            def launch():
+                ops.split_bf16(dz[:K], hi, lo)
+                one(hi, accum)
+                one(lo, True)
+        else:
+            launch = lambda: one(dz, accum)
         if side and (_WGRAD_STREAM & 1) and self._side_stream() is not None:
             self._event().wait_on(self._side)
             with torch.cuda.stream(self._side):

@@ -134,6 +134,11 @@ def embed_ln_bwd(dy, ids16, P, lin_bias, pos, ln_w, mean, rstd, dP, dpos, dbias,
              p_drop, _stream())
 
 
+def split_bf16(x, hi, lo):
+    """x (f32) -> hi = bf16(x), lo = bf16(x - hi) (pb_split_bf16)."""
+    LIB.call('pb_split_bf16', _p(x), _p(hi), _p(lo), x.numel(), _stream())
+
+
 def onehot_build(ids16, out, padded=False):
     LIB.call('pb_onehot_build', _p(ids16), _TAB9 if padded else _SEG9, _p(out), ids16.numel() // 8, TAB_TOTAL if padded else VOCAB, _stream())
 
