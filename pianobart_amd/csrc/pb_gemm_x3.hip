@@ -18,6 +18,7 @@
 #include "pb_common.h"
 #include "pb_api_internal.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -259,8 +260,10 @@ int pb_gemm_x3(const pb_gemm_desc* d, void* stream_) {
     g.sA1 = a_one * nb2; g.sA2 = a_one; g.sB1 = b_one * nb2; g.sB2 = b_one;
     g.flags = (d->flags | PB_GEMM_C_F32) & ~(PB_GEMM_GELU | PB_GEMM_MUL_GELU_GRAD);
     // few rows (the parity instantiations are run at small batches): 256 x 256 tiles would leave most CUs without a tile -- a 4096 x 768
-    // output is 48 of them on 256 CUs -- so the 128 x 128 kernel (2 workgroups per CU) takes every unsplit problem below ~2/3 of a round
-    if (d->splitk <= 1 && nbt == 1 && (long)((d->M + 255) / 256) * ((d->N + 255) / 256) < 160) g.flags |= PB_GEMM_TILE128;
+    // output is 48 of them on 256 CUs -- so the 128 x 128 kernel (2 workgroups per CU) takes every unsplit problem below HALF a round of 256 x 256 tiles.
+    // Measured at the cfg-2 model (tools/x3_ab.sh, same box; the threshold was 160 until late in round 6): 45 tiles (B = 4) 45.5 ms on the small tiles against 46.7, 81 tiles (B = 8) 65.9 / 67.0,
+    // 156 tiles (B = 16) 108.2 / 99.2 -- the ping-pong kernel at 61 % of a round beats the small-tile kernel at 1.2 rounds
+    if (d->splitk <= 1 && nbt == 1 && (long)((d->M + 255) / 256) * ((d->N + 255) / 256) < 128) g.flags |= PB_GEMM_TILE128;
     g.aux_in = nullptr; g.aux_out = nullptr;
     g.colsum_out = nullptr; g.colsum_ws = nullptr;               // taken from the finished C below
     const int rc = pb_gemm(&g, stream_);
