@@ -715,6 +715,20 @@ def test_one_pass_backward_masked_keys_with_a_very_negative_log_sum_exp(ops):
     assert float(dbuf[..., d:].double()[(km == 0)[..., None].expand(B, S, 2 * d)].abs().max()) == 0.0     # masked keys: zero dK / dV rows
 
 
+def test_split_bf16_planes(ops):
+    """pb_split_bf16 (round 6): x -> hi = bf16(x) (round to nearest even, what torch's cast gives), lo = bf16(x - hi); hi + lo restores x to 2^-17 relative -- the two planes the
+    bf16x3 embedding-table gradient feeds to its pair of one-hot GEMMs."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(1024, 264, device='cuda', generator=g) * torch.logspace(-6, 3, 264, device='cuda')
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-38, 65504.0], device='cuda')
+    hi = torch.full(x.shape, float('nan'), device='cuda', dtype=torch.bfloat16); lo = torch.full_like(hi, float('nan'))
+    ops.split_bf16(x, hi, lo)
+    assert torch.equal(hi, x.to(torch.bfloat16))
+    assert torch.equal(lo, (x - hi.float()).to(torch.bfloat16))
+    err = ((hi.double() + lo.double()) - x.double()).abs() / x.double().abs().clamp(min=1e-30)
+    assert float(err[x.abs() > 1e-30].max()) < 2.0 ** -16
+
+
 @pytest.mark.parametrize('M,N,K,akc,bkc', [(512, 384, 256, True, True), (300, 136, 96, True, True), (2048, 768, 768, True, False), (768, 3072, 4096, False, False),
                                            (264, 72, 40, False, True), (1024, 1280, 768, True, True)])
 def test_gemm_f32x3_against_fp64(ops, M, N, K, akc, bkc):
