@@ -28,6 +28,7 @@ _WG_TARGET = 192 if _WGRAD_STREAM & 1 else 256            # split-K work items a
 _NO_DEFER = False                  # settled (round 2): True reduces every bias / LayerNorm gradient right behind its producer
 _DECODE_SPLIT = True               # settled (round 2): False = single-query attention with one workgroup per head
 _ROWDOT = int(os.environ.get('PB_ROWDOT', '1'))                                  # 1 = delta of the one-pass attention backward from the out-projection dgrad's epilogue (0: a separate pass)
+_X3_ONEHOT = int(os.environ.get('PB_X3_ONEHOT', '1'))                        # bf16x3: embedding-table gradient as two one-hot GEMMs over dz's (hi, lo) planes (0: the exact path's f32 atomics, for A/B)
 _DP_RESERVE_CUS = int(os.environ.get('PB_DP_RESERVE_CUS', '0'))                 # data parallel: 0 = backward GEMMs as ordinary grids (default: +0.45 ms at world 1, profiles/r06_dp_mode_ab.txt); n > 0 = persistent grids that leave n CUs to RCCL's kernels (+1.0 / +1.4 ms for 8 / 16)
 _SIDE_PRIORITY = int(os.environ.get('PB_SIDE_PRIORITY', '0'))                      # HIP priority of the second stream (1 = low, -1 = high; developer A/B)
 _X3_FLASH = int(os.environ.get('PB_X3_FLASH', '1'))                            # bf16x3: 1 = fused split-bf16 attention (pb_flash_*_x3), 0 = the unfused QK^T / softmax / PV chain of the exact-f32 path
@@ -857,7 +858,7 @@ class Engine:
         emask, dmask = sv['emask'], sv['dmask']
         gy, galt = (t[:Td] for t in ws['gy'])
         genc = ws['genc'][:Te]
-        onehot_route = (self.code == PB_BF16 or self.x3) and Te % 64 == 0 and Td % 64 == 0      # dP = Onehot^T dz on the matrix cores, no atomics (bf16x3: dz as two bf16 planes, two GEMMs)
+        onehot_route = (self.code == PB_BF16 or (self.x3 and _X3_ONEHOT)) and Te % 64 == 0 and Td % 64 == 0      # dP = Onehot^T dz on the matrix cores, no atomics (bf16x3: dz as two bf16 planes, two GEMMs)
         dec_tab_done = None                                  # event: the decoder tokens' half of dP has been written
         base = ws.get('_base', ws)
         if not _NO_DEFER:

@@ -363,7 +363,7 @@ def test_bf16_loss_curve_follows_the_exact_f32_curve():
 
 def test_split_bf16_loss_curve_stays_on_the_exact_f32_curve():
     """The bf16x3 parity instantiation as a TRAINING run against the exact-f32 one (same weights, batches, Philox dropout bits; tools/loss_overlay.py
-    --precision bf16x3; 200 steps at B = 8 are committed as profiles/r06_loss_overlay_bf16x3.txt: gap <= 4e-7 for 50 steps, 8e-4 at most). Here: B = 2, 24 steps."""
+    --precision bf16x3; 200 steps at B = 8 are committed as profiles/r06_loss_overlay_bf16x3.txt: gap <= 2.3e-5 for 50 steps, 9e-4 to step 150). Here: B = 2, 24 steps."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     import types
